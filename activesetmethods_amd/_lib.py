@@ -1,0 +1,79 @@
+"""ctypes binding of libasmhip.so (include/asm_hip.h).  The HIP library is the product: loading fails
+loudly when it is missing - there is no CPU fallback."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libasmhip.so")
+
+OPTIMAL, INFEASIBLE, DUAL_INFEASIBLE, OTHER = 1, 2, 3, 4
+K_NAMES = ("assemble", "scale", "gemv", "syrk", "chol", "trsv")
+
+
+class SolveStats(C.Structure):
+    _fields_ = [("path", C.c_int32), ("polished", C.c_int32), ("ipm_iters", C.c_int32), ("nfact", C.c_int32),
+                ("eqp", C.c_int32), ("M", C.c_int32), ("n", C.c_int32), ("ns", C.c_int32),
+                ("ipm_pinf", C.c_double), ("ipm_dinf", C.c_double), ("ipm_gap", C.c_double),
+                ("kkt_pr", C.c_double), ("kkt_du", C.c_double), ("wall_ms", C.c_double)]
+
+
+class KernelStats(C.Structure):
+    _fields_ = [("ms", C.c_double * 6), ("calls", C.c_int64 * 6), ("flops", C.c_double * 6), ("bytes", C.c_double * 6)]
+
+
+_P = C.c_void_p
+_D = C.POINTER(C.c_double)
+_I64 = C.POINTER(C.c_int64)
+_I32 = C.POINTER(C.c_int32)
+
+PROTOTYPES = {
+    "asm_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "asm_destroy": (C.c_int, [_P]),
+    "asm_last_error": (C.c_char_p, [_P]),
+    "asm_sublp_setup": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, _I64, _I64, _D, _D, _D, _D]),
+    "asm_sublp_solve": (C.c_int, [_P, _D, _D, C.c_double, _D, _D, C.c_double, C.c_int, _D, _D, _D, _D, _D, _I32]),
+    "asm_sublp_upload": (C.c_int, [_P, _D, _D, C.c_double, _D, _D]),
+    "asm_sublp_solve_resident": (C.c_int, [_P, C.c_double, C.c_int, _D, _D, _D, _D, _D, _I32]),
+    "asm_sublp_active_set": (C.c_int, [_P, _I32, _I32, _I32, _I64, _I64]),
+    "asm_sublp_reset_warm": (C.c_int, [_P]),
+    "asm_sublp_last_stats": (C.c_int, [_P, C.POINTER(SolveStats)]),
+    "asm_kernel_stats_get": (C.c_int, [_P, C.POINTER(KernelStats)]),
+    "asm_kernel_stats_reset": (C.c_int, [_P]),
+    "asm_kt_residuals": (C.c_int, [_P, _D, _D, _D, _D, _D]),
+    "asm_jac_row_norms": (C.c_int, [_P, _D]),
+    "asm_test_syrk": (C.c_int, [_P, _D, C.c_int64, C.c_int64, _I32, C.c_int64, _D, _D, _D, C.c_int]),
+    "asm_test_cholesky": (C.c_int, [_P, _D, C.c_int64, _D]),
+    "asm_test_chol_solve": (C.c_int, [_P, _D, C.c_int64, _D, _D]),
+    "asm_test_gemv": (C.c_int, [_P, _D, C.c_int64, C.c_int64, _D, _D, _D, _D]),
+    "asm_test_assemble": (C.c_int, [_P, _D, _D]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libasmhip.so and bind every symbol include/asm_hip.h declares."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(make -C activesetmethods_amd/csrc).  There is no CPU fallback." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)      # AttributeError here = ABI drift, fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def dptr(a):
+    return a.ctypes.data_as(_D)
+
+
+def i64ptr(a):
+    return a.ctypes.data_as(_I64)
+
+
+def i32ptr(a):
+    return a.ctypes.data_as(_I32)

@@ -1,0 +1,1308 @@
+// libasmhip: host-side solver logic + C ABI (include/asm_hip.h) above the gfx950 kernels in
+// asm_kernels.hip.h.  The algorithm (scaling -> warm active-set verify -> Mehrotra IPM in Schur form ->
+// partition identification -> active-set Schur/Cholesky polish) is specified in DESIGN.md; reference
+// citations for the formulation are given at each step (file:line under the reference tree).
+//
+// Round-1 split of work: every O(M*n) and O(M^3) operation (assembly, scaling, Ah x, Ah' y, the Schur
+// SYRK, the Cholesky factorisation and the triangular solves) runs on the GPU; the O(M+n) vector
+// algebra between them runs on the host and exchanges vectors through pinned staging buffers.
+#include "asm_kernels.hip.h"
+#include "../../include/asm_hip.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace {
+
+const double INF = std::numeric_limits<double>::infinity();
+const double TOL_P = 1e-9, TOL_D = 1e-6;
+const int IPM_MAXIT = 60;
+
+struct HipError : std::runtime_error {
+    explicit HipError(const std::string& s) : std::runtime_error(s) {}
+};
+#define HIPCHK(expr)                                                                                     \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            throw HipError(std::string(#expr) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + ":" +   \
+                           std::to_string(__LINE__) + ")");                                              \
+    } while (0)
+
+inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+inline double pow2_round(double x) {
+    if (!(x > 0.0)) return 1.0;
+    int e;
+    double f = std::frexp(x, &e);
+    if (f < 0.70710678118654752) e -= 1;
+    return std::ldexp(1.0, e);
+}
+
+typedef std::vector<double> vec;
+typedef std::vector<int8_t> ivec;
+
+struct ActiveSet {
+    ivec rowst, bst, sst;
+    bool valid = false;
+};
+
+struct TimedRegion {
+    hipEvent_t a, b;
+    int kind;
+};
+
+}  // namespace
+
+struct asm_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool setup_done = false, inputs_ready = false;
+
+    // ---- problem (subproblem.jl:51-215) ----
+    int64_t n = 0, m = 0, nnz = 0, nadj = 0, M = 0, Mp = 0, ldn = 0, ns = 0;
+    vec c_lb, c_ub, v_lb, v_ub;
+    std::vector<int> kind;          // 0 EQ, 2 range, +1 lower only, -1 upper only
+    std::vector<int64_t> adj;       // rows with two distinct finite bounds
+    std::vector<int> rtype;         // LP row types (M)
+    std::vector<int> srow;          // slack -> LP row
+    vec scoef;                      // slack coefficient (+1 / -1)
+    std::vector<int64_t> sown;      // slack -> original row (for p_slack)
+    std::vector<int> nslack;        // slacks per original row (1 or 2)
+
+    // ---- assembly plan ----
+    int64_t nu = 0;
+    bool dense_fast = false;
+    int64_t *d_perm = nullptr, *d_ustart = nullptr, *d_uoff = nullptr, *d_adjoff = nullptr;
+
+    // ---- device buffers ----
+    double *d_dE = nullptr, *d_J = nullptr, *d_Ah = nullptr, *d_S = nullptr;
+    double *d_c = nullptr, *d_rho = nullptr, *d_theta = nullptr, *d_diag = nullptr, *d_diag0 = nullptr;
+    double *d_vecN = nullptr, *d_vecM = nullptr, *d_vecM2 = nullptr, *d_part = nullptr, *d_partial = nullptr;
+    int* d_idx = nullptr;
+    double* h_pin = nullptr;        // pinned staging (max(ldn, Mp) doubles) x 2
+    int64_t pin_len = 0;
+
+    // ---- host copies of the evaluation results (slp.jl:8-21) ----
+    vec df, E, x_k;
+    double f = 0.0;
+
+    // ---- warm start (retained active set per phase; GLPK keeps its basis, slp.jl:38-40) ----
+    ActiveSet warm[2];
+    ActiveSet last;
+    asm_solve_stats stats;
+
+    // ---- kernel timing ----
+    asm_kernel_stats kstats;
+    std::vector<TimedRegion> regions;
+    std::vector<hipEvent_t> event_pool;
+    bool timing = true;
+};
+
+namespace {
+
+// =====================================================================================================
+// device helpers
+// =====================================================================================================
+struct Dev {
+    asm_handle* h;
+    explicit Dev(asm_handle* hh) : h(hh) {}
+
+    hipEvent_t get_event() {
+        if (!h->event_pool.empty()) {
+            hipEvent_t e = h->event_pool.back();
+            h->event_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        return e;
+    }
+    int begin(int kind, double flops, double bytes) {
+        h->kstats.flops[kind] += flops;
+        h->kstats.bytes[kind] += bytes;
+        h->kstats.calls[kind] += 1;
+        if (!h->timing) return -1;
+        TimedRegion r;
+        r.a = get_event();
+        r.b = get_event();
+        r.kind = kind;
+        HIPCHK(hipEventRecord(r.a, h->stream));
+        h->regions.push_back(r);
+        return (int)h->regions.size() - 1;
+    }
+    void end(int id) {
+        if (id < 0) return;
+        HIPCHK(hipEventRecord(h->regions[id].b, h->stream));
+    }
+    void resolve_timing() {
+        if (h->regions.empty()) return;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (auto& r : h->regions) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
+            h->kstats.ms[r.kind] += ms;
+            h->event_pool.push_back(r.a);
+            h->event_pool.push_back(r.b);
+        }
+        h->regions.clear();
+    }
+
+    void h2d(double* dst, const double* src, int64_t cnt, int64_t padded) {
+        double* st = h->h_pin;
+        std::memcpy(st, src, cnt * sizeof(double));
+        for (int64_t i = cnt; i < padded; ++i) st[i] = 0.0;
+        HIPCHK(hipMemcpyAsync(dst, st, padded * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));   // staging buffer is reused by the next call
+    }
+    void d2h(double* dst, const double* src, int64_t cnt) {
+        double* st = h->h_pin + h->pin_len;
+        HIPCHK(hipMemcpyAsync(st, src, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        std::memcpy(dst, st, cnt * sizeof(double));
+    }
+
+    // out[M] = A x   (A = Ah or J, M rows)
+    void gemv_n(const double* A, const double* x, double* out) {
+        h2d(h->d_vecN, x, h->n, h->ldn);
+        int id = begin(ASM_K_GEMV, 2.0 * h->M * h->n, 8.0 * h->M * h->ldn);
+        hipLaunchKernelGGL(k_gemv_n, dim3((unsigned)((h->M + 3) / 4)), dim3(256), 0, h->stream, A, h->ldn, h->d_vecN,
+                           h->d_vecM, h->M, h->ldn);
+        end(id);
+        d2h(out, h->d_vecM, h->M);
+    }
+    // out[n] = A' y
+    void gemv_t(const double* A, const double* y, double* out) {
+        h2d(h->d_vecM, y, h->M, h->Mp);
+        int64_t R = (h->M + ASM_TCHUNK - 1) / ASM_TCHUNK;
+        int id = begin(ASM_K_GEMV, 2.0 * h->M * h->n, 8.0 * h->M * h->ldn);
+        hipLaunchKernelGGL(k_gemv_t_stage1, dim3((unsigned)((h->ldn + 255) / 256), (unsigned)R), dim3(256), 0, h->stream, A,
+                           h->ldn, h->d_vecM, h->d_partial, h->M, h->ldn);
+        hipLaunchKernelGGL(k_gemv_t_stage2, dim3((unsigned)((h->ldn + 255) / 256)), dim3(256), 0, h->stream, h->d_partial,
+                           h->d_vecN, R, h->ldn);
+        end(id);
+        d2h(out, h->d_vecN, h->n);
+    }
+
+    static int pick_tile(int64_t Ms) { return Ms >= 3072 ? 4 : (Ms >= 768 ? 2 : 1); }
+
+    void launch_syrk(int T, const double* A, int64_t ld, const int* idx, int64_t row0, int Ms, int K, const double* theta,
+                     const double* diag, double* S, int64_t ldS, int64_t srow0, int mode) {
+        int TS = 32 * T;
+        int64_t nt = (Ms + TS - 1) / TS;
+        int64_t blocks = nt * (nt + 1) / 2;
+        if (blocks <= 0) return;
+        if (T == 4)
+            hipLaunchKernelGGL(k_syrk<4>, dim3((unsigned)blocks), dim3(256), 0, h->stream, A, ld, idx, row0, Ms, K, theta, diag, S,
+                               ldS, srow0, mode);
+        else if (T == 2)
+            hipLaunchKernelGGL(k_syrk<2>, dim3((unsigned)blocks), dim3(256), 0, h->stream, A, ld, idx, row0, Ms, K, theta, diag, S,
+                               ldS, srow0, mode);
+        else
+            hipLaunchKernelGGL(k_syrk<1>, dim3((unsigned)blocks), dim3(256), 0, h->stream, A, ld, idx, row0, Ms, K, theta, diag, S,
+                               ldS, srow0, mode);
+    }
+
+    // S[0:Ms,0:Ms] (lower) = Ah[idx,:] diag(theta) Ah[idx,:]' + diag     idx == nullptr -> identity
+    void syrk(const int* idx_host, int Ms, const double* theta, const double* diag) {
+        h2d(h->d_theta, theta, h->n, h->ldn);
+        if (diag) h2d(h->d_diag, diag, Ms, Ms);
+        if (idx_host) {
+            HIPCHK(hipMemcpyAsync(h->d_idx, idx_host, Ms * sizeof(int), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
+        int id = begin(ASM_K_SYRK, (double)Ms * (Ms + 1) * h->ldn, 8.0 * (Ms * (double)h->ldn + 0.5 * Ms * (double)Ms));
+        launch_syrk(pick_tile(Ms), h->d_Ah, h->ldn, idx_host ? h->d_idx : nullptr, 0, Ms, (int)h->ldn, h->d_theta,
+                    diag ? h->d_diag : nullptr, h->d_S, h->Mp, 0, 0);
+        end(id);
+    }
+    void diag_prepare(int Ms, int mode, double rel, double absv) {
+        hipLaunchKernelGGL(k_diag_prepare, dim3(1), dim3(1024), 0, h->stream, h->d_S, h->Mp, Ms, h->d_diag0, mode, rel, absv);
+    }
+    // in-place blocked right-looking Cholesky of S[0:Ms,0:Ms] (lower)
+    void chol(int Ms) {
+        int id = begin(ASM_K_CHOL, (double)Ms * Ms * Ms / 3.0, 8.0 * 1.5 * Ms * (double)Ms);
+        for (int k0 = 0; k0 < Ms; k0 += ASM_NB) {
+            int nb = std::min(ASM_NB, Ms - k0);
+            hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, h->stream, h->d_S, h->Mp, k0, nb, h->d_diag0);
+            int k1 = k0 + nb;
+            if (k1 < Ms) {
+                int rem = Ms - k1;
+                hipLaunchKernelGGL(k_trsm_panel, dim3((unsigned)((rem + 63) / 64)), dim3(64), 0, h->stream, h->d_S, h->Mp, k0, nb, Ms);
+                launch_syrk(pick_tile(rem), h->d_S + k0, h->Mp, nullptr, k1, rem, nb, nullptr, nullptr, h->d_S, h->Mp, k1, 1);
+            }
+        }
+        end(id);
+        h->stats.nfact += 1;
+    }
+    // out = (L L')^-1 rhs   (compact vectors of length Ms)
+    void chol_solve(const double* rhs, double* out, int Ms) {
+        h2d(h->d_vecM2, rhs, Ms, Ms);
+        int id = begin(ASM_K_TRSV, 2.0 * Ms * (double)Ms, 8.0 * Ms * (double)Ms);
+        double* z = h->d_vecM;
+        for (int k0 = 0; k0 < Ms; k0 += ASM_NB) {
+            int nb = std::min(ASM_NB, Ms - k0);
+            if (k0 > 0)
+                hipLaunchKernelGGL(k_trsv_panel_dot, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, h->stream, h->d_S, h->Mp, k0, nb, z,
+                                   h->d_part);
+            hipLaunchKernelGGL(k_trsv_diag_fwd, dim3(1), dim3(64), 0, h->stream, h->d_S, h->Mp, k0, nb, h->d_vecM2, h->d_part, z,
+                               k0 > 0 ? 1 : 0);
+        }
+        int last = ((Ms - 1) / ASM_NB) * ASM_NB;
+        for (int k0 = last; k0 >= 0; k0 -= ASM_NB) {
+            int nb = std::min(ASM_NB, Ms - k0);
+            hipLaunchKernelGGL(k_trsv_diag_bwd, dim3(1), dim3(64), 0, h->stream, h->d_S, h->Mp, k0, nb, z);
+            if (k0 > 0)
+                hipLaunchKernelGGL(k_trsv_panel_axpy, dim3((unsigned)((k0 + 255) / 256)), dim3(256), 0, h->stream, h->d_S, h->Mp, k0, nb,
+                                   z);
+        }
+        end(id);
+        d2h(out, z, Ms);
+    }
+
+    // COO values (device resident) -> dense J incl. the extra range rows (common.jl:12-20, subproblem.jl:438-457)
+    void assemble() {
+        int id = begin(ASM_K_ASSEMBLE, 0.0, 8.0 * h->nnz + 8.0 * h->nu + (h->dense_fast ? 0.0 : 24.0 * h->nu + 8.0 * h->nnz));
+        if (h->dense_fast) {
+            int64_t total = h->m * h->n;
+            unsigned g = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
+            hipLaunchKernelGGL(k_assemble_dense, dim3(g), dim3(256), 0, h->stream, h->d_dE, h->d_J, h->m, h->n, h->ldn);
+        } else if (h->nu > 0) {
+            unsigned g = (unsigned)std::min<int64_t>((h->nu + 255) / 256, 4096);
+            hipLaunchKernelGGL(k_assemble, dim3(g), dim3(256), 0, h->stream, h->d_dE, h->d_perm, h->d_ustart, h->d_uoff,
+                               h->d_adjoff, h->d_J, h->nu);
+        }
+        end(id);
+    }
+    // Ah = diag(1/rho) J diag(c);  rho (host, M)
+    void scale(const double* c, double* rho) {
+        h2d(h->d_c, c, h->n, h->ldn);
+        int id = begin(ASM_K_SCALE, 0.0, 8.0 * 3.0 * h->M * h->ldn);
+        hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)h->M), dim3(256), 0, h->stream, h->d_J, h->d_c, h->d_Ah, h->d_rho, h->n,
+                           h->ldn);
+        end(id);
+        d2h(rho, h->d_rho, h->M);
+    }
+};
+
+// =====================================================================================================
+// LP in scaled units (oracle/lp_solver.py: class LP / scale_lp)
+// =====================================================================================================
+struct SLP {
+    int64_t n, M, ns;
+    vec q, r, lb, ub, w, slo;
+    const int* rtype;
+    const int* srow;
+    const double* scoef;
+    double scale_q;
+};
+
+struct Solver {
+    asm_handle* h;
+    Dev dev;
+    SLP lp;
+    vec tmpM, tmpN;
+
+    explicit Solver(asm_handle* hh) : h(hh), dev(hh) {}
+
+    // t = Ah p + E s
+    void rowact(const vec& p, const vec& s, vec& t) {
+        t.resize(lp.M);
+        dev.gemv_n(h->d_Ah, p.data(), t.data());
+        for (int64_t k = 0; k < lp.ns; ++k) t[lp.srow[k]] += lp.scoef[k] * s[k];
+    }
+    void atv(const vec& y, vec& out) {
+        out.resize(lp.n);
+        dev.gemv_t(h->d_Ah, y.data(), out.data());
+    }
+
+    // ---------------------------------------------------------------- interior point (oracle: class IPM)
+    struct IpmState {
+        vec p, s, g, y, tL, tU, muL, muU, ts, mus, pi, rp, rdp, rds;
+        std::vector<char> ineq, free_;
+        vec sg;
+        int64_t ncomp = 1;
+        int iters = 0;
+        int status = ASM_OTHER;
+        double mu = 0, pinf = 0, dinf = 0, gap = 0;
+    } ip;
+
+    void ipm_init() {
+        const int64_t n = lp.n, M = lp.M, ns = lp.ns;
+        ip = IpmState();
+        ip.ineq.resize(M);
+        ip.sg.resize(M);
+        ip.free_.resize(n);
+        int64_t nfree = 0, nineq = 0;
+        for (int64_t i = 0; i < M; ++i) {
+            ip.ineq[i] = lp.rtype[i] != 0;
+            ip.sg[i] = (double)lp.rtype[i];
+            nineq += ip.ineq[i];
+        }
+        for (int64_t j = 0; j < n; ++j) {
+            ip.free_[j] = lp.ub[j] > lp.lb[j];
+            nfree += ip.free_[j];
+        }
+        ip.p.resize(n);
+        for (int64_t j = 0; j < n; ++j) ip.p[j] = 0.5 * (lp.lb[j] + lp.ub[j]);
+        ip.s.resize(ns);
+        for (int64_t k = 0; k < ns; ++k) ip.s[k] = lp.slo[k] + 1.0;
+        vec act;
+        rowact(ip.p, ip.s, act);
+        ip.g.resize(M);
+        for (int64_t i = 0; i < M; ++i) ip.g[i] = ip.ineq[i] ? std::max(ip.sg[i] * (act[i] - lp.r[i]), 1.0) : 1.0;
+        double mu0 = lp.scale_q;
+        ip.tL.resize(n); ip.tU.resize(n); ip.muL.resize(n); ip.muU.resize(n);
+        for (int64_t j = 0; j < n; ++j) {
+            ip.tL[j] = ip.free_[j] ? ip.p[j] - lp.lb[j] : 1.0;
+            ip.tU[j] = ip.free_[j] ? lp.ub[j] - ip.p[j] : 1.0;
+            ip.muL[j] = ip.free_[j] ? mu0 / ip.tL[j] : 0.0;
+            ip.muU[j] = ip.free_[j] ? mu0 / ip.tU[j] : 0.0;
+        }
+        ip.ts.resize(ns); ip.mus.resize(ns);
+        for (int64_t k = 0; k < ns; ++k) {
+            ip.ts[k] = ip.s[k] - lp.slo[k];
+            ip.mus[k] = mu0 / ip.ts[k];
+        }
+        ip.pi.resize(M); ip.y.resize(M);
+        for (int64_t i = 0; i < M; ++i) {
+            ip.pi[i] = ip.ineq[i] ? mu0 / ip.g[i] : 0.0;
+            ip.y[i] = ip.sg[i] * ip.pi[i];
+        }
+        ip.ncomp = std::max<int64_t>(2 * nfree + ns + nineq, 1);
+    }
+
+    void ipm_measures() {
+        const int64_t n = lp.n, M = lp.M, ns = lp.ns;
+        vec act, aty;
+        rowact(ip.p, ip.s, act);
+        atv(ip.y, aty);
+        ip.rp.resize(M); ip.rdp.resize(n); ip.rds.resize(ns);
+        double pinf = 0.0, dinf = 0.0, mu = 0.0;
+        for (int64_t i = 0; i < M; ++i) {
+            ip.rp[i] = act[i] - (lp.r[i] + ip.sg[i] * (ip.ineq[i] ? ip.g[i] : 0.0));
+            pinf = std::max(pinf, std::fabs(ip.rp[i]) / (1.0 + std::fabs(lp.r[i])));
+            if (ip.ineq[i]) mu += ip.g[i] * ip.pi[i];
+        }
+        for (int64_t j = 0; j < n; ++j) {
+            ip.rdp[j] = ip.free_[j] ? lp.q[j] - aty[j] - ip.muL[j] + ip.muU[j] : 0.0;
+            dinf = std::max(dinf, std::fabs(ip.rdp[j]));
+            if (ip.free_[j]) mu += ip.tL[j] * ip.muL[j] + ip.tU[j] * ip.muU[j];
+        }
+        for (int64_t k = 0; k < ns; ++k) {
+            ip.rds[k] = lp.w[k] - lp.scoef[k] * ip.y[lp.srow[k]] - ip.mus[k];
+            dinf = std::max(dinf, std::fabs(ip.rds[k]));
+            mu += ip.ts[k] * ip.mus[k];
+        }
+        ip.mu = mu / (double)ip.ncomp;
+        ip.pinf = pinf;
+        ip.dinf = dinf / lp.scale_q;
+        ip.gap = ip.mu / lp.scale_q;
+    }
+
+    // rigorous primal-infeasibility certificate test (oracle: farkas_margin)
+    double farkas_margin(const vec& y) {
+        double ymax = 0.0;
+        for (double v : y) ymax = std::max(ymax, std::fabs(v));
+        ymax = std::max(ymax, 1e-300);
+        vec yn(lp.M), rho;
+        for (int64_t i = 0; i < lp.M; ++i) yn[i] = y[i] / ymax;
+        atv(yn, rho);
+        double cmax = -1.0, sl = 0.0;
+        for (int64_t k = 0; k < lp.ns; ++k) {
+            double coef = lp.scoef[k] * yn[lp.srow[k]];
+            cmax = std::max(cmax, coef);
+            sl += coef * lp.slo[k];
+        }
+        if (lp.ns && cmax > 1e-12) return -INF;
+        double lhs = sl, ynr = 0.0;
+        for (int64_t j = 0; j < lp.n; ++j) lhs += std::max(rho[j] * lp.lb[j], rho[j] * lp.ub[j]);
+        for (int64_t i = 0; i < lp.M; ++i) ynr += yn[i] * lp.r[i];
+        return ynr - lhs;
+    }
+
+    static double maxstep(const vec& x, const vec& dx, const std::vector<char>* mask, double sign = 1.0) {
+        double a = 1.0;
+        bool any = false;
+        for (size_t i = 0; i < x.size(); ++i) {
+            if (mask && !(*mask)[i]) continue;
+            double d = sign * dx[i];
+            if (d < 0) {
+                double v = -x[i] / d;
+                if (!any || v < a) a = v;
+                any = true;
+            }
+        }
+        return any ? std::min(1.0, a) : 1.0;
+    }
+
+    struct Dir {
+        vec dp, ds, dg, dy, dmuL, dmuU, dmus, dpi;
+    };
+
+    // one Newton solve with the current factor (oracle: IPM.run.solve)
+    void ipm_solve(const vec& thp_inv, const vec& ths_inv, const vec& rcL, const vec& rcU, const vec& rcs, const vec& rcg, Dir& d) {
+        const int64_t n = lp.n, M = lp.M, ns = lp.ns;
+        vec hp(n), hs(ns), tmp(n), rhs(M), t2;
+        for (int64_t j = 0; j < n; ++j) {
+            hp[j] = ip.free_[j] ? -ip.rdp[j] + rcL[j] / ip.tL[j] - rcU[j] / ip.tU[j] : 0.0;
+            tmp[j] = thp_inv[j] * hp[j];
+        }
+        for (int64_t k = 0; k < ns; ++k) hs[k] = -ip.rds[k] + rcs[k] / ip.ts[k];
+        dev.gemv_n(h->d_Ah, tmp.data(), rhs.data());
+        for (int64_t i = 0; i < M; ++i)
+            rhs[i] = -ip.rp[i] - rhs[i] + (ip.ineq[i] ? ip.sg[i] * rcg[i] / ip.pi[i] : 0.0);
+        if (ns) {
+            vec acc(M, 0.0);
+            for (int64_t k = 0; k < ns; ++k) acc[lp.srow[k]] += lp.scoef[k] * ths_inv[k] * hs[k];
+            for (int64_t i = 0; i < M; ++i) rhs[i] -= acc[i];
+        }
+        d.dy.resize(M);
+        dev.chol_solve(rhs.data(), d.dy.data(), (int)M);
+        atv(d.dy, t2);
+        d.dp.resize(n); d.dmuL.resize(n); d.dmuU.resize(n);
+        for (int64_t j = 0; j < n; ++j) {
+            d.dp[j] = thp_inv[j] * (hp[j] + t2[j]);
+            d.dmuL[j] = ip.free_[j] ? (rcL[j] - ip.muL[j] * d.dp[j]) / ip.tL[j] : 0.0;
+            d.dmuU[j] = ip.free_[j] ? (rcU[j] + ip.muU[j] * d.dp[j]) / ip.tU[j] : 0.0;
+        }
+        d.ds.resize(ns); d.dmus.resize(ns);
+        for (int64_t k = 0; k < ns; ++k) {
+            d.ds[k] = ths_inv[k] * (hs[k] + lp.scoef[k] * d.dy[lp.srow[k]]);
+            d.dmus[k] = (rcs[k] - ip.mus[k] * d.ds[k]) / ip.ts[k];
+        }
+        d.dpi.resize(M); d.dg.resize(M);
+        for (int64_t i = 0; i < M; ++i) {
+            d.dpi[i] = ip.ineq[i] ? ip.sg[i] * d.dy[i] : 0.0;
+            d.dg[i] = ip.ineq[i] ? (rcg[i] - ip.g[i] * d.dpi[i]) / ip.pi[i] : 0.0;
+        }
+    }
+
+    void steps(const Dir& d, double& ap, double& ad) {
+        ap = std::min(std::min(maxstep(ip.tL, d.dp, &ip.free_), maxstep(ip.tU, d.dp, &ip.free_, -1.0)),
+                      std::min(maxstep(ip.ts, d.ds, nullptr), maxstep(ip.g, d.dg, &ip.ineq)));
+        ad = std::min(std::min(maxstep(ip.muL, d.dmuL, &ip.free_), maxstep(ip.muU, d.dmuU, &ip.free_)),
+                      std::min(maxstep(ip.mus, d.dmus, nullptr), maxstep(ip.pi, d.dpi, &ip.ineq)));
+    }
+
+    int ipm_run(double tol, int max_more) {
+        const int64_t n = lp.n, M = lp.M, ns = lp.ns;
+        int done = 0;
+        while (true) {
+            ipm_measures();
+            if (ip.pinf <= tol && ip.dinf <= tol && ip.gap <= tol) return ip.status = ASM_OPTIMAL;
+            double ymax = 0.0;
+            for (double v : ip.y) ymax = std::max(ymax, std::fabs(v));
+            if (ip.iters >= 3 && ymax > 1e3 * lp.scale_q) {
+                if (farkas_margin(ip.y) > 1e-9) return ip.status = ASM_INFEASIBLE;
+            }
+            if (done >= max_more) return ip.status = ASM_OTHER;
+            vec thp_inv(n), ths_inv(ns), dS(M);
+            for (int64_t j = 0; j < n; ++j)
+                thp_inv[j] = ip.free_[j] ? 1.0 / (ip.muL[j] / ip.tL[j] + ip.muU[j] / ip.tU[j]) : 0.0;
+            for (int64_t k = 0; k < ns; ++k) ths_inv[k] = ip.ts[k] / ip.mus[k];
+            for (int64_t i = 0; i < M; ++i) dS[i] = ip.ineq[i] ? ip.g[i] / ip.pi[i] : 0.0;
+            for (int64_t k = 0; k < ns; ++k) dS[lp.srow[k]] += ths_inv[k];
+            dev.syrk(nullptr, (int)M, thp_inv.data(), dS.data());
+            dev.diag_prepare((int)M, 0, 1e-13, 1e-30);
+            dev.chol((int)M);
+            ip.iters += 1;
+            done += 1;
+
+            vec rcL(n), rcU(n), rcs(ns), rcg(M);
+            for (int64_t j = 0; j < n; ++j) { rcL[j] = -ip.tL[j] * ip.muL[j]; rcU[j] = -ip.tU[j] * ip.muU[j]; }
+            for (int64_t k = 0; k < ns; ++k) rcs[k] = -ip.ts[k] * ip.mus[k];
+            for (int64_t i = 0; i < M; ++i) rcg[i] = -ip.g[i] * ip.pi[i];
+            Dir a;
+            ipm_solve(thp_inv, ths_inv, rcL, rcU, rcs, rcg, a);
+            double ap, ad;
+            steps(a, ap, ad);
+            double mu_aff = 0.0;
+            for (int64_t j = 0; j < n; ++j)
+                if (ip.free_[j])
+                    mu_aff += (ip.tL[j] + ap * a.dp[j]) * (ip.muL[j] + ad * a.dmuL[j]) +
+                              (ip.tU[j] - ap * a.dp[j]) * (ip.muU[j] + ad * a.dmuU[j]);
+            for (int64_t k = 0; k < ns; ++k) mu_aff += (ip.ts[k] + ap * a.ds[k]) * (ip.mus[k] + ad * a.dmus[k]);
+            for (int64_t i = 0; i < M; ++i)
+                if (ip.ineq[i]) mu_aff += (ip.g[i] + ap * a.dg[i]) * (ip.pi[i] + ad * a.dpi[i]);
+            mu_aff /= (double)ip.ncomp;
+            double sig = ip.mu > 0 ? std::pow(mu_aff / ip.mu, 3.0) : 0.0;
+            double sm = sig * ip.mu;
+            for (int64_t j = 0; j < n; ++j) {
+                rcL[j] = sm - ip.tL[j] * ip.muL[j] - a.dp[j] * a.dmuL[j];
+                rcU[j] = sm - ip.tU[j] * ip.muU[j] + a.dp[j] * a.dmuU[j];
+            }
+            for (int64_t k = 0; k < ns; ++k) rcs[k] = sm - ip.ts[k] * ip.mus[k] - a.ds[k] * a.dmus[k];
+            for (int64_t i = 0; i < M; ++i) rcg[i] = sm - ip.g[i] * ip.pi[i] - a.dg[i] * a.dpi[i];
+            Dir c;
+            ipm_solve(thp_inv, ths_inv, rcL, rcU, rcs, rcg, c);
+            double eta = ip.mu >= 1.0 ? 0.995 : std::min(std::max(0.995, 1.0 - ip.mu / lp.scale_q), 0.999999);
+            steps(c, ap, ad);
+            double al = std::min(1.0, eta * std::min(ap, ad));
+            for (int64_t j = 0; j < n; ++j) {
+                ip.p[j] += al * c.dp[j];
+                ip.tL[j] = ip.free_[j] ? ip.tL[j] + al * c.dp[j] : 1.0;
+                ip.tU[j] = ip.free_[j] ? ip.tU[j] - al * c.dp[j] : 1.0;
+                ip.muL[j] += al * c.dmuL[j];
+                ip.muU[j] += al * c.dmuU[j];
+            }
+            for (int64_t k = 0; k < ns; ++k) {
+                ip.s[k] += al * c.ds[k];
+                ip.ts[k] += al * c.ds[k];
+                ip.mus[k] += al * c.dmus[k];
+            }
+            for (int64_t i = 0; i < M; ++i) {
+                ip.g[i] = ip.ineq[i] ? ip.g[i] + al * c.dg[i] : 1.0;
+                ip.pi[i] += al * c.dpi[i];
+                ip.y[i] = ip.ineq[i] ? ip.sg[i] * ip.pi[i] : ip.y[i] + al * c.dy[i];
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------- active-set machinery
+    void identify(ActiveSet& as) {
+        const int64_t n = lp.n, M = lp.M, ns = lp.ns;
+        as.rowst.assign(M, 0); as.bst.assign(n, 0); as.sst.assign(ns, 0);
+        double sq = lp.scale_q;
+        for (int64_t j = 0; j < n; ++j) {
+            if (!ip.free_[j]) { as.bst[j] = -1; continue; }
+            double width = lp.ub[j] - lp.lb[j];
+            if ((ip.tL[j] / width) < (ip.muL[j] / sq)) as.bst[j] = -1;
+            if ((ip.tU[j] / width) < (ip.muU[j] / sq)) as.bst[j] = 1;
+        }
+        for (int64_t i = 0; i < M; ++i) {
+            if (lp.rtype[i] == 0) as.rowst[i] = 1;
+            else as.rowst[i] = ((ip.g[i] / (1.0 + std::fabs(lp.r[i]))) < (ip.pi[i] / sq)) ? 1 : 0;
+        }
+        for (int64_t k = 0; k < ns; ++k) {
+            as.sst[k] = ((ip.ts[k] / (1.0 + std::fabs(lp.slo[k]))) >= (ip.mus[k] / sq)) ? 1 : 0;
+            if (as.sst[k]) as.rowst[lp.srow[k]] = 1;
+        }
+        as.valid = true;
+    }
+
+    struct EqpOut {
+        vec p, s, y, act, z;   // act = Ah p + E s ; z = q - Ah' y
+    };
+
+    // equality-constrained solve on the active set (oracle: eqp)
+    void eqp(const ActiveSet& as, const vec& p_ref, const vec& y_ref, EqpOut& o) {
+        const int64_t n = lp.n, M = lp.M, ns = lp.ns;
+        o.p.resize(n); o.s = lp.slo; o.y.assign(M, 0.0);
+        std::vector<char> soft(M, 0);
+        for (int64_t j = 0; j < n; ++j) o.p[j] = as.bst[j] < 0 ? lp.lb[j] : (as.bst[j] > 0 ? lp.ub[j] : p_ref[j]);
+        bool any_soft = false;
+        for (int64_t k = 0; k < ns; ++k)
+            if (as.sst[k] == 1) {
+                int i = lp.srow[k];
+                if (!soft[i]) { soft[i] = 1; o.y[i] = lp.w[k] * lp.scoef[k]; any_soft = true; }
+            }
+        std::vector<int> H;
+        for (int64_t i = 0; i < M; ++i) if (as.rowst[i] == 1 && !soft[i]) H.push_back((int)i);
+        int64_t nF = 0;
+        for (int64_t j = 0; j < n; ++j) nF += as.bst[j] == 0;
+        const int Ms = (int)H.size();
+        if (Ms > 0 && nF > 0) {
+            vec pB(n), t(M), sl(M, 0.0), bH(Ms), cF(n, 0.0), mask(n), tN;
+            for (int64_t j = 0; j < n; ++j) { pB[j] = as.bst[j] == 0 ? 0.0 : o.p[j]; mask[j] = as.bst[j] == 0 ? 1.0 : 0.0; }
+            dev.gemv_n(h->d_Ah, pB.data(), t.data());
+            for (int64_t k = 0; k < ns; ++k) sl[lp.srow[k]] += lp.scoef[k] * lp.slo[k];
+            for (int a = 0; a < Ms; ++a) bH[a] = lp.r[H[a]] - t[H[a]] - sl[H[a]];
+            if (any_soft) {
+                vec ys(M);
+                for (int64_t i = 0; i < M; ++i) ys[i] = soft[i] ? o.y[i] : 0.0;
+                atv(ys, tN);
+                for (int64_t j = 0; j < n; ++j) cF[j] = as.bst[j] == 0 ? lp.q[j] - tN[j] : 0.0;
+            } else {
+                for (int64_t j = 0; j < n; ++j) cF[j] = as.bst[j] == 0 ? lp.q[j] : 0.0;
+            }
+            dev.syrk(H.data(), Ms, mask.data(), nullptr);
+            dev.diag_prepare(Ms, 1, 1e-12, 0.0);
+            dev.chol(Ms);
+            vec pF(n), yH(Ms), v(Ms), u(Ms), yfull(M), rd(n);
+            for (int64_t j = 0; j < n; ++j) pF[j] = as.bst[j] == 0 ? p_ref[j] : 0.0;
+            for (int a = 0; a < Ms; ++a) yH[a] = y_ref[H[a]];
+            for (int it = 0; it < 4; ++it) {
+                dev.gemv_n(h->d_Ah, pF.data(), t.data());                       // AHF pF
+                for (int a = 0; a < Ms; ++a) v[a] = bH[a] - t[H[a]];
+                dev.chol_solve(v.data(), u.data(), Ms);
+                std::fill(yfull.begin(), yfull.end(), 0.0);
+                for (int a = 0; a < Ms; ++a) yfull[H[a]] = u[a];
+                atv(yfull, tN);                                                 // AHF' u
+                for (int64_t j = 0; j < n; ++j) if (as.bst[j] == 0) pF[j] += tN[j];
+                std::fill(yfull.begin(), yfull.end(), 0.0);
+                for (int a = 0; a < Ms; ++a) yfull[H[a]] = yH[a];
+                atv(yfull, tN);                                                 // AHF' yH
+                for (int64_t j = 0; j < n; ++j) rd[j] = as.bst[j] == 0 ? cF[j] - tN[j] : 0.0;
+                dev.gemv_n(h->d_Ah, rd.data(), t.data());                       // AHF rd
+                for (int a = 0; a < Ms; ++a) v[a] = t[H[a]];
+                dev.chol_solve(v.data(), u.data(), Ms);
+                for (int a = 0; a < Ms; ++a) yH[a] += u[a];
+            }
+            for (int64_t j = 0; j < n; ++j) if (as.bst[j] == 0) o.p[j] = pF[j];
+            for (int a = 0; a < Ms; ++a) o.y[H[a]] = yH[a];
+        } else if (Ms > 0) {
+            for (int a = 0; a < Ms; ++a) o.y[H[a]] = y_ref[H[a]];
+        }
+        // basic slack values from their tight row, then the final activities / reduced costs
+        rowact(o.p, o.s, o.act);
+        bool chg = false;
+        std::vector<char> done(M, 0);
+        for (int64_t k = 0; k < ns; ++k)
+            if (as.sst[k] == 1) {
+                int i = lp.srow[k];
+                if (!done[i]) {
+                    done[i] = 1;
+                    double snew = lp.slo[k] + (lp.r[i] - o.act[i]) / lp.scoef[k];
+                    o.act[i] += lp.scoef[k] * (snew - o.s[k]);
+                    o.s[k] = snew;
+                    chg = true;
+                }
+            }
+        (void)chg;
+        vec aty;
+        atv(o.y, aty);
+        o.z.resize(n);
+        for (int64_t j = 0; j < n; ++j) o.z[j] = lp.q[j] - aty[j];
+        h->stats.eqp += 1;
+    }
+
+    void kkt_measures(const ActiveSet& as, const EqpOut& o, double& pr, double& du) {
+        const int64_t n = lp.n, M = lp.M, ns = lp.ns;
+        pr = 0.0; du = 0.0;
+        for (int64_t i = 0; i < M; ++i) {
+            double viol = lp.rtype[i] == 0 ? std::fabs(o.act[i] - lp.r[i]) : std::max(0.0, lp.rtype[i] * (lp.r[i] - o.act[i]));
+            pr = std::max(pr, viol / (1.0 + std::fabs(lp.r[i])));
+            double y = o.y[i], dr;
+            if (as.rowst[i] == 0) dr = std::fabs(y);
+            else dr = lp.rtype[i] == 1 ? std::max(-y, 0.0) : (lp.rtype[i] == -1 ? std::max(y, 0.0) : 0.0);
+            du = std::max(du, dr);
+        }
+        for (int64_t j = 0; j < n; ++j) {
+            pr = std::max(pr, std::max(lp.lb[j] - o.p[j], 0.0));
+            pr = std::max(pr, std::max(o.p[j] - lp.ub[j], 0.0));
+            if (lp.ub[j] <= lp.lb[j]) continue;
+            double z = o.z[j];
+            double dz = as.bst[j] < 0 ? std::max(-z, 0.0) : (as.bst[j] > 0 ? std::max(z, 0.0) : std::fabs(z));
+            du = std::max(du, dz);
+        }
+        for (int64_t k = 0; k < ns; ++k) {
+            pr = std::max(pr, std::max(lp.slo[k] - o.s[k], 0.0) / (1.0 + std::fabs(lp.slo[k])));
+            double zs = lp.w[k] - lp.scoef[k] * o.y[lp.srow[k]];
+            du = std::max(du, as.sst[k] == 0 ? std::max(-zs, 0.0) : std::fabs(zs));
+        }
+        du /= lp.scale_q;
+    }
+
+    int64_t correct(const ActiveSet& as, const EqpOut& o, ActiveSet& nx) {
+        const int64_t n = lp.n, M = lp.M, ns = lp.ns;
+        nx = as;
+        double td = TOL_D * lp.scale_q;
+        int64_t nchg = 0;
+        for (int64_t i = 0; i < M; ++i) {
+            if (lp.rtype[i] == 0) continue;
+            double viol = lp.rtype[i] * (lp.r[i] - o.act[i]) / (1.0 + std::fabs(lp.r[i]));
+            if (as.rowst[i] == 1 && lp.rtype[i] * o.y[i] < -td) { nx.rowst[i] = 0; ++nchg; }
+            else if (as.rowst[i] == 0 && viol > TOL_P) { nx.rowst[i] = 1; ++nchg; }
+        }
+        for (int64_t j = 0; j < n; ++j) {
+            bool fixed = lp.ub[j] <= lp.lb[j];
+            double z = o.z[j];
+            if (!fixed && ((as.bst[j] < 0 && z < -td) || (as.bst[j] > 0 && z > td))) { nx.bst[j] = 0; ++nchg; }
+            else if (as.bst[j] == 0 && o.p[j] < lp.lb[j] - TOL_P) { nx.bst[j] = -1; ++nchg; }
+            else if (as.bst[j] == 0 && o.p[j] > lp.ub[j] + TOL_P) { nx.bst[j] = 1; ++nchg; }
+        }
+        for (int64_t k = 0; k < ns; ++k) {
+            double zs = lp.w[k] - lp.scoef[k] * o.y[lp.srow[k]];
+            if (as.sst[k] == 0 && zs < -td) { nx.sst[k] = 1; ++nchg; }
+            else if (as.sst[k] == 1 && o.s[k] < lp.slo[k] - TOL_P * (1.0 + std::fabs(lp.slo[k]))) { nx.sst[k] = 0; ++nchg; }
+        }
+        for (int64_t k = 0; k < ns; ++k) if (nx.sst[k] == 1) nx.rowst[lp.srow[k]] = 1;
+        return nchg;
+    }
+
+    static bool same(const ActiveSet& a, const ActiveSet& b) { return a.rowst == b.rowst && a.bst == b.bst && a.sst == b.sst; }
+
+    bool eqp_loop(ActiveSet as, const vec& p_ref, const vec& y_ref, int rounds, EqpOut& o, ActiveSet& out_as) {
+        ActiveSet prev;
+        bool have_prev = false;
+        for (int k = 0; k <= rounds; ++k) {
+            eqp(as, p_ref, y_ref, o);
+            double pr, du;
+            kkt_measures(as, o, pr, du);
+            h->stats.kkt_pr = pr;
+            h->stats.kkt_du = du;
+            if (pr <= TOL_P && du <= TOL_D) { out_as = as; return true; }
+            if (k == rounds) break;
+            ActiveSet nx;
+            int64_t nchg = correct(as, o, nx);
+            if (nchg == 0 || (have_prev && same(nx, prev))) break;
+            prev = as; have_prev = true;
+            as = nx;
+        }
+        out_as = as;
+        return false;
+    }
+
+    // oracle: solve_scaled
+    int solve_scaled(const ActiveSet* warm, EqpOut& o, ActiveSet& out_as) {
+        const int64_t n = lp.n, M = lp.M, ns = lp.ns;
+        vec zero_p(n), zero_y(M, 0.0);
+        for (int64_t j = 0; j < n; ++j) zero_p[j] = std::min(std::max(0.0, lp.lb[j]), lp.ub[j]);
+        h->stats.path = -1;
+        h->stats.polished = 1;
+        if (warm && warm->valid && (int64_t)warm->rowst.size() == M && (int64_t)warm->bst.size() == n && (int64_t)warm->sst.size() == ns) {
+            if (eqp_loop(*warm, zero_p, zero_y, 1, o, out_as)) { h->stats.path = 0; return ASM_OPTIMAL; }
+        }
+        ipm_init();
+        const double tols[3] = {1e-8, 1e-10, 1e-12};
+        const int more[3] = {IPM_MAXIT, 6, 6};
+        ActiveSet sets0;
+        bool have_sets = false;
+        for (int stage = 0; stage < 3; ++stage) {
+            int st = ipm_run(tols[stage], more[stage]);
+            h->stats.ipm_iters = ip.iters;
+            h->stats.ipm_pinf = ip.pinf; h->stats.ipm_dinf = ip.dinf; h->stats.ipm_gap = ip.gap;
+            if (st == ASM_INFEASIBLE) { h->stats.path = 6; return ASM_INFEASIBLE; }
+            if (st == ASM_OTHER && stage == 0) break;
+            identify(sets0);
+            have_sets = true;
+            if (eqp_loop(sets0, zero_p, zero_y, 2, o, out_as)) { h->stats.path = 1 + stage; return ASM_OPTIMAL; }
+        }
+        if (have_sets) {
+            vec pc(n);
+            for (int64_t j = 0; j < n; ++j) pc[j] = std::min(std::max(ip.p[j], lp.lb[j]), lp.ub[j]);
+            if (eqp_loop(sets0, pc, ip.y, 2, o, out_as)) { h->stats.path = 4; return ASM_OPTIMAL; }
+        }
+        h->stats.path = 5;
+        h->stats.polished = 0;
+        if (!have_sets) identify(sets0);
+        out_as = sets0;
+        o.p.resize(n); o.s.resize(ns); o.y = ip.y;
+        for (int64_t j = 0; j < n; ++j) o.p[j] = std::min(std::max(ip.p[j], lp.lb[j]), lp.ub[j]);
+        for (int64_t k = 0; k < ns; ++k) o.s[k] = std::max(ip.s[k], lp.slo[k]);
+        vec aty;
+        atv(o.y, aty);
+        o.z.resize(n);
+        for (int64_t j = 0; j < n; ++j) o.z[j] = lp.q[j] - aty[j];
+        return std::max(std::max(ip.pinf, ip.dinf), ip.gap) <= 1e-6 ? ASM_OPTIMAL : ASM_OTHER;
+    }
+};
+
+// =====================================================================================================
+// formulation + extraction (subproblem.jl:229-542)
+// =====================================================================================================
+int row_kind(double lb, double ub) {
+    if (lb == ub) return 0;
+    if (lb != -INF && ub != INF && lb < ub) return 2;
+    if (lb != -INF) return 1;
+    if (ub != INF) return -1;
+    return 9;
+}
+
+void free_device(asm_handle* h) {
+    auto F = [](void* p) { if (p) (void)hipFree(p); };
+    F(h->d_perm); F(h->d_ustart); F(h->d_uoff); F(h->d_adjoff);
+    F(h->d_dE); F(h->d_J); F(h->d_Ah); F(h->d_S); F(h->d_c); F(h->d_rho); F(h->d_theta); F(h->d_diag); F(h->d_diag0);
+    F(h->d_vecN); F(h->d_vecM); F(h->d_vecM2); F(h->d_part); F(h->d_partial); F(h->d_idx);
+    if (h->h_pin) (void)hipHostFree(h->h_pin);
+    h->d_perm = h->d_ustart = h->d_uoff = h->d_adjoff = nullptr;
+    h->d_dE = h->d_J = h->d_Ah = h->d_S = h->d_c = h->d_rho = h->d_theta = h->d_diag = h->d_diag0 = nullptr;
+    h->d_vecN = h->d_vecM = h->d_vecM2 = h->d_part = h->d_partial = nullptr;
+    h->d_idx = nullptr;
+    h->h_pin = nullptr;
+}
+
+template <class T>
+void dmalloc(T** p, int64_t count) {
+    HIPCHK(hipMalloc((void**)p, std::max<int64_t>(count, 1) * sizeof(T)));
+}
+
+void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j_row, const int64_t* j_col, const double* c_lb,
+              const double* c_ub, const double* v_lb, const double* v_ub) {
+    HIPCHK(hipSetDevice(h->device));
+    free_device(h);
+    h->setup_done = false;
+    h->inputs_ready = false;
+    h->n = n; h->m = m; h->nnz = nnz;
+    h->c_lb.assign(c_lb, c_lb + m); h->c_ub.assign(c_ub, c_ub + m);
+    h->v_lb.assign(v_lb, v_lb + n); h->v_ub.assign(v_ub, v_ub + n);
+    h->kind.resize(m);
+    h->adj.clear();
+    for (int64_t i = 0; i < m; ++i) {
+        h->kind[i] = row_kind(c_lb[i], c_ub[i]);
+        if (h->kind[i] == 9) throw std::invalid_argument("free constraint row (c_lb=-Inf, c_ub=+Inf) is not representable");
+        if (h->kind[i] == 2) h->adj.push_back(i);
+    }
+    h->nadj = (int64_t)h->adj.size();
+    h->M = m + h->nadj;
+    h->Mp = round_up(std::max<int64_t>(h->M, 1), 16);
+    h->ldn = round_up(n, 16);
+    h->rtype.assign(h->M, 0);
+    for (int64_t i = 0; i < m; ++i) h->rtype[i] = h->kind[i] == 0 ? 0 : (h->kind[i] == -1 ? -1 : 1);
+    for (int64_t k = 0; k < h->nadj; ++k) h->rtype[m + k] = -1;
+    // slack layout (subproblem.jl:83-112): one per row, two when both bounds are finite
+    h->srow.clear(); h->scoef.clear(); h->sown.clear(); h->nslack.assign(m, 1);
+    std::vector<int64_t> adjpos(m, -1);
+    for (int64_t k = 0; k < h->nadj; ++k) adjpos[h->adj[k]] = k;
+    for (int64_t i = 0; i < m; ++i) {
+        h->nslack[i] = (c_lb[i] > -INF && c_ub[i] < INF) ? 2 : 1;
+        int kd = h->kind[i];
+        if (kd == 0) { h->srow.push_back((int)i); h->scoef.push_back(1.0); h->srow.push_back((int)i); h->scoef.push_back(-1.0); h->sown.push_back(i); h->sown.push_back(i); }
+        else if (kd == 2) { h->srow.push_back((int)i); h->scoef.push_back(1.0); h->srow.push_back((int)(m + adjpos[i])); h->scoef.push_back(-1.0); h->sown.push_back(i); h->sown.push_back(i); }
+        else if (kd == 1) { h->srow.push_back((int)i); h->scoef.push_back(1.0); h->sown.push_back(i); }
+        else { h->srow.push_back((int)i); h->scoef.push_back(-1.0); h->sown.push_back(i); }
+    }
+    h->ns = (int64_t)h->srow.size();
+
+    // assembly plan: stable sort of the COO entries by (row, col)
+    for (int64_t k = 0; k < nnz; ++k)
+        if (j_row[k] < 1 || j_row[k] > m || j_col[k] < 1 || j_col[k] > n) throw std::invalid_argument("j_row/j_col out of range (1-based)");
+    bool dense = (nnz == m * n) && h->nadj == 0 && nnz > 0;
+    if (dense)
+        for (int64_t k = 0; k < nnz && dense; ++k) dense = (j_row[k] - 1) * n + (j_col[k] - 1) == k;
+    h->dense_fast = dense;
+    std::vector<int64_t> perm(nnz), ustart, uoff, adjoff;
+    std::iota(perm.begin(), perm.end(), 0);
+    if (!dense) {
+        std::stable_sort(perm.begin(), perm.end(), [&](int64_t a, int64_t b) {
+            int64_t ka = (j_row[a] - 1) * n + (j_col[a] - 1), kb = (j_row[b] - 1) * n + (j_col[b] - 1);
+            return ka < kb;
+        });
+        int64_t prev = -1;
+        for (int64_t t = 0; t < nnz; ++t) {
+            int64_t k = perm[t];
+            int64_t r = j_row[k] - 1, c = j_col[k] - 1, key = r * n + c;
+            if (key != prev) {
+                ustart.push_back(t);
+                uoff.push_back(r * h->ldn + c);
+                adjoff.push_back(adjpos[r] >= 0 ? (m + adjpos[r]) * h->ldn + c : -1);
+                prev = key;
+            }
+        }
+        ustart.push_back(nnz);
+    }
+    h->nu = dense ? nnz : (int64_t)uoff.size();
+
+    dmalloc(&h->d_dE, nnz);
+    dmalloc(&h->d_J, h->Mp * h->ldn);
+    dmalloc(&h->d_Ah, h->Mp * h->ldn);
+    dmalloc(&h->d_S, h->Mp * h->Mp);
+    dmalloc(&h->d_c, h->ldn); dmalloc(&h->d_rho, h->Mp); dmalloc(&h->d_theta, h->ldn);
+    dmalloc(&h->d_diag, h->Mp); dmalloc(&h->d_diag0, h->Mp);
+    dmalloc(&h->d_vecN, h->ldn); dmalloc(&h->d_vecM, h->Mp); dmalloc(&h->d_vecM2, h->Mp); dmalloc(&h->d_part, ASM_NB);
+    int64_t R = (h->M + ASM_TCHUNK - 1) / ASM_TCHUNK;
+    dmalloc(&h->d_partial, std::max<int64_t>(R, 1) * h->ldn);
+    dmalloc(&h->d_idx, h->Mp);
+    h->pin_len = std::max(h->ldn, h->Mp);
+    HIPCHK(hipHostMalloc((void**)&h->h_pin, 2 * h->pin_len * sizeof(double)));
+    HIPCHK(hipMemsetAsync(h->d_J, 0, h->Mp * h->ldn * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_Ah, 0, h->Mp * h->ldn * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_vecN, 0, h->ldn * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_vecM, 0, h->Mp * sizeof(double), h->stream));
+    if (!dense) {
+        dmalloc(&h->d_perm, nnz); dmalloc(&h->d_ustart, h->nu + 1); dmalloc(&h->d_uoff, h->nu); dmalloc(&h->d_adjoff, h->nu);
+        HIPCHK(hipMemcpy(h->d_perm, perm.data(), nnz * sizeof(int64_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_ustart, ustart.data(), (h->nu + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_uoff, uoff.data(), h->nu * sizeof(int64_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_adjoff, adjoff.data(), h->nu * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->warm[0] = ActiveSet(); h->warm[1] = ActiveSet(); h->last = ActiveSet();
+    std::memset(&h->stats, 0, sizeof(h->stats));
+    h->setup_done = true;
+}
+
+void do_upload(asm_handle* h, const double* dE, const double* df, double f, const double* E, const double* x_k) {
+    if (!h->setup_done) throw std::logic_error("asm_sublp_setup has not been called");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(h->d_dE, dE, h->nnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->df.assign(df, df + h->n); h->E.assign(E, E + h->m); h->x_k.assign(x_k, x_k + h->n);
+    h->f = f;
+    h->inputs_ready = true;
+}
+
+void do_solve(asm_handle* h, double delta, int feasibility, double* p_out, double* lambda, double* mult_x_U, double* mult_x_L,
+              double* p_slack, int32_t* status) {
+    if (!h->setup_done || !h->inputs_ready) throw std::logic_error("inputs have not been uploaded");
+    HIPCHK(hipSetDevice(h->device));
+    auto t0 = std::chrono::steady_clock::now();
+    const int64_t n = h->n, m = h->m, M = h->M;
+    const bool fr = feasibility != 0;
+    Solver sv(h);
+    SLP& lp = sv.lp;
+    std::memset(&h->stats, 0, sizeof(h->stats));
+    lp.n = n; lp.M = M; lp.ns = fr ? h->ns : 0;
+    lp.rtype = h->rtype.data(); lp.srow = h->srow.data(); lp.scoef = h->scoef.data();
+    h->stats.M = (int)M; h->stats.n = (int)n; h->stats.ns = (int)lp.ns;
+
+    // trust region intersected with the variable bounds (subproblem.jl:427-434)
+    vec lb(n), ub(n), c(n);
+    for (int64_t j = 0; j < n; ++j) {
+        ub[j] = std::min(delta, h->v_ub[j] - h->x_k[j]);
+        lb[j] = std::max(-delta, h->v_lb[j] - h->x_k[j]);
+        c[j] = pow2_round(std::max(ub[j], -lb[j]));
+    }
+    // Jacobian -> dense rows incl. range rows; scaled copy
+    sv.dev.assemble();
+    vec rho(M);
+    sv.dev.scale(c.data(), rho.data());
+
+    // feasibility-restoration shift (subproblem.jl:287-295) and slack lower bounds (:298-381)
+    vec b(h->E), viol(m, 0.0), slo_un;
+    if (fr) {
+        slo_un.reserve(h->ns);
+        for (int64_t i = 0; i < m; ++i) {
+            double v = 0.0;
+            if (h->E[i] > h->c_ub[i]) v = h->c_ub[i] - h->E[i];
+            else if (h->E[i] < h->c_lb[i]) v = h->c_lb[i] - h->E[i];
+            viol[i] = v;
+            b[i] -= std::fabs(v);
+            if (h->nslack[i] == 2) {
+                if (v < 0) { slo_un.push_back(0.0); slo_un.push_back(v); }
+                else { slo_un.push_back(-v); slo_un.push_back(0.0); }
+            } else {
+                slo_un.push_back(-std::fabs(v));
+            }
+        }
+    }
+    // right-hand sides (subproblem.jl:461-484)
+    vec r(M);
+    for (int64_t i = 0; i < m; ++i) r[i] = h->kind[i] == -1 ? h->c_ub[i] - b[i] : h->c_lb[i] - b[i];
+    for (int64_t k = 0; k < h->nadj; ++k) r[m + k] = h->c_ub[h->adj[k]] - b[h->adj[k]];
+    // objective (subproblem.jl:250-272 | 384-405)
+    vec q(n, 0.0), w(lp.ns, fr ? 1.0 : 0.0);
+    if (!fr) q = h->df;
+
+    // scaling (oracle: scale_lp)
+    lp.q.resize(n); lp.lb.resize(n); lp.ub.resize(n); lp.r.resize(M); lp.w.resize(lp.ns); lp.slo.resize(lp.ns);
+    double qmax = 0.0;
+    for (int64_t j = 0; j < n; ++j) { lp.q[j] = q[j] * c[j]; qmax = std::max(qmax, std::fabs(lp.q[j])); }
+    for (int64_t k = 0; k < lp.ns; ++k) { lp.w[k] = w[k] * rho[h->srow[k]]; qmax = std::max(qmax, std::fabs(lp.w[k])); }
+    double kap = pow2_round(qmax);
+    for (int64_t j = 0; j < n; ++j) { lp.q[j] /= kap; lp.lb[j] = lb[j] / c[j]; lp.ub[j] = ub[j] / c[j]; }
+    for (int64_t k = 0; k < lp.ns; ++k) { lp.w[k] /= kap; lp.slo[k] = slo_un[k] / rho[h->srow[k]]; }
+    for (int64_t i = 0; i < M; ++i) lp.r[i] = r[i] / rho[i];
+    lp.scale_q = 1.0;
+    for (double v : lp.q) lp.scale_q = std::max(lp.scale_q, std::fabs(v));
+    for (double v : lp.w) lp.scale_q = std::max(lp.scale_q, std::fabs(v));
+
+    Solver::EqpOut o;
+    ActiveSet as;
+    int st = sv.solve_scaled(&h->warm[fr ? 1 : 0], o, as);
+    *status = st;
+
+    for (int64_t j = 0; j < n; ++j) { p_out[j] = 0.0; mult_x_U[j] = 0.0; mult_x_L[j] = 0.0; }
+    for (int64_t i = 0; i < m; ++i) { lambda[i] = 0.0; p_slack[2 * i] = 0.0; p_slack[2 * i + 1] = h->nslack[i] == 2 ? 0.0 : std::nan(""); }
+    if (st == ASM_OPTIMAL) {
+        h->warm[fr ? 1 : 0] = as;
+        h->last = as;
+        // unscale (oracle: solve_lp) - bound-active components are exactly on their bound
+        vec y(M), z(n);
+        for (int64_t j = 0; j < n; ++j) {
+            double pj = o.p[j] * c[j];
+            pj = std::min(std::max(pj, lb[j]), ub[j]);
+            if (as.bst[j] < 0) pj = lb[j];
+            else if (as.bst[j] > 0) pj = ub[j];
+            p_out[j] = pj;                                                     // subproblem.jl:502
+        }
+        for (int64_t i = 0; i < M; ++i) y[i] = o.y[i] * kap / rho[i];
+        // reduced costs in caller units: z = q - J'y  ==  kap * zhat / c
+        for (int64_t j = 0; j < n; ++j) z[j] = o.z[j] * kap / c[j];
+        if (fr) {
+            int64_t k = 0;
+            for (int64_t i = 0; i < m; ++i)
+                for (int t = 0; t < h->nslack[i]; ++t, ++k) p_slack[2 * i + t] = o.s[k] * rho[h->srow[k]];   // :503-505
+        }
+        for (int64_t i = 0; i < M; ++i) {
+            if (h->rtype[i] == 1) y[i] = std::max(y[i], 0.0);
+            else if (h->rtype[i] == -1) y[i] = std::min(y[i], 0.0);
+        }
+        for (int64_t i = 0; i < m; ++i) lambda[i] = y[i];                       // :510-512
+        for (int64_t k = 0; k < h->nadj; ++k) lambda[h->adj[k]] += y[m + k];    // :513-515
+        for (int64_t j = 0; j < n; ++j) {                                       // :519-529
+            bool fixed = ub[j] <= lb[j];
+            double mL = as.bst[j] < 0 ? std::max(z[j], 0.0) : 0.0;
+            double mU = as.bst[j] > 0 ? std::min(z[j], 0.0) : 0.0;
+            if (fixed) mU = std::min(z[j], 0.0);
+            if (p_out[j] < h->v_ub[j] - h->x_k[j]) mU = 0.0;
+            if (p_out[j] > h->v_lb[j] - h->x_k[j]) mL = 0.0;
+            mult_x_L[j] = mL;
+            mult_x_U[j] = mU;
+        }
+    } else {
+        h->last = ActiveSet();
+    }
+    sv.dev.resolve_timing();
+    h->stats.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+template <class F>
+int guarded(asm_handle* h, F&& fn) {
+    if (!h) return ASM_ERR_ARG;
+    try {
+        fn();
+        return ASM_OK;
+    } catch (const HipError& e) {
+        h->err = e.what();
+        return ASM_ERR_HIP;
+    } catch (const std::invalid_argument& e) {
+        h->err = e.what();
+        return std::string(e.what()).find("not representable") != std::string::npos ? ASM_ERR_UNSUPPORTED : ASM_ERR_ARG;
+    } catch (const std::logic_error& e) {
+        h->err = e.what();
+        return ASM_ERR_STATE;
+    } catch (const std::exception& e) {
+        h->err = e.what();
+        return ASM_ERR_ARG;
+    }
+}
+
+}  // namespace
+
+// =========================================================================================================
+// C ABI
+// =========================================================================================================
+extern "C" {
+
+int asm_create(int device, asm_handle** out) {
+    if (!out) return ASM_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return ASM_ERR_HIP;
+    asm_handle* h = new (std::nothrow) asm_handle();
+    if (!h) return ASM_ERR_ARG;
+    h->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
+        delete h;
+        return ASM_ERR_HIP;
+    }
+    std::memset(&h->kstats, 0, sizeof(h->kstats));
+    std::memset(&h->stats, 0, sizeof(h->stats));
+    *out = h;
+    return ASM_OK;
+}
+
+int asm_destroy(asm_handle* h) {
+    if (!h) return ASM_ERR_ARG;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto& r : h->regions) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : h->event_pool) (void)hipEventDestroy(e);
+    free_device(h);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return ASM_OK;
+}
+
+const char* asm_last_error(const asm_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int asm_sublp_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j_row, const int64_t* j_col,
+                    const double* c_lb, const double* c_ub, const double* v_lb, const double* v_ub) {
+    return guarded(h, [&] {
+        if (n <= 0 || m < 0 || nnz < 0 || (nnz > 0 && (!j_row || !j_col)) || (m > 0 && (!c_lb || !c_ub)) || !v_lb || !v_ub)
+            throw std::invalid_argument("asm_sublp_setup: bad dimensions or null pointer");
+        do_setup(h, n, m, nnz, j_row, j_col, c_lb, c_ub, v_lb, v_ub);
+    });
+}
+
+int asm_sublp_upload(asm_handle* h, const double* dE, const double* df, double f, const double* E, const double* x_k) {
+    return guarded(h, [&] {
+        if ((h->nnz > 0 && !dE) || !df || (h->m > 0 && !E) || !x_k) throw std::invalid_argument("asm_sublp_upload: null pointer");
+        do_upload(h, dE, df, f, E, x_k);
+    });
+}
+
+int asm_sublp_solve_resident(asm_handle* h, double delta, int feasibility, double* p, double* lambda, double* mult_x_U,
+                             double* mult_x_L, double* p_slack, int32_t* status) {
+    return guarded(h, [&] {
+        if (!p || (h->m > 0 && (!lambda || !p_slack)) || !mult_x_U || !mult_x_L || !status)
+            throw std::invalid_argument("asm_sublp_solve: null output pointer");
+        if (!(delta >= 0.0)) throw std::invalid_argument("asm_sublp_solve: delta must be >= 0");
+        do_solve(h, delta, feasibility, p, lambda, mult_x_U, mult_x_L, p_slack, status);
+    });
+}
+
+int asm_sublp_solve(asm_handle* h, const double* dE, const double* df, double f, const double* E, const double* x_k, double delta,
+                    int feasibility, double* p, double* lambda, double* mult_x_U, double* mult_x_L, double* p_slack,
+                    int32_t* status) {
+    int rc = asm_sublp_upload(h, dE, df, f, E, x_k);
+    if (rc != ASM_OK) return rc;
+    return asm_sublp_solve_resident(h, delta, feasibility, p, lambda, mult_x_U, mult_x_L, p_slack, status);
+}
+
+int asm_sublp_active_set(const asm_handle* h, int32_t* row_state, int32_t* bound_state, int32_t* slack_state, int64_t* n_rows,
+                         int64_t* n_slack) {
+    if (!h) return ASM_ERR_ARG;
+    if (!h->last.valid) return ASM_ERR_STATE;
+    if (n_rows) *n_rows = (int64_t)h->last.rowst.size();
+    if (n_slack) *n_slack = (int64_t)h->last.sst.size();
+    if (row_state) for (size_t i = 0; i < h->last.rowst.size(); ++i) row_state[i] = h->last.rowst[i];
+    if (bound_state) for (size_t i = 0; i < h->last.bst.size(); ++i) bound_state[i] = h->last.bst[i];
+    if (slack_state) for (size_t i = 0; i < h->last.sst.size(); ++i) slack_state[i] = h->last.sst[i];
+    return ASM_OK;
+}
+
+int asm_sublp_reset_warm(asm_handle* h) {
+    if (!h) return ASM_ERR_ARG;
+    h->warm[0] = ActiveSet();
+    h->warm[1] = ActiveSet();
+    return ASM_OK;
+}
+
+int asm_sublp_last_stats(const asm_handle* h, asm_solve_stats* out) {
+    if (!h || !out) return ASM_ERR_ARG;
+    *out = h->stats;
+    return ASM_OK;
+}
+
+int asm_kernel_stats_get(asm_handle* h, asm_kernel_stats* out) {
+    if (!out) return ASM_ERR_ARG;
+    return guarded(h, [&] {
+        Dev d(h);
+        d.resolve_timing();
+        *out = h->kstats;
+    });
+}
+
+int asm_kernel_stats_reset(asm_handle* h) {
+    return guarded(h, [&] {
+        Dev d(h);
+        d.resolve_timing();
+        std::memset(&h->kstats, 0, sizeof(h->kstats));
+    });
+}
+
+// --------------------------------------------------------------------------------- norms on the resident Jacobian
+int asm_jac_row_norms(asm_handle* h, double* out_m) {
+    return guarded(h, [&] {
+        if (!h->setup_done || !h->inputs_ready || !out_m) throw std::logic_error("asm_jac_row_norms: no assembled Jacobian");
+        HIPCHK(hipSetDevice(h->device));
+        Dev d(h);
+        d.assemble();
+        hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((h->m + 3) / 4)), dim3(256), 0, h->stream, h->d_J, h->ldn, h->d_vecM, h->m, h->ldn);
+        d.d2h(out_m, h->d_vecM, h->m);
+    });
+}
+
+int asm_kt_residuals(asm_handle* h, const double* df, const double* lambda, const double* mult_x_U, const double* mult_x_L, double* out) {
+    return guarded(h, [&] {
+        if (!h->setup_done || !h->inputs_ready || !df || !mult_x_U || !mult_x_L || !out || (h->m > 0 && !lambda))
+            throw std::logic_error("asm_kt_residuals: no assembled Jacobian or null pointer");
+        HIPCHK(hipSetDevice(h->device));
+        Dev d(h);
+        d.assemble();
+        const int64_t n = h->n, m = h->m;
+        vec lam(h->M, 0.0), jtl(n), rn(std::max<int64_t>(m, 1));
+        for (int64_t i = 0; i < m; ++i) lam[i] = lambda[i];
+        d.gemv_t(h->d_J, lam.data(), jtl.data());
+        hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, h->stream, h->d_J, h->ldn, h->d_vecM, m, h->ldn);
+        if (m > 0) d.d2h(rn.data(), h->d_vecM, m);
+        // common.jl:38-43
+        double res = 0.0, ndf = 0.0;
+        for (int64_t j = 0; j < n; ++j) {
+            double v = df[j] - jtl[j] - mult_x_U[j] - mult_x_L[j];
+            res += v * v;
+            ndf += df[j] * df[j];
+        }
+        double scalar = std::max(1.0, std::sqrt(ndf));
+        for (int64_t i = 0; i < m; ++i) scalar = std::max(scalar, std::fabs(lambda[i]) * rn[i]);
+        *out = std::sqrt(res) / scalar;
+    });
+}
+
+// --------------------------------------------------------------------------------- kernel test hooks
+static void test_alloc(asm_handle* h, int64_t M, int64_t K) {
+    // minimal "problem" so that the generic buffers exist: dense pattern M x K
+    std::vector<int64_t> jr(1, 1), jc(1, 1);
+    vec lo(M, 0.0), hi(M, 0.0), vl(K, -1.0), vu(K, 1.0);
+    do_setup(h, K, M, 1, jr.data(), jc.data(), lo.data(), hi.data(), vl.data(), vu.data());
+}
+
+int asm_test_syrk(asm_handle* h, const double* A, int64_t M, int64_t K, const int32_t* idx, int64_t Ms, const double* theta,
+                  const double* diag, double* S_out, int tile) {
+    return guarded(h, [&] {
+        test_alloc(h, M, K);
+        Dev d(h);
+        for (int64_t i = 0; i < M; ++i)
+            HIPCHK(hipMemcpy(h->d_Ah + i * h->ldn, A + i * K, K * sizeof(double), hipMemcpyHostToDevice));
+        d.h2d(h->d_theta, theta, K, h->ldn);
+        if (diag) d.h2d(h->d_diag, diag, Ms, Ms);
+        if (idx) HIPCHK(hipMemcpy(h->d_idx, idx, Ms * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(h->d_S, 0, h->Mp * h->Mp * sizeof(double)));
+        d.launch_syrk(tile > 0 ? tile : Dev::pick_tile(Ms), h->d_Ah, h->ldn, idx ? h->d_idx : nullptr, 0, (int)Ms, (int)h->ldn, h->d_theta,
+                      diag ? h->d_diag : nullptr, h->d_S, h->Mp, 0, 0);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (int64_t i = 0; i < Ms; ++i)
+            HIPCHK(hipMemcpy(S_out + i * Ms, h->d_S + i * h->Mp, Ms * sizeof(double), hipMemcpyDeviceToHost));
+    });
+}
+
+static void test_load_S(asm_handle* h, const double* S, int64_t N) {
+    test_alloc(h, N, 16);
+    for (int64_t i = 0; i < N; ++i)
+        HIPCHK(hipMemcpy(h->d_S + i * h->Mp, S + i * N, N * sizeof(double), hipMemcpyHostToDevice));
+}
+
+int asm_test_cholesky(asm_handle* h, const double* S, int64_t N, double* L_out) {
+    return guarded(h, [&] {
+        test_load_S(h, S, N);
+        Dev d(h);
+        d.diag_prepare((int)N, 0, 0.0, 0.0);
+        d.chol((int)N);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (int64_t i = 0; i < N; ++i) {
+            HIPCHK(hipMemcpy(L_out + i * N, h->d_S + i * h->Mp, N * sizeof(double), hipMemcpyDeviceToHost));
+            for (int64_t j = i + 1; j < N; ++j) L_out[i * N + j] = 0.0;
+        }
+        d.resolve_timing();
+    });
+}
+
+int asm_test_chol_solve(asm_handle* h, const double* S, int64_t N, const double* b, double* x) {
+    return guarded(h, [&] {
+        test_load_S(h, S, N);
+        Dev d(h);
+        d.diag_prepare((int)N, 0, 0.0, 0.0);
+        d.chol((int)N);
+        d.chol_solve(b, x, (int)N);
+        d.resolve_timing();
+    });
+}
+
+int asm_test_gemv(asm_handle* h, const double* A, int64_t M, int64_t K, const double* x, const double* y, double* Ax, double* ATy) {
+    return guarded(h, [&] {
+        test_alloc(h, M, K);
+        Dev d(h);
+        for (int64_t i = 0; i < M; ++i)
+            HIPCHK(hipMemcpy(h->d_Ah + i * h->ldn, A + i * K, K * sizeof(double), hipMemcpyHostToDevice));
+        d.gemv_n(h->d_Ah, x, Ax);
+        d.gemv_t(h->d_Ah, y, ATy);
+        d.resolve_timing();
+    });
+}
+
+int asm_test_assemble(asm_handle* h, const double* dE, double* J_out) {
+    return guarded(h, [&] {
+        if (!h->setup_done) throw std::logic_error("setup first");
+        HIPCHK(hipMemcpy(h->d_dE, dE, h->nnz * sizeof(double), hipMemcpyHostToDevice));
+        Dev d(h);
+        d.assemble();
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (int64_t i = 0; i < h->M; ++i)
+            HIPCHK(hipMemcpy(J_out + i * h->n, h->d_J + i * h->ldn, h->n * sizeof(double), hipMemcpyDeviceToHost));
+        d.resolve_timing();
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,404 @@
+// Device kernels for the SLP sub-LP hot path on MI355X (gfx950 / CDNA4).  FP64 throughout.
+//
+// Layout in HBM (all row-major, leading dimensions padded to a multiple of 16 doubles = 128 B so that
+// every row starts on a cache-line boundary and the MFMA k-loops need no edge code):
+//   J    (Mp x ldn)  dense constraint Jacobian incl. the extra range rows        [assembled each call]
+//   Ah   (Mp x ldn)  power-of-two scaled copy  Ah = diag(1/rho) J diag(c)        [one pass each call]
+//   S    (Mp x Mp)   Schur complement / its Cholesky factor (lower triangle)     [per factorisation]
+//
+// Kernels (roofline that bounds each one; bytes/flops per launch are tabulated in DESIGN.md):
+//   k_assemble        HBM   COO -> dense J, duplicate accumulation in j_str order (bit-exact vs common.jl:12-20)
+//   k_scale_rows      HBM   row max + scaled copy
+//   k_gemv_n/t        HBM   Ah x , Ah' y
+//   k_syrk<T>         MFMA  S = Ah[idx,:] diag(theta) Ah[idx,:]' (+diag)  and  S22 -= P P'   (v_mfma_f64_16x16x4_f64)
+//   k_potrf_diag      LDS   64x64 diagonal block Cholesky with static pivot guard
+//   k_trsm_panel      LDS   panel  P = S21 L11^-T
+//   k_trsv_*          HBM   blocked forward / backward substitution (wave-shuffle dot products)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+#define ASM_NB 64          // Cholesky panel width
+#define ASM_KC 16          // k-chunk staged through LDS by k_syrk
+#define ASM_PITCH 18       // LDS row pitch in doubles: KC + 2  (pitch = 2 mod 32 -> conflict-free ds_read_b64 fragments)
+
+// ---------------------------------------------------------------------------------------------------
+// Assembly.  One thread per distinct (row, col) of the pattern; its duplicates are summed in the
+// original j_str order (perm is a stable sort), starting from 0.0 exactly like `J[r,c] += dE[k]`.
+// `adj_off` (>=0) is the image of that entry in the extra `<=` row of a range constraint; it is
+// refreshed only when one of the terms is non-zero (stored-entry semantics of subproblem.jl:448-457).
+__global__ void k_assemble(const double* __restrict__ dE, const int64_t* __restrict__ perm,
+                           const int64_t* __restrict__ ustart, const int64_t* __restrict__ uoff,
+                           const int64_t* __restrict__ adj_off, double* __restrict__ J, int64_t nu) {
+    for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u < nu; u += (int64_t)gridDim.x * blockDim.x) {
+        double acc = 0.0;
+        bool any = false;
+        for (int64_t k = ustart[u]; k < ustart[u + 1]; ++k) {
+            double v = dE[perm[k]];
+            acc = acc + v;
+            any = any || (v != 0.0);
+        }
+        J[uoff[u]] = acc;
+        int64_t a = adj_off[u];
+        if (a >= 0 && any) J[a] = acc;
+    }
+}
+
+// Fast path when the pattern is duplicate-free and already row-major dense (config C2): a strided copy.
+__global__ void k_assemble_dense(const double* __restrict__ dE, double* __restrict__ J, int64_t m, int64_t n, int64_t ldn) {
+    int64_t total = m * n;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t i = t / n, j = t - i * n;
+        J[i * ldn + j] = 0.0 + dE[t];
+    }
+}
+
+__device__ __forceinline__ double pow2_round_dev(double x) {
+    if (!(x > 0.0)) return 1.0;
+    int e;
+    double f = frexp(x, &e);
+    if (f < 0.70710678118654752) e -= 1;
+    return ldexp(1.0, e);
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// One workgroup per row: rho_i = pow2(max_j |J_ij c_j|),  Ah_ij = J_ij c_j / rho_i  (all factors are powers of two).
+__global__ __launch_bounds__(256) void k_scale_rows(const double* __restrict__ J, const double* __restrict__ c,
+                                                    double* __restrict__ Ah, double* __restrict__ rho, int64_t n, int64_t ldn) {
+    __shared__ double red[4];
+    __shared__ double s_inv;
+    int64_t i = blockIdx.x;
+    const double* row = J + i * ldn;
+    double mx = 0.0;
+    for (int64_t j = threadIdx.x; j < n; j += 256) mx = fmax(mx, fabs(row[j] * c[j]));
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m4 = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        double r = pow2_round_dev(m4);
+        rho[i] = r;
+        s_inv = 1.0 / r;
+    }
+    __syncthreads();
+    double inv = s_inv;
+    double* out = Ah + i * ldn;
+    for (int64_t j = threadIdx.x; j < n; j += 256) out[j] = row[j] * c[j] * inv;
+}
+
+// out[i] = sum_j A[i,j] x[j]   (one wavefront per row, 16-byte loads along the row)
+__global__ __launch_bounds__(256) void k_gemv_n(const double* __restrict__ A, int64_t ld, const double* __restrict__ x,
+                                                double* __restrict__ out, int64_t M, int64_t ncols) {
+    int64_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= M) return;
+    int lane = threadIdx.x & 63;
+    const double2* row = reinterpret_cast<const double2*>(A + i * ld);
+    const double2* xv = reinterpret_cast<const double2*>(x);
+    double acc = 0.0;
+    int64_t n2 = ncols >> 1;                     // ncols is padded to an even count
+    for (int64_t j = lane; j < n2; j += 64) {
+        double2 a = row[j];
+        double2 b = xv[j];
+        acc = fma(a.x, b.x, acc);
+        acc = fma(a.y, b.y, acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[i] = acc;
+}
+
+// partial[r][j] = sum_{i in row chunk r} A[i,j] y[i]   ; second stage sums the chunks in order (deterministic).
+#define ASM_TCHUNK 128
+__global__ __launch_bounds__(256) void k_gemv_t_stage1(const double* __restrict__ A, int64_t ld, const double* __restrict__ y,
+                                                       double* __restrict__ partial, int64_t M, int64_t ncols) {
+    int64_t j = blockIdx.x * 256 + threadIdx.x;
+    int64_t r = blockIdx.y;
+    int64_t i0 = r * ASM_TCHUNK, i1 = i0 + ASM_TCHUNK;
+    if (i1 > M) i1 = M;
+    if (j >= ncols) return;
+    double acc = 0.0;
+    for (int64_t i = i0; i < i1; ++i) acc = fma(A[i * ld + j], y[i], acc);
+    partial[r * ncols + j] = acc;
+}
+__global__ __launch_bounds__(256) void k_gemv_t_stage2(const double* __restrict__ partial, double* __restrict__ out,
+                                                       int64_t R, int64_t ncols) {
+    int64_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= ncols) return;
+    double acc = 0.0;
+    for (int64_t r = 0; r < R; ++r) acc += partial[r * ncols + j];
+    out[j] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Symmetric rank-K kernel on the f64 matrix cores.
+//   mode 0:  S[a,b]  = sum_k A[row(a),k] theta[k] A[row(b),k]  (+ diag[a] if a==b)      a >= b
+//   mode 1:  S[a,b] -= sum_k A[row(a),k] A[row(b),k]                                    a >= b
+// row(a) = idx[a] when idx != nullptr, else row0 + a.  Tile = 32*T x 32*T per 256-thread workgroup;
+// the four wavefronts form a 2x2 grid and each owns T x T MFMA tiles of 16x16.
+// v_mfma_f64_16x16x4_f64 operand maps (cdna_hip_programming.md:161): lane l holds A[i=l&15][k=l>>4] and
+// B[k=l>>4][j=l&15]; result register r of lane l is D[row=(l>>4)+4r][col=l&15].
+template <int T>
+__global__ __launch_bounds__(256) void k_syrk(const double* __restrict__ A, int64_t ld, const int* __restrict__ idx, int64_t row0,
+                                              int Ms, int K, const double* __restrict__ theta, const double* __restrict__ diag,
+                                              double* __restrict__ S, int64_t ldS, int64_t srow0, int mode) {
+    constexpr int TS = 32 * T;
+    __shared__ double As[TS * ASM_PITCH];
+    __shared__ double Bs[TS * ASM_PITCH];
+    // lower-triangular tile pair (bi >= bj) from the linear block id
+    int t = blockIdx.x;
+    int bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((int64_t)(bi + 1) * (bi + 2) / 2 <= t) ++bi;
+    while ((int64_t)bi * (bi + 1) / 2 > t) --bi;
+    int bj = t - (int)((int64_t)bi * (bi + 1) / 2);
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    v4f64 acc[T][T];
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+
+    // staging assignment: TS rows x KC doubles per operand; each thread moves 2 doubles (16 B) per pass
+    constexpr int PER_ROW = ASM_KC / 2;                 // threads per row
+    constexpr int ROWS_PER_PASS = 256 / PER_ROW;        // 32
+    constexpr int PASSES = (TS + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
+    const int lr = tid / PER_ROW, lk = (tid % PER_ROW) * 2;
+    const double* arow[PASSES];
+    const double* brow[PASSES];
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+        int r = ps * ROWS_PER_PASS + lr;
+        int ga = bi * TS + r, gb = bj * TS + r;
+        arow[ps] = nullptr;
+        brow[ps] = nullptr;
+        if (r < TS && ga < Ms) arow[ps] = A + (idx ? (int64_t)idx[ga] : row0 + ga) * ld;
+        if (r < TS && gb < Ms) brow[ps] = A + (idx ? (int64_t)idx[gb] : row0 + gb) * ld;
+    }
+
+    for (int k0 = 0; k0 < K; k0 += ASM_KC) {
+        double2 th = theta ? *reinterpret_cast<const double2*>(theta + k0 + lk) : make_double2(1.0, 1.0);
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            int r = ps * ROWS_PER_PASS + lr;
+            if (r < TS) {
+                double2 a = arow[ps] ? *reinterpret_cast<const double2*>(arow[ps] + k0 + lk) : make_double2(0.0, 0.0);
+                double2 b = brow[ps] ? *reinterpret_cast<const double2*>(brow[ps] + k0 + lk) : make_double2(0.0, 0.0);
+                As[r * ASM_PITCH + lk] = a.x;
+                As[r * ASM_PITCH + lk + 1] = a.y;
+                Bs[r * ASM_PITCH + lk] = b.x * th.x;
+                Bs[r * ASM_PITCH + lk + 1] = b.y * th.y;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < ASM_KC; kk += 4) {
+            double af[T], bf[T];
+#pragma unroll
+            for (int i = 0; i < T; ++i) af[i] = As[(wr * 16 * T + i * 16 + (lane & 15)) * ASM_PITCH + kk + (lane >> 4)];
+#pragma unroll
+            for (int j = 0; j < T; ++j) bf[j] = Bs[(wc * 16 * T + j * 16 + (lane & 15)) * ASM_PITCH + kk + (lane >> 4)];
+#pragma unroll
+            for (int i = 0; i < T; ++i)
+#pragma unroll
+                for (int j = 0; j < T; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int row = bi * TS + wr * 16 * T + i * 16 + (lane >> 4) + 4 * r;
+                int col = bj * TS + wc * 16 * T + j * 16 + (lane & 15);
+                if (row < Ms && col <= row) {
+                    double* dst = S + (srow0 + row) * ldS + (srow0 + col);
+                    double v = acc[i][j][r];
+                    if (mode == 0) {
+                        if (row == col && diag) v += diag[row];
+                        *dst = v;
+                    } else {
+                        *dst = *dst - v;
+                    }
+                }
+            }
+}
+
+// diag0[i] = S_ii ; then S_ii += reg.   mode 0: reg_i = rel*S_ii + absv ;  mode 1: reg = rel*max(max_i S_ii, 1e-300)
+__global__ __launch_bounds__(1024) void k_diag_prepare(double* __restrict__ S, int64_t ldS, int Ms, double* __restrict__ diag0,
+                                                       int mode, double rel, double absv) {
+    __shared__ double red[16];
+    __shared__ double s_max;
+    double mx = 0.0;
+    for (int i = threadIdx.x; i < Ms; i += 1024) {
+        double d = S[(int64_t)i * ldS + i];
+        diag0[i] = d;
+        mx = fmax(mx, d);
+    }
+    if (mode == 1) {
+        mx = wave_max(mx);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double m = 0.0;
+            for (int k = 0; k < 16; ++k) m = fmax(m, red[k]);
+            s_max = fmax(m, 1e-300);
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < Ms; i += 1024) {
+        double d = diag0[i];
+        double reg = (mode == 0) ? (rel * d + absv) : (rel * s_max);
+        S[(int64_t)i * ldS + i] = d + reg;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Cholesky of one NB x NB diagonal block, staged in LDS.  Pivot guard: d <= 1e-14*diag0 -> d := 1e256.
+#define ASM_DP (ASM_NB + 1)
+__global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int64_t ldS, int k0, int nb,
+                                                    const double* __restrict__ diag0) {
+    __shared__ double D[ASM_NB * ASM_DP];
+    __shared__ double s_piv;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < nb * nb; e += 256) {
+        int r = e / nb, c = e - r * nb;
+        D[r * ASM_DP + c] = (c <= r) ? S[(int64_t)(k0 + r) * ldS + k0 + c] : 0.0;
+    }
+    __syncthreads();
+    for (int j = 0; j < nb; ++j) {
+        if (tid == 0) {
+            double d = D[j * ASM_DP + j];
+            if (!(d > 1e-14 * diag0[k0 + j])) d = 1e256;
+            s_piv = sqrt(d);
+            D[j * ASM_DP + j] = s_piv;
+        }
+        __syncthreads();
+        double ljj = s_piv;
+        if (tid > j && tid < nb) D[tid * ASM_DP + j] = D[tid * ASM_DP + j] / ljj;
+        __syncthreads();
+        // trailing update of the lower triangle: rows r > j, cols j < c <= r
+        int rem = nb - j - 1;
+        for (int e = tid; e < rem * rem; e += 256) {
+            int rr = e / rem, cc = e - rr * rem;
+            if (cc <= rr) {
+                int r = j + 1 + rr, c = j + 1 + cc;
+                D[r * ASM_DP + c] -= D[r * ASM_DP + j] * D[c * ASM_DP + j];
+            }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < nb * nb; e += 256) {
+        int r = e / nb, c = e - r * nb;
+        if (c <= r) S[(int64_t)(k0 + r) * ldS + k0 + c] = D[r * ASM_DP + c];
+    }
+}
+
+// Panel solve: for every row i >= k1,  S[i, k0:k1] <- S[i, k0:k1] * L11^-T   (one thread per row, L11 broadcast from LDS)
+__global__ __launch_bounds__(64) void k_trsm_panel(double* __restrict__ S, int64_t ldS, int k0, int nb, int Ms) {
+    __shared__ double Lk[ASM_NB * ASM_DP];
+    for (int e = threadIdx.x; e < nb * nb; e += 64) {
+        int r = e / nb, c = e - r * nb;
+        Lk[r * ASM_DP + c] = (c <= r) ? S[(int64_t)(k0 + r) * ldS + k0 + c] : 0.0;
+    }
+    __syncthreads();
+    int i = k0 + nb + blockIdx.x * 64 + threadIdx.x;
+    if (i >= Ms) return;
+    double* row = S + (int64_t)i * ldS + k0;
+    double x[ASM_NB];
+#pragma unroll
+    for (int c = 0; c < ASM_NB; ++c) x[c] = (c < nb) ? row[c] : 0.0;
+#pragma unroll
+    for (int c = 0; c < ASM_NB; ++c) {
+        if (c < nb) {
+            double v = x[c];
+#pragma unroll
+            for (int q = 0; q < c; ++q) v -= x[q] * Lk[c * ASM_DP + q];
+            x[c] = v / Lk[c * ASM_DP + c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < ASM_NB; ++c)
+        if (c < nb) row[c] = x[c];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Blocked triangular solves with the row-major lower factor.
+// forward, step k:   part[r] = sum_{j<k0} L[k0+r, j] z[j]          (k_trsv_panel_dot: one wavefront per row)
+//                    z[k0:k1] = L11^-1 (b[k0:k1] - part)            (k_trsv_diag_fwd)
+// backward, step k:  x[k0:k1] = L11^-T z[k0:k1]                     (k_trsv_diag_bwd)
+//                    z[j] -= sum_r L[k0+r, j] x[k0+r]   for j < k0  (k_trsv_panel_axpy: one thread per column)
+__global__ __launch_bounds__(256) void k_trsv_panel_dot(const double* __restrict__ L, int64_t ld, int k0, int nb,
+                                                        const double* __restrict__ z, double* __restrict__ part) {
+    int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nb) return;
+    int lane = threadIdx.x & 63;
+    const double* row = L + (int64_t)(k0 + r) * ld;
+    double acc = 0.0;
+    for (int j = lane; j < k0; j += 64) acc = fma(row[j], z[j], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) part[r] = acc;
+}
+
+__global__ __launch_bounds__(64) void k_trsv_diag_fwd(const double* __restrict__ L, int64_t ld, int k0, int nb,
+                                                      const double* __restrict__ b, const double* __restrict__ part,
+                                                      double* __restrict__ z, int use_part) {
+    // one wavefront; lane r owns unknown r.  Column-oriented substitution with a wave broadcast per step.
+    int r = threadIdx.x;
+    double v = 0.0;
+    if (r < nb) v = b[k0 + r] - (use_part ? part[r] : 0.0);
+    for (int c = 0; c < nb; ++c) {
+        double lcc = L[(int64_t)(k0 + c) * ld + k0 + c];
+        double xc = __shfl(v, c, 64) / lcc;
+        if (r == c) v = xc;
+        else if (r > c && r < nb) v -= L[(int64_t)(k0 + r) * ld + k0 + c] * xc;
+    }
+    if (r < nb) z[k0 + r] = v;
+}
+
+__global__ __launch_bounds__(64) void k_trsv_diag_bwd(const double* __restrict__ L, int64_t ld, int k0, int nb,
+                                                      double* __restrict__ z) {
+    // x = L11^-T z  in place; lane r owns unknown r; step c from nb-1 down: x_c = v_c / L_cc ; v_r -= L[c][r] x_c (r < c)
+    int r = threadIdx.x;
+    double v = (r < nb) ? z[k0 + r] : 0.0;
+    for (int c = nb - 1; c >= 0; --c) {
+        double lcc = L[(int64_t)(k0 + c) * ld + k0 + c];
+        double xc = __shfl(v, c, 64) / lcc;
+        if (r == c) v = xc;
+        else if (r < c) v -= L[(int64_t)(k0 + c) * ld + k0 + r] * xc;
+    }
+    if (r < nb) z[k0 + r] = v;
+}
+
+__global__ __launch_bounds__(256) void k_trsv_panel_axpy(const double* __restrict__ L, int64_t ld, int k0, int nb,
+                                                         double* __restrict__ z) {
+    int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= k0) return;
+    double acc = 0.0;
+    for (int r = 0; r < nb; ++r) acc = fma(L[(int64_t)(k0 + r) * ld + j], z[k0 + r], acc);
+    z[j] -= acc;
+}
+
+// out[i] = || A[i, :] ||_2   (one wavefront per row) - KT_residuals / compute_nu! (common.jl:41, slp.jl:58)
+__global__ __launch_bounds__(256) void k_row_norms(const double* __restrict__ A, int64_t ld, double* __restrict__ out, int64_t M,
+                                                   int64_t ncols) {
+    int64_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= M) return;
+    int lane = threadIdx.x & 63;
+    const double* row = A + i * ld;
+    double acc = 0.0;
+    for (int64_t j = lane; j < ncols; j += 64) acc = fma(row[j], row[j], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) out[i] = sqrt(acc);
+}

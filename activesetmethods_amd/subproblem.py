@@ -1,0 +1,133 @@
+"""Host-side mirror of the reference's sub-problem interface (src/algorithms/subproblem.jl) on top of
+the C ABI of libasmhip (include/asm_hip.h).
+
+    QpData            subproblem.jl:3-14  (same field names; Q is always None on the SLP path, slp.jl:12)
+    HipSubOptimizer   the `AbstractSubOptimizer` (subproblem.jl:1) that replaces `QpModel`; it is created
+                      once per SLP run (slp.jl:25-36) and called once per outer iteration with
+                      `sub_optimize(x_k, Delta, feasibility)` -> the reference's 6-tuple (subproblem.jl:541)
+
+The Jacobian travels as the COO value vector `dE` in `j_str` order (what `eval_jac_g` fills,
+slp.jl:186-191); `compute_jacobian_matrix` (common.jl:12-20) runs on the GPU inside the call.
+"""
+import ctypes as C
+import numpy as np
+from . import _lib
+
+
+class AsmHipError(RuntimeError):
+    pass
+
+
+class QpData:
+    """LpData(slp) of slp.jl:8-21: c = df, c0 = f, A = Jacobian (as COO values dE), b = E."""
+
+    def __init__(self, c, c0, dE, b, c_lb, c_ub, v_lb, v_ub, sense="MIN_SENSE", Q=None):
+        self.sense, self.Q = sense, Q
+        self.c, self.c0, self.dE, self.b = c, c0, dE, b
+        self.c_lb, self.c_ub, self.v_lb, self.v_ub = c_lb, c_ub, v_lb, v_ub
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class HipSubOptimizer:
+    """One handle <-> one HIP stream <-> one LP skeleton (create_model!, subproblem.jl:51-215)."""
+
+    def __init__(self, data, j_row, j_col, device=0):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        rc = self._lib.asm_create(int(device), C.byref(self._h))
+        if rc != 0:
+            raise AsmHipError("asm_create(device=%d) failed with code %d (no usable HIP device?)" % (device, rc))
+        self.data = data
+        self.j_row = np.ascontiguousarray(j_row, dtype=np.int64)
+        self.j_col = np.ascontiguousarray(j_col, dtype=np.int64)
+        self.n = len(data.v_lb)
+        self.m = len(data.c_lb)
+        assert self.n > 0 and self.m >= 0                       # subproblem.jl:65-72
+        assert len(data.c_ub) == self.m and len(data.v_ub) == self.n
+        c_lb, c_ub, v_lb, v_ub = map(_f64, (data.c_lb, data.c_ub, data.v_lb, data.v_ub))
+        self._check(self._lib.asm_sublp_setup(self._h, self.n, self.m, len(self.j_row), _lib.i64ptr(self.j_row),
+                                              _lib.i64ptr(self.j_col), _lib.dptr(c_lb), _lib.dptr(c_ub),
+                                              _lib.dptr(v_lb), _lib.dptr(v_ub)))
+        self.nslack = np.where((c_lb > -np.inf) & (c_ub < np.inf), 2, 1)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise AsmHipError("libasmhip error %d: %s" % (rc, self._lib.asm_last_error(self._h).decode()))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.asm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ the hot call
+    def sub_optimize(self, x_k, Delta, feasibility=False):
+        """sub_optimize!(qp, x_k, Δ, feasibility) - subproblem.jl:229-542.
+        Returns (Xsol, lambda, mult_x_U, mult_x_L, p_slack, status)."""
+        d, n, m = self.data, self.n, self.m
+        assert len(d.c) == n and len(d.b) == m and len(x_k) == n   # subproblem.jl:239-246
+        self.upload(d.dE, d.c, d.c0, d.b, x_k)
+        return self.solve_resident(Delta, feasibility)
+
+    def upload(self, dE, df, f, E, x_k):
+        dE, df, E, x_k = map(_f64, (dE, df, E, x_k))
+        assert len(dE) == len(self.j_row)
+        self._check(self._lib.asm_sublp_upload(self._h, _lib.dptr(dE), _lib.dptr(df), float(f), _lib.dptr(E), _lib.dptr(x_k)))
+
+    def solve_resident(self, Delta, feasibility=False):
+        n, m = self.n, self.m
+        Xsol = np.empty(n); lam = np.empty(m); mU = np.empty(n); mL = np.empty(n)
+        ps = np.empty(2 * max(m, 1)); status = C.c_int32(0)
+        self._check(self._lib.asm_sublp_solve_resident(self._h, float(Delta), int(bool(feasibility)), _lib.dptr(Xsol),
+                                                       _lib.dptr(lam), _lib.dptr(mU), _lib.dptr(mL), _lib.dptr(ps),
+                                                       C.byref(status)))
+        p_slack = {}
+        for i in range(m):                                       # Dict{Int,Vector{Float64}}, subproblem.jl:495-505
+            p_slack[i] = [float(ps[2 * i])] if self.nslack[i] == 1 else [float(ps[2 * i]), float(ps[2 * i + 1])]
+        return Xsol, lam, mU, mL, p_slack, int(status.value)
+
+    # ------------------------------------------------------------------ observability
+    def active_set(self):
+        nr, nsl = C.c_int64(0), C.c_int64(0)
+        rc = self._lib.asm_sublp_active_set(self._h, None, None, None, C.byref(nr), C.byref(nsl))
+        if rc != 0:
+            return None
+        rows = np.empty(nr.value, np.int32); bnd = np.empty(self.n, np.int32); sl = np.empty(max(nsl.value, 1), np.int32)
+        self._check(self._lib.asm_sublp_active_set(self._h, _lib.i32ptr(rows), _lib.i32ptr(bnd), _lib.i32ptr(sl), None, None))
+        return rows, bnd, sl[:nsl.value]
+
+    def reset_warm(self):
+        self._check(self._lib.asm_sublp_reset_warm(self._h))
+
+    def last_stats(self):
+        s = _lib.SolveStats()
+        self._check(self._lib.asm_sublp_last_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in s._fields_}
+
+    def kernel_stats(self, reset=False):
+        s = _lib.KernelStats()
+        self._check(self._lib.asm_kernel_stats_get(self._h, C.byref(s)))
+        out = {name: dict(ms=s.ms[i], calls=s.calls[i], flops=s.flops[i], bytes=s.bytes[i]) for i, name in enumerate(_lib.K_NAMES)}
+        if reset:
+            self._check(self._lib.asm_kernel_stats_reset(self._h))
+        return out
+
+    # per-iteration reductions on the resident Jacobian (common.jl:35-44, slp.jl:54-66)
+    def kt_residuals(self, df, lam, mult_x_U, mult_x_L):
+        out = C.c_double(0.0)
+        df, lam, mult_x_U, mult_x_L = map(_f64, (df, lam, mult_x_U, mult_x_L))
+        self._check(self._lib.asm_kt_residuals(self._h, _lib.dptr(df), _lib.dptr(lam), _lib.dptr(mult_x_U), _lib.dptr(mult_x_L), C.byref(out)))
+        return out.value
+
+    def jac_row_norms(self):
+        out = np.empty(max(self.m, 1))
+        self._check(self._lib.asm_jac_row_norms(self._h, _lib.dptr(out)))
+        return out[:self.m]

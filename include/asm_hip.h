@@ -1,0 +1,128 @@
+/* libasmhip - C ABI of the MI355X-native SLP sub-problem solver.
+ *
+ * This is the drop-in boundary for the per-iteration sub-LP path of exanauts/ActiveSetMethods:
+ * everything `sub_optimize!(slp, Δ)` (src/algorithms/slp.jl:23-47) does below the SLP outer loop -
+ * Jacobian assembly (src/algorithms/common.jl:12-20), LP formulation for the normal and the
+ * feasibility-restoration phase (src/algorithms/subproblem.jl:51-215, 229-484), the LP solve that the
+ * reference hands to an external MOI optimizer (subproblem.jl:490, GLPK in all its tests) and the
+ * extraction of step / multipliers (subproblem.jl:494-541).
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary; every entry returns 0 on success, <0 on misuse or a
+ *     HIP error (asm_last_error gives the text).  The LP outcome is reported only through `status`.
+ *   - the caller owns every array; the library copies what it needs during the call and keeps no host
+ *     pointer afterwards.  Device buffers belong to the handle and are freed by asm_destroy.
+ *   - reals are IEEE double, indices int64 and 1-BASED exactly as the reference's `j_str`
+ *     (src/MOI_wrapper.jl:726-746); +-Inf bounds are IEEE infinities.
+ *   - one handle <-> one HIP stream; distinct handles may be used concurrently from different host
+ *     threads / devices (needed for scenario batches); a single handle is not re-entrant.
+ *
+ * Reference-side binding (Julia `ccall`): see INTEGRATION.md.
+ */
+#ifndef ASM_HIP_H
+#define ASM_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct asm_handle asm_handle;
+
+/* MOI.TerminationStatusCode values this path can produce (subproblem.jl:491, 500-539). */
+enum { ASM_OPTIMAL = 1, ASM_INFEASIBLE = 2, ASM_DUAL_INFEASIBLE = 3, ASM_OTHER = 4 };
+
+/* error codes */
+enum { ASM_OK = 0, ASM_ERR_ARG = -1, ASM_ERR_HIP = -2, ASM_ERR_STATE = -3, ASM_ERR_UNSUPPORTED = -11 };
+
+/* Replaces `MOI.instantiate(slp.options.external_optimizer)` (slp.jl:32). */
+int asm_create(int device, asm_handle** out);
+int asm_destroy(asm_handle* h);
+const char* asm_last_error(const asm_handle* h);
+
+/* Replaces QpModel(...) + create_model! (subproblem.jl:16-215): fixes the pattern and the row/slack
+ * layout.  j_row/j_col: nnz entries, 1-based, duplicates allowed, any order (order defines the
+ * accumulation order of duplicates).  Rows with c_lb=-Inf and c_ub=+Inf are rejected
+ * (ASM_ERR_UNSUPPORTED): create_model! adds no row for them and the reference's indexing breaks. */
+int asm_sublp_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz,
+                    const int64_t* j_row, const int64_t* j_col,
+                    const double* c_lb, const double* c_ub,
+                    const double* v_lb, const double* v_ub);
+
+/* Replaces sub_optimize!(qp, x_k, Δ, feasibility) (subproblem.jl:229-542) with data = LpData(slp)
+ * (slp.jl:8-21): dE = Jacobian values in j_str order, df = gradient (c), f = objective value (c0),
+ * E = constraint values (b).
+ * Outputs (caller-allocated): p[n] (Xsol), lambda[m], mult_x_U[n], mult_x_L[n],
+ *   p_slack[2m]: p_slack[2i], p_slack[2i+1] = slack values of row i, second entry NaN when the row has
+ *   one slack (Dict{Int,Vector{Float64}} of subproblem.jl:495-505);  status: enum above.
+ * INFEASIBLE -> all outputs zero (subproblem.jl:532-536). */
+int asm_sublp_solve(asm_handle* h, const double* dE, const double* df, double f, const double* E,
+                    const double* x_k, double delta, int feasibility,
+                    double* p, double* lambda, double* mult_x_U, double* mult_x_L, double* p_slack,
+                    int32_t* status);
+
+/* Split form of the same call for callers that keep the evaluation results resident in HBM:
+ * upload once (or write the device buffers directly), then solve from device-resident inputs.
+ * asm_sublp_solve == asm_sublp_upload + asm_sublp_solve_resident. */
+int asm_sublp_upload(asm_handle* h, const double* dE, const double* df, double f, const double* E,
+                     const double* x_k);
+int asm_sublp_solve_resident(asm_handle* h, double delta, int feasibility,
+                             double* p, double* lambda, double* mult_x_U, double* mult_x_L, double* p_slack,
+                             int32_t* status);
+
+/* Active set of the last OPTIMAL solve, as the reference could observe it from the LP solution:
+ * row_state[m+nadj]: 1 active / 0 inactive (rows m.. are the extra `<=` rows of range constraints,
+ * in the order of `adj`, subproblem.jl:200-214); bound_state[n]: -1 at lower, +1 at upper, 0 free;
+ * slack_state[nslack]: 1 basic / 0 at its bound (all 0 in the normal phase).
+ * Any pointer may be NULL.  n_rows/n_slack receive the array lengths. */
+int asm_sublp_active_set(const asm_handle* h, int32_t* row_state, int32_t* bound_state, int32_t* slack_state,
+                         int64_t* n_rows, int64_t* n_slack);
+
+/* Drop the retained active sets (the analogue of GLPK's retained basis, slp.jl:38-40). */
+int asm_sublp_reset_warm(asm_handle* h);
+
+/* Statistics of the last solve / accumulated device-kernel timing. */
+typedef struct {
+    int32_t path;          /* 0 warm, 1 ipm stage0+polish, 2 stage1, 3 stage2, 4 ipm+ref, 5 unpolished, 6 infeasible */
+    int32_t polished;
+    int32_t ipm_iters;
+    int32_t nfact;         /* Cholesky factorisations */
+    int32_t eqp;           /* active-set (EQP) solves */
+    int32_t M, n, ns;      /* LP rows, columns, slack columns */
+    double  ipm_pinf, ipm_dinf, ipm_gap;
+    double  kkt_pr, kkt_du;
+    double  wall_ms;       /* host wall time of the solve */
+} asm_solve_stats;
+int asm_sublp_last_stats(const asm_handle* h, asm_solve_stats* out);
+
+/* Device time per kernel family, measured with HIP events on the handle's stream. */
+enum { ASM_K_ASSEMBLE = 0, ASM_K_SCALE, ASM_K_GEMV, ASM_K_SYRK, ASM_K_CHOL, ASM_K_TRSV, ASM_K_COUNT };
+typedef struct {
+    double  ms[ASM_K_COUNT];      /* accumulated device milliseconds */
+    int64_t calls[ASM_K_COUNT];   /* number of timed regions */
+    double  flops[ASM_K_COUNT];   /* algorithmic flops issued */
+    double  bytes[ASM_K_COUNT];   /* algorithmic bytes moved */
+} asm_kernel_stats;
+int asm_kernel_stats_get(asm_handle* h, asm_kernel_stats* out);
+int asm_kernel_stats_reset(asm_handle* h);
+
+/* ---- per-iteration reductions that consume J, lambda already in HBM (common.jl:35-44) ----------- */
+/* KT_residuals(df, lambda, mult_x_U, mult_x_L, J) with J = the Jacobian assembled by the last
+ * upload/solve on this handle. */
+int asm_kt_residuals(asm_handle* h, const double* df, const double* lambda,
+                     const double* mult_x_U, const double* mult_x_L, double* out);
+/* per-row 2-norms of the assembled Jacobian (compute_nu!, slp.jl:54-66). */
+int asm_jac_row_norms(asm_handle* h, double* out_m);
+
+/* ---- kernel-level test hooks (used by tests/ to check each kernel against NumPy) ---------------- */
+int asm_test_syrk(asm_handle* h, const double* A, int64_t M, int64_t K, const int32_t* idx, int64_t Ms,
+                  const double* theta, const double* diag, double* S_out /* Ms*Ms, lower valid */, int tile);
+int asm_test_cholesky(asm_handle* h, const double* S /* N*N sym */, int64_t N, double* L_out /* N*N lower */);
+int asm_test_chol_solve(asm_handle* h, const double* S, int64_t N, const double* b, double* x);
+int asm_test_gemv(asm_handle* h, const double* A, int64_t M, int64_t K, const double* x, const double* y,
+                  double* Ax, double* ATy);
+int asm_test_assemble(asm_handle* h, const double* dE, double* J_out /* (m+nadj)*n */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

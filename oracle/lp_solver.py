@@ -33,6 +33,7 @@ TOL_P = 1e-9      # primal feasibility of the accepted vertex (scaled units)
 TOL_D = 1e-6      # dual feasibility of the accepted vertex (scaled units)
 IPM_TOL = 1e-8
 IPM_MAXIT = 60
+IPM_REFINE = 0
 CHOL_NB = 64
 PIV_BIG = 1e128
 
@@ -223,7 +224,7 @@ class IPM:
                     np.add.at(tmp, lp.srow, lp.scoef * ths_inv * hs)
                     rhs -= tmp
                 dy = chol_solve(L, rhs)
-                for _ in range(2):                       # iterative refinement on S dy = rhs
+                for _ in range(IPM_REFINE):              # iterative refinement on S dy = rhs
                     dy = dy + chol_solve(L, rhs - S @ dy)
                 dp = thp_inv * (hp + A.T @ dy)
                 ds = ths_inv * (hs + lp.scoef * dy[lp.srow])

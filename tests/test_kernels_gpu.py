@@ -1,0 +1,107 @@
+"""Kernel-level checks of libasmhip against NumPy (float64), through the C ABI test hooks."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def handle(hip_lib):
+    h = C.c_void_p()
+    assert hip_lib.asm_create(0, C.byref(h)) == 0
+    yield h
+    hip_lib.asm_destroy(h)
+
+
+def _d(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+@pytest.mark.parametrize("M,K,Ms,tile", [(40, 50, 40, 1), (100, 70, 37, 1), (200, 333, 200, 2), (300, 129, 211, 4),
+                                           (500, 1000, 500, 0), (130, 64, 130, 4)])
+def test_syrk_matches_numpy(hip_lib, handle, M, K, Ms, tile):
+    rng = np.random.default_rng(M * 7 + K)
+    A = rng.standard_normal((M, K))
+    theta = rng.uniform(0.0, 2.0, K)
+    theta[rng.random(K) < 0.2] = 0.0
+    idx = np.sort(rng.choice(M, Ms, replace=False)).astype(np.int32)
+    diag = rng.uniform(0.0, 1.0, Ms)
+    S = np.zeros((Ms, Ms))
+    rc = hip_lib.asm_test_syrk(handle, _d(A), M, K, idx.ctypes.data_as(C.POINTER(C.c_int32)), Ms, _d(theta), _d(diag), _d(S), tile)
+    assert rc == 0, hip_lib.asm_last_error(handle)
+    ref = (A[idx] * theta) @ A[idx].T + np.diag(diag)
+    err = np.abs(np.tril(S) - np.tril(ref)).max() / np.abs(ref).max()
+    assert err < 1e-13          # f64 MFMA accumulation, K <= 1000
+
+
+@pytest.mark.parametrize("N", [1, 17, 64, 65, 200, 513, 1000])
+def test_cholesky_and_solve(hip_lib, handle, N):
+    rng = np.random.default_rng(N)
+    B = rng.standard_normal((N, N + 5))
+    S = B @ B.T + 0.1 * np.eye(N)
+    L = np.zeros((N, N))
+    assert hip_lib.asm_test_cholesky(handle, _d(S), N, _d(L)) == 0, hip_lib.asm_last_error(handle)
+    Lref = np.linalg.cholesky(S)
+    assert np.abs(L - Lref).max() / np.abs(Lref).max() < 1e-11
+    b = rng.standard_normal(N)
+    x = np.zeros(N)
+    assert hip_lib.asm_test_chol_solve(handle, _d(S), N, _d(b), _d(x)) == 0
+    xref = np.linalg.solve(S, b)
+    assert np.abs(x - xref).max() / np.abs(xref).max() < 1e-9
+    assert np.abs(S @ x - b).max() < 1e-10 * max(1.0, np.abs(S).max() * np.abs(x).max())
+
+
+def test_cholesky_pivot_guard(hip_lib, handle):
+    """A duplicated row makes S singular: the static guard drops it instead of producing NaNs."""
+    rng = np.random.default_rng(3)
+    B = rng.standard_normal((30, 50))
+    B[7] = B[3]
+    S = B @ B.T
+    L = np.zeros((30, 30))
+    assert hip_lib.asm_test_cholesky(handle, _d(S), 30, _d(L)) == 0
+    assert np.isfinite(L).all()
+    assert L[7, 7] > 1e100
+
+
+@pytest.mark.parametrize("M,K", [(5, 3), (130, 77), (500, 1000), (1000, 129)])
+def test_gemv(hip_lib, handle, M, K):
+    rng = np.random.default_rng(M + K)
+    A = rng.standard_normal((M, K)); x = rng.standard_normal(K); y = rng.standard_normal(M)
+    Ax = np.zeros(M); ATy = np.zeros(K)
+    assert hip_lib.asm_test_gemv(handle, _d(A), M, K, _d(x), _d(y), _d(Ax), _d(ATy)) == 0
+    assert np.abs(Ax - A @ x).max() < 1e-12 * K
+    assert np.abs(ATy - A.T @ y).max() < 1e-12 * M
+
+
+@pytest.mark.parametrize("seed,n,m,density,dup,nrange", [(1, 7, 5, 0.5, 0.5, 2), (2, 60, 40, 0.1, 0.3, 5), (3, 50, 30, 1.0, 0.0, 0),
+                                                         (4, 33, 21, 0.3, 1.0, 3)])
+def test_assembly_bit_exact(hip_lib, seed, n, m, density, dup, nrange):
+    """Duplicate accumulation in j_str order is bitwise identical to the oracle's restatement of
+    common.jl:12-20, including the stale-entry rule of the extra range rows (subproblem.jl:448-457)."""
+    from tests.util import random_subproblem
+    from activesetmethods_amd.subproblem import QpData, HipSubOptimizer
+    from oracle.subproblem import QpData as OQpData, QpModel, compute_jacobian_matrix
+    sp = random_subproblem(seed, n, m, density, dup, nrange)
+    opt = HipSubOptimizer(QpData(sp['df'], sp['f'], sp['dE'], sp['E'], sp['c_lb'], sp['c_ub'], sp['v_lb'], sp['v_ub']),
+                          sp['j_row'], sp['j_col'])
+    qp = None
+    rng = np.random.default_rng(seed + 100)
+    for call in range(3):
+        dE = sp['dE'].copy()
+        if call == 1:
+            dE[rng.random(len(dE)) < 0.4] = 0.0          # entries vanish: stale coefficients must persist
+        if call == 2:
+            dE = rng.standard_normal(len(dE))
+        A, stored = compute_jacobian_matrix(m, n, sp['j_row'] - 1, sp['j_col'] - 1, dE)
+        data = OQpData(sp['df'], sp['f'], A, sp['E'], sp['c_lb'], sp['c_ub'], sp['v_lb'], sp['v_ub'], stored)
+        if qp is None:
+            qp = QpModel(data, sp['j_row'], sp['j_col'])
+        qp.data = data
+        lp = qp.build_lp(sp['x_k'], 0.4, False)
+        M = m + len(qp.adj)
+        Jg = np.zeros((M, n))
+        assert hip_lib.asm_test_assemble(opt._h, _d(np.ascontiguousarray(dE)), _d(Jg)) == 0
+        assert np.array_equal(Jg, lp.A)
+    opt.close()

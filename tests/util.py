@@ -1,0 +1,70 @@
+"""Shared generators for the parity tests (seeded, deterministic)."""
+import numpy as np
+
+INF = np.inf
+
+
+def random_subproblem(seed, n, m, density=1.0, dup_frac=0.0, n_range=0, infeasible=False, delta=0.4):
+    """A random instance of the data `sub_optimize!` sees (subproblem.jl:229-246): COO Jacobian with
+    optional duplicate entries, mixed EQ / >= / <= / range rows, finite variable bounds, a point x_k."""
+    rng = np.random.default_rng(seed)
+    mask = rng.random((m, n)) < density
+    mask[np.arange(m), rng.integers(0, n, m)] = True
+    rows, cols = np.nonzero(mask)
+    vals = rng.standard_normal(len(rows)) / np.sqrt(max(1.0, density * n))
+    ndup = int(dup_frac * len(rows))
+    if ndup:
+        pick = rng.integers(0, len(rows), ndup)
+        rows = np.concatenate([rows, rows[pick]]); cols = np.concatenate([cols, cols[pick]])
+        vals = np.concatenate([vals, 0.25 * rng.standard_normal(ndup)])
+        perm = rng.permutation(len(rows))
+        rows, cols, vals = rows[perm], cols[perm], vals[perm]
+    J = np.zeros((m, n))
+    np.add.at(J, (rows, cols), vals)
+    x_k = rng.uniform(-0.5, 0.5, n)
+    v_lb = -np.ones(n); v_ub = np.ones(n)
+    p_star = rng.uniform(-0.3, 0.3, n) * min(1.0, delta / 0.4)
+    E = rng.standard_normal(m) * 0.1                       # current constraint values b
+    act = E + J @ p_star                                    # linearised value at a feasible step
+    c_lb = np.full(m, -INF); c_ub = np.full(m, INF)
+    meq = m // 3
+    c_lb[:meq] = act[:meq]; c_ub[:meq] = act[:meq]
+    k = (m - meq) // 2
+    c_ub[meq:meq + k] = act[meq:meq + k] + rng.uniform(0, 0.05, k)
+    c_lb[meq + k:] = act[meq + k:] - rng.uniform(0, 0.05, m - meq - k)
+    for i in range(n_range):                                # two-sided rows at the end
+        r = m - 1 - i
+        c_lb[r] = act[r] - 0.02; c_ub[r] = act[r] + 0.03
+    if infeasible:
+        c_lb[0] = c_ub[0] = act[0] + 50.0
+    df = rng.standard_normal(n)
+    return dict(n=n, m=m, j_row=rows + 1, j_col=cols + 1, dE=vals, df=df, f=0.3, E=E, x_k=x_k,
+                c_lb=c_lb, c_ub=c_ub, v_lb=v_lb, v_ub=v_ub, delta=delta, J=J)
+
+
+def oracle_solve(sp, feasibility=False, qp=None):
+    from oracle.subproblem import QpData, QpModel, compute_jacobian_matrix
+    A, stored = compute_jacobian_matrix(sp['m'], sp['n'], sp['j_row'] - 1, sp['j_col'] - 1, sp['dE'])
+    data = QpData(sp['df'], sp['f'], A, sp['E'], sp['c_lb'], sp['c_ub'], sp['v_lb'], sp['v_ub'], stored)
+    if qp is None:
+        qp = QpModel(data, sp['j_row'], sp['j_col'])
+    else:
+        qp.data = data
+    out = qp.sub_optimize(sp['x_k'], sp['delta'], feasibility)
+    return qp, out
+
+
+def hip_solve(sp, feasibility=False, opt=None, device=0):
+    from activesetmethods_amd.subproblem import QpData, HipSubOptimizer
+    data = QpData(sp['df'], sp['f'], sp['dE'], sp['E'], sp['c_lb'], sp['c_ub'], sp['v_lb'], sp['v_ub'])
+    if opt is None:
+        opt = HipSubOptimizer(data, sp['j_row'], sp['j_col'], device=device)
+    else:
+        opt.data = data
+    out = opt.sub_optimize(sp['x_k'], sp['delta'], feasibility)
+    return opt, out
+
+
+def rel_err(a, b):
+    a = np.asarray(a, float); b = np.asarray(b, float)
+    return float(np.abs(a - b).max(initial=0.0) / max(1.0, np.abs(b).max(initial=0.0)))
