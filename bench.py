@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""Benchmark of the SLP sub-problem hot path (BASELINE.json metric: SLP iterations/sec).
+
+  python bench.py --gpus N --steps K --warmup W [--workload c2|c2small] [--algorithm "Trust Region"]
+
+A "step" is one SLP outer iteration that reaches the LP solve: evaluation callbacks,
+Jacobian assembly, LP formulation, the HIP LP solve and the merit/step logic.  At N>1 every rank runs
+its own independent NLP replica (the path does not shard inside one NLP - "replicas only");
+value = total steps of all ranks / max-over-ranks time.  One JSON line is printed by rank 0.
+
+The dominant kernel's roofline numbers come from HIP events recorded on the solver's own stream
+around each launch (include/asm_hip.h: asm_kernel_stats_get); the CPU baseline is the oracle's NumPy
+restatement of the same path (oracle/, "port") on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# dense FP64 matrix-core peak of MI355X (AMD public specification; the HIP guides in this image give no
+# FP64 figure) and HBM3E peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+FP64_MFMA_PEAK_TFLOPS = 78.6
+HBM_PEAK_GBS = 8000.0
+
+WORKLOADS = {
+    "c2": dict(n=1000, m=500, desc="synthetic dense NLP n=1000 m=500 (BASELINE.json configs[1])"),
+    "c2small": dict(n=200, m=100, desc="synthetic dense NLP n=200 m=100 (reduced; parity-test size)"),
+}
+
+
+def make_problem(name):
+    from activesetmethods_amd import problems
+    w = WORKLOADS[name]
+    return problems.synthetic_dense_nlp(w["n"], w["m"])
+
+
+def run_steps(pr, algorithm, device, n_steps, state):
+    """Advance the SLP run by `n_steps` LP solves (restarting from x0 if the run terminates)."""
+    import activesetmethods_amd as A
+    done = 0
+    while done < n_steps:
+        if state.get("slp") is None:
+            par = A.Parameters(algorithm=algorithm, max_iter=10 ** 9,
+                               external_optimizer=lambda d, r, c: A.HipSubOptimizer(d, r, c, device=device))
+            mdl = A.Model.from_problem(pr, par)
+            slp = A.SlpTR(mdl) if algorithm == "Trust Region" else A.SlpLS(mdl)
+            state["slp"], state["resume"] = slp, False
+            if state.get("opt") is not None:            # keep one handle (and its HBM buffers) per rank
+                slp.optimizer = state["opt"]
+        slp = state["slp"]
+        before = slp.lp_solves
+        target = before + (n_steps - done)
+        slp.run(max_lp_solves=target, resume=state["resume"])
+        state["resume"] = True
+        state["opt"] = slp.optimizer
+        done += slp.lp_solves - before
+        if slp.lp_solves < target:                      # the SLP run terminated: restart from x0
+            state["restarts"] = state.get("restarts", 0) + 1
+            state["slp"] = None
+    return done
+
+
+def cpu_baseline(pr, algorithm, budget_s):
+    """Oracle (NumPy restatement of the same path) on a bounded sample of the same workload."""
+    import numpy as np
+    from oracle import slp as O
+    try:
+        import threadpoolctl
+        cores = max((p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()), default=1)
+    except Exception:
+        cores = os.cpu_count() or 1
+    steps, t_total, k = 0, 0.0, 1
+    while True:
+        m = O.Model(pr.n, pr.m, pr.x_L, pr.x_U, pr.g_L, pr.g_U, pr.j_str, pr.eval_f, pr.eval_g, pr.eval_grad_f, pr.eval_jac_g,
+                    O.Parameters(algorithm=algorithm, max_iter=k))
+        m.x[:] = pr.x0
+        t0 = time.perf_counter()
+        s = O.optimize(m)
+        dt = time.perf_counter() - t0
+        steps, t_total = s.lp_solves, dt
+        if dt >= 0.5 * budget_s or k >= 64:
+            break
+        k = max(k + 1, int(k * min(4.0, 0.8 * budget_s / max(dt, 1e-3))))
+    return dict(value=steps / t_total, unit="iter/s", cores=int(cores), kind="port",
+                sample="oracle SLP (%s) from x0, first %d SLP iterations of the same NLP, %.1f s" % (algorithm, steps, t_total))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--algorithm", default="Trust Region")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+
+    pr = make_problem(args.workload)
+    state = {}
+    run_steps(pr, args.algorithm, local_rank, args.warmup, state)
+    opt = state["opt"]
+    opt.kernel_stats(reset=True)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    done = run_steps(pr, args.algorithm, local_rank, args.steps, state)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert done == args.steps
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ks = opt.kernel_stats()
+    slp = state["slp"] or None
+    dom = max(ks, key=lambda k: ks[k]["ms"])
+    d = ks[dom]
+    if dom in ("syrk", "chol"):
+        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+        roof = dict(bound="mfma", kernel=dom, achieved=ach, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=ach / FP64_MFMA_PEAK_TFLOPS, traffic=None,
+                    avg_launch_ms=d["ms"] / max(d["calls"], 1), launches=d["calls"])
+    else:
+        ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
+        roof = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                    traffic=None, avg_launch_ms=d["ms"] / max(d["calls"], 1), launches=d["calls"])
+
+    if rank == 0:
+        w = WORKLOADS[args.workload]
+        out = {
+            "metric": "SLP iterations/sec", "value": world * args.steps / elapsed, "unit": "iter/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": w["desc"], "algorithm": args.algorithm, "n": w["n"], "m": w["m"],
+                       "parallelism": "replicas x%d" % world, "restarts": state.get("restarts", 0)},
+            "roofline": roof,
+            "kernels_ms": {k: round(v["ms"], 3) for k, v in ks.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(pr, args.algorithm, args.cpu_seconds)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,78 @@
+"""End-to-end SLP runs: the HIP path (activesetmethods_amd.slp -> libasmhip) against the oracle's
+restatement of the same callers, plus the reference's own known answers for the path
+(test/runtests.jl:11-13: toy -> X = Y = -1, LOCALLY_SOLVED)."""
+import numpy as np
+import pytest
+
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_run(pr, **kw):
+    from oracle import slp as O
+    m = O.Model(pr.n, pr.m, pr.x_L, pr.x_U, pr.g_L, pr.g_U, pr.j_str, pr.eval_f, pr.eval_g, pr.eval_grad_f, pr.eval_jac_g,
+                O.Parameters(**kw))
+    m.x[:] = pr.x0
+    return m, O.optimize(m)
+
+
+def _hip_run(pr, **kw):
+    import activesetmethods_amd as A
+    m = A.Model.from_problem(pr, A.Parameters(**kw))
+    return m, A.optimize(m)
+
+
+def _compare_traces(so, sh, tol=1e-9):
+    assert len(so.trace) == len(sh.trace)
+    for ro, rh in zip(so.trace, sh.trace):
+        assert ro['status'] == rh['status'] and ro['fr'] == rh['fr'] and ro['iter'] == rh['iter']
+        if ro['status'] == 1:
+            for a, b in zip(ro['sets'], rh['sets']):
+                assert np.array_equal(a, b)                       # active-set index sequence identical
+            assert rel_err(rh['p'], ro['p']) < tol
+            assert rel_err(rh['lam'], ro['lam']) < tol
+            assert rel_err(rh['mult_x_U'], ro['mult_x_U']) < tol and rel_err(rh['mult_x_L'], ro['mult_x_L']) < tol
+
+
+@pytest.mark.parametrize("alg", ["Line Search", "Trust Region"])
+def test_toy_known_answer_and_trace(alg):
+    from activesetmethods_amd import problems
+    mh, sh = _hip_run(problems.toy_problem(), algorithm=alg)
+    assert mh.status == 0                                                 # LOCALLY_SOLVED
+    assert np.allclose(mh.x, [-1.0, -1.0], rtol=1e-4)                     # test/runtests.jl:11-12
+    assert np.allclose(mh.mult_g, [0.0, 1.0 / 3.0, 0.0, 0.0], atol=1e-6)  # from df - J'lambda = 0 (common.jl:38)
+    mo, so = _oracle_run(problems.toy_problem(), algorithm=alg)
+    assert mo.status == mh.status and so.iter == sh.iter and so.lp_solves == sh.lp_solves
+    _compare_traces(so, sh)
+    assert rel_err(mh.x, mo.x) < 1e-9
+
+
+@pytest.mark.parametrize("alg,iters", [("Trust Region", 12), ("Line Search", 8)])
+def test_synthetic_dense_small_trace(alg, iters):
+    from activesetmethods_amd import problems
+    pr = problems.synthetic_dense_nlp(120, 60)
+    mh, sh = _hip_run(pr, algorithm=alg, max_iter=iters)
+    mo, so = _oracle_run(pr, algorithm=alg, max_iter=iters)
+    assert mo.status == mh.status and so.iter == sh.iter
+    _compare_traces(so, sh)
+    assert rel_err(mh.x, mo.x) < 1e-8
+    assert all(r['stats']['polished'] == 1 for r in sh.trace)
+
+
+def test_reductions_on_resident_jacobian():
+    """KT_residuals / row norms computed from the HBM-resident Jacobian (common.jl:35-44)."""
+    from activesetmethods_amd import problems, QpData, HipSubOptimizer
+    from oracle import slp as O
+    from oracle.subproblem import compute_jacobian_matrix
+    pr = problems.synthetic_dense_nlp(90, 40)
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-0.5, 0.5, pr.n)
+    df = pr.eval_grad_f(x, np.zeros(pr.n)); E = pr.eval_g(x, np.zeros(pr.m)); dE = pr.eval_jac_g(x, np.zeros(pr.nnz))
+    opt = HipSubOptimizer(QpData(df, 0.0, dE, E, pr.g_L, pr.g_U, pr.x_L, pr.x_U), pr.j_row, pr.j_col)
+    opt.upload(dE, df, 0.0, E, x)
+    lam = rng.standard_normal(pr.m); mu = rng.standard_normal(pr.n) * 0.1; ml = rng.standard_normal(pr.n) * 0.1
+    J, _ = compute_jacobian_matrix(pr.m, pr.n, pr.j_row - 1, pr.j_col - 1, dE)
+    assert abs(opt.kt_residuals(df, lam, mu, ml) - O.KT_residuals(df, lam, mu, ml, J)) < 1e-12
+    assert rel_err(opt.jac_row_norms(), np.linalg.norm(J, axis=1)) < 1e-13
+    opt.close()
