@@ -1,0 +1,160 @@
+"""CPU suite for everything around the HIP kernels: the C ABI library loads and exports exactly the
+symbols include/asm_hip.h declares (no compute call without a GPU), the host-side SLP drivers of the
+package reproduce the oracle's callers when driven through the `external_optimizer` plug-in slot, and
+the scenario-batch statistics reduce correctly over a world_size-2 gloo group."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "asm_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(asm_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from activesetmethods_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    syms = _header_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(lib, s), "libasmhip.so does not export %s" % s
+    assert sorted(_lib.PROTOTYPES) == syms          # the Python binding covers the whole header
+
+
+def test_missing_gpu_fails_loudly():
+    """No silent fallback: without a HIP device the sub-optimizer cannot be created."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from activesetmethods_amd import HipSubOptimizer, QpData, AsmHipError
+    d = QpData(np.ones(2), 0.0, np.ones(2), np.zeros(1), np.zeros(1), np.zeros(1), -np.ones(2), np.ones(2))
+    with pytest.raises(AsmHipError):
+        HipSubOptimizer(d, [1, 1], [1, 2])
+
+
+class _OracleBackedSubOptimizer:
+    """Stand-in for the HIP plug-in so that the package's SLP drivers can be exercised without a GPU.
+    (Test-only: the shipped default factory is HipSubOptimizer.)"""
+
+    def __init__(self, data, j_row, j_col):
+        from oracle.subproblem import QpModel
+        self.j_row, self.j_col = np.asarray(j_row), np.asarray(j_col)
+        self.data = data
+        self.qp = None
+        self._QpModel = QpModel
+        self._info = None
+
+    def upload(self, dE, df, f, E, x_k):
+        from oracle.subproblem import QpData, compute_jacobian_matrix
+        d = self.data
+        m, n = len(d.c_lb), len(d.v_lb)
+        A, st = compute_jacobian_matrix(m, n, self.j_row - 1, self.j_col - 1, np.array(dE))
+        self.A = A
+        od = QpData(np.array(df), f, A, np.array(E), d.c_lb, d.c_ub, d.v_lb, d.v_ub, st)
+        if self.qp is None:
+            self.qp = self._QpModel(od, self.j_row, self.j_col)
+        self.qp.data = od
+        self.x_k = np.array(x_k)
+
+    def solve_resident(self, Delta, feasibility=False):
+        out = self.qp.sub_optimize(self.x_k, Delta, feasibility)
+        self._info = out[6]
+        return out[:6]
+
+    def last_stats(self):
+        s = dict(self._info["stats"])
+        s["path"] = 0 if s["path"] == "warm" else 1
+        return s
+
+    def active_set(self):
+        return self._info["sets"]
+
+    def kt_residuals(self, df, lam, mU, mL):
+        from oracle.slp import KT_residuals
+        return KT_residuals(df, lam, mU, mL, self.A)
+
+    def jac_row_norms(self):
+        return np.linalg.norm(self.A, axis=1)
+
+
+@pytest.mark.parametrize("alg", ["Line Search", "Trust Region"])
+def test_host_drivers_follow_the_reference_callers(alg):
+    import activesetmethods_amd as A
+    from oracle import slp as O
+    for pr, iters in ((A.problems.toy_problem(), 1000), (A.problems.synthetic_dense_nlp(40, 20), 6)):
+        mh = A.Model.from_problem(pr, A.Parameters(algorithm=alg, max_iter=iters, external_optimizer=_OracleBackedSubOptimizer))
+        sh = A.optimize(mh)
+        mo = O.Model(pr.n, pr.m, pr.x_L, pr.x_U, pr.g_L, pr.g_U, pr.j_str, pr.eval_f, pr.eval_g, pr.eval_grad_f, pr.eval_jac_g,
+                     O.Parameters(algorithm=alg, max_iter=iters))
+        mo.x[:] = pr.x0
+        so = O.optimize(mo)
+        assert mh.status == mo.status and sh.iter == so.iter and sh.lp_solves == so.lp_solves
+        assert np.abs(mh.x - mo.x).max() < 1e-10
+        assert np.abs(mh.mult_g - mo.mult_g).max() < 1e-9
+        assert [r["fr"] for r in sh.trace] == [r["fr"] for r in so.trace]
+
+
+def test_parameters_defaults_are_the_reference_contract():
+    import activesetmethods_amd as A
+    p = A.Parameters()
+    assert (p.tol_direction, p.tol_residual, p.tol_infeas, p.max_iter) == (1e-6, 0.01, 0.01, 1000)    # src/parameters.jl:17-20
+    assert (p.eta, p.tau, p.min_alpha, p.tr_size) == (0.4, 0.9, 1e-6, 0.4)                           # :25-28
+    assert p.algorithm == "Line Search" and p.method == "SLP"
+    A.set_parameter(p, "max_iter", 7)
+    assert A.get_parameter(p, "max_iter") == 7
+    assert A.ApplicationReturnStatus[0] == "Solve_Succeeded" and A.ApplicationReturnStatus[-12] == "Invalid_Option"
+
+
+def test_partition_covers_all_scenarios():
+    from activesetmethods_amd.batch import partition
+    for n, w in ((512, 8), (10, 3), (2, 4)):
+        spans = [partition(n, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+    assert partition(512, 8, 3) == (192, 256)
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    import activesetmethods_amd as A
+    from activesetmethods_amd.batch import solve_batch
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+
+    def make_model(s):                      # scenario s: toy NLP started from a scenario-dependent point
+        pr = A.problems.toy_problem()
+        mdl = A.Model.from_problem(pr, A.Parameters(algorithm="Line Search", external_optimizer=_OracleBackedSubOptimizer))
+        mdl.x[:] = [0.1 * s, 0.0]
+        return mdl
+
+    slps, stats = solve_batch(make_model, 5, rank, world)
+    q.put((rank, len(slps), stats))
+    dist.destroy_process_group()
+
+
+def test_batch_statistics_all_reduce_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    res.sort()
+    assert [r[1] for r in res] == [3, 2]                         # block partition of 5 scenarios
+    s0, s1 = res[0][2], res[1][2]
+    assert s0 == s1                                              # every rank holds the reduced statistics
+    assert s0["scenarios"] == 5 and s0["converged"] == 5
+    assert s0["lp_solves"] >= s0["iterations"] - 5 and s0["wall_s"] > 0

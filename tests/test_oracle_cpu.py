@@ -1,0 +1,138 @@
+"""CPU suite: pins the oracle (the checker of every GPU parity test) against
+  - the known answers the reference's own tests hold for this path (test/runtests.jl:11-13, the two LP
+    snapshots test/sublp_org.lp / test/sublp.lp whose data is kept in tests/golden/sublp_snapshots.json),
+  - SciPy/HiGHS optima of seeded LPs (tests/golden/lp_highs.npz, made by scripts/gen_golden.py),
+and checks the literal quirks of the formulation."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import lp_solver as L
+from oracle import slp as O
+from oracle.subproblem import QpData, QpModel, compute_jacobian_matrix
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+INF = np.inf
+
+
+def test_lp_snapshots_known_answers():
+    d = json.load(open(os.path.join(GOLD, "sublp_snapshots.json")))
+    for name in ("sublp_org", "sublp"):
+        s = d[name]
+        lp = L.LP(s["q"], np.array(s["A"]), s["rtype"], s["r"], s["lb"], s["ub"], s["srow"], s["scoef"], s["w"], np.zeros(8))
+        out = L.solve_lp(lp)
+        assert out["status"] == L.OPTIMAL
+        obj = np.dot(s["q"], out["p"]) + np.dot(s["w"], out["s"])
+        assert abs(obj - s["expected_obj"]) < 1e-9
+        if "expected_x1" in s:
+            assert abs(out["p"][0] - s["expected_x1"]) < 1e-12
+        if "expected_dual_c1" in s:
+            assert abs(out["y"][2] - s["expected_dual_c1"]) < 1e-9
+
+
+def test_lp_solver_matches_highs_goldens():
+    g = np.load(os.path.join(GOLD, "lp_highs.npz"))
+    for i in range(int(g["count"])):
+        f = lambda k: g["lp%d_%s" % (i, k)]
+        out = L.solve_lp(L.LP(f("q"), f("A"), f("rtype"), f("r"), f("lb"), f("ub")))
+        assert out["status"] == L.OPTIMAL and out["stats"]["polished"] == 1
+        assert np.abs(out["p"] - f("x")).max() < 1e-9
+        assert np.abs(out["y"] - f("y")).max() < 1e-8
+        assert np.abs(out["z"] - f("z")).max() < 1e-8
+        assert abs(f("q") @ out["p"] - float(f("obj"))) < 1e-9
+        rowst, bst, sst = out["sets"]
+        assert np.array_equal(bst == -1, np.isclose(f("x"), f("lb"), atol=1e-9))     # identical active bounds
+        assert np.array_equal(bst == 1, np.isclose(f("x"), f("ub"), atol=1e-9))
+
+
+def test_infeasible_lp_detected_with_farkas_certificate():
+    g = np.load(os.path.join(GOLD, "lp_highs.npz"))
+    f = lambda k: g["lp1_%s" % k]
+    r = f("r").copy()
+    r[0] += 50.0
+    out = L.solve_lp(L.LP(f("q"), f("A"), f("rtype"), r, f("lb"), f("ub")))
+    assert out["status"] == L.INFEASIBLE
+
+
+def test_scaling_is_exact_powers_of_two():
+    x = np.array([3.0, 0.7, 0.71, 1e-5, 0.0, -2.0, 1000.0])
+    p = L.pow2_round(x)
+    assert np.array_equal(p, [4.0, 0.5, 1.0, 2.0 ** -17, 1.0, 1.0, 1024.0])
+
+
+def test_jacobian_assembly_duplicates_and_storage():
+    """common.jl:12-20 `+=` in j_str order; stored-entry semantics observed by subproblem.jl:448-457."""
+    rows = np.array([0, 0, 1, 1, 1]); cols = np.array([1, 1, 0, 2, 2])
+    J, st = compute_jacobian_matrix(2, 3, rows, cols, np.array([1.0, 2.0, 0.0, 5.0, -5.0]))
+    assert J[0, 1] == 3.0 and J[1, 2] == 0.0 and J[1, 0] == 0.0
+    assert st[0, 1] and st[1, 2] and not st[1, 0] and not st[0, 0]     # (1,2) stored although it cancelled to 0
+
+
+def _qp(c_lb, c_ub, E, J, n=2):
+    m = len(c_lb)
+    rows, cols = np.nonzero(np.ones((m, n)))
+    data = QpData(np.ones(n), 0.0, np.asarray(J, float), np.asarray(E, float), np.asarray(c_lb, float), np.asarray(c_ub, float),
+                  -10 * np.ones(n), 10 * np.ones(n))
+    return QpModel(data, rows + 1, cols + 1)
+
+
+def test_formulation_row_and_slack_layout():
+    """create_model! (subproblem.jl:83-214): 2 slacks when both bounds finite (equalities too), extra <= row per range row."""
+    qp = _qp([1.0, -INF, 0.0, 0.0], [1.0, 2.0, INF, 3.0], [0.0, 0.0, 0.0, 0.0], np.ones((4, 2)))
+    assert list(qp.kind) == [0, -1, 1, 2] and list(qp.adj) == [3] and qp.M == 5
+    assert list(qp.rtype) == [0, -1, 1, 1, -1]
+    assert list(qp.nslack) == [2, 1, 1, 2]
+    assert list(qp.srow) == [0, 0, 1, 2, 3, 4] and list(qp.scoef) == [1, -1, -1, 1, 1, -1]
+
+
+def test_restoration_shift_is_abs_viol_in_both_directions():
+    """subproblem.jl:289-295: b[i] -= abs(viol) whether the row is violated above or below; slack lower
+    bounds (0, viol) / (-viol, 0) for 2-slack rows and -abs(viol) for 1-slack rows (:298-381)."""
+    qp = _qp([1.0, -INF, 0.0], [1.0, 2.0, INF], [3.0, 5.0, -4.0], np.ones((3, 2)))
+    lp = qp.build_lp(np.zeros(2), 1000.0, True)
+    viol = np.array([1.0 - 3.0, 2.0 - 5.0, 0.0 - (-4.0)])           # c_ub-b (above), c_ub-b (above), c_lb-b (below)
+    b_shift = np.array([3.0, 5.0, -4.0]) - np.abs(viol)
+    assert np.allclose(lp.r, [1.0 - b_shift[0], 2.0 - b_shift[1], 0.0 - b_shift[2]])
+    assert np.allclose(lp.slo, [0.0, viol[0], -abs(viol[1]), -abs(viol[2])])
+    assert np.all(lp.q == 0) and np.all(lp.w == 1)
+    lpn = qp.build_lp(np.zeros(2), 1000.0, False)
+    assert lpn.ns == 0 and np.allclose(lpn.r, [1.0 - 3.0, 2.0 - 5.0, 0.0 + 4.0])
+
+
+def test_trust_region_only_multipliers_are_zeroed():
+    """subproblem.jl:522-529: a bound multiplier survives only if the active bound is the variable's own bound."""
+    J = np.array([[1.0, 1.0]])
+    data = QpData(np.array([1.0, -1.0]), 0.0, J, np.array([0.0]), np.array([-INF]), np.array([10.0]), np.array([-0.05, -5.0]),
+                  np.array([5.0, 5.0]))
+    qp = QpModel(data, [1, 1], [1, 2])
+    X, lam, mU, mL, ps, st, info = qp.sub_optimize(np.zeros(2), 0.1, False)
+    assert st == L.OPTIMAL and np.allclose(X, [-0.05, 0.1])
+    assert mL[0] == pytest.approx(1.0) and mU[1] == 0.0            # x1 at its own lower bound; x2 only at the trust region
+
+
+@pytest.mark.parametrize("alg", ["Line Search", "Trust Region"])
+def test_toy_known_answer(alg):
+    """test/runtests.jl:11-13: X = Y = -1 (rtol 1e-4), LOCALLY_SOLVED; multipliers (0, 1/3, 0, 0) follow
+    from df - J'lambda = 0 at the solution (common.jl:38)."""
+    from activesetmethods_amd import problems
+    pr = problems.toy_problem()
+    m = O.Model(pr.n, pr.m, pr.x_L, pr.x_U, pr.g_L, pr.g_U, pr.j_str, pr.eval_f, pr.eval_g, pr.eval_grad_f, pr.eval_jac_g,
+                O.Parameters(algorithm=alg))
+    m.x[:] = pr.x0
+    slp = O.optimize(m)
+    assert m.status == 0
+    assert np.allclose(m.x, [-1.0, -1.0], rtol=1e-4)
+    assert np.allclose(m.mult_g, [0.0, 1.0 / 3.0, 0.0, 0.0], atol=1e-6)
+    assert slp.trace[0]["status"] == L.INFEASIBLE and slp.trace[1]["fr"]     # first LP infeasible -> restoration
+
+
+def test_norm_helpers():
+    E = np.array([3.0, -1.0, 0.5]); gL = np.array([0.0, 0.0, 0.5]); gU = np.array([2.0, INF, 0.5])
+    x = np.array([2.0, -3.0]); xL = np.array([-1.0, -1.0]); xU = np.array([1.0, 1.0])
+    assert O.norm_violations(E, gL, gU, x, xL, xU, 1) == pytest.approx(1 + 1 + 1 + 2)
+    assert O.norm_violations(E, gL, gU, x, xL, xU, INF) == pytest.approx(2.0)
+    lam = np.array([2.0, -1.0, 7.0])
+    c = O.norm_complementarity(E, gL, gU, lam)
+    assert c == pytest.approx(2.0 / (1 + np.sqrt(5.0)))              # max|min(3,-1)*2|, |min(-1,inf)*-1| ; eq row skipped
