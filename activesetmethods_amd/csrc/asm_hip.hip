@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -25,6 +26,7 @@ namespace {
 const double INF = std::numeric_limits<double>::infinity();
 const double TOL_P = 1e-9, TOL_D = 1e-6;
 const int IPM_MAXIT = 60;
+const double IPM_RHO_P = 1e-8;   // primal proximal regularisation of the Newton system
 
 struct HipError : std::runtime_error {
     explicit HipError(const std::string& s) : std::runtime_error(s) {}
@@ -183,10 +185,12 @@ struct Dev {
     // out[n] = A' y
     void gemv_t(const double* A, const double* y, double* out) {
         h2d(h->d_vecM, y, h->M, h->Mp);
-        int64_t R = (h->M + ASM_TCHUNK - 1) / ASM_TCHUNK;
+        int64_t R = std::min<int64_t>((h->M + 31) / 32, ASM_TMAXCHUNKS);
+        int64_t chunk = (h->M + R - 1) / R;
+        R = (h->M + chunk - 1) / chunk;
         int id = begin(ASM_K_GEMV, 2.0 * h->M * h->n, 8.0 * h->M * h->ldn);
         hipLaunchKernelGGL(k_gemv_t_stage1, dim3((unsigned)((h->ldn + 255) / 256), (unsigned)R), dim3(256), 0, h->stream, A,
-                           h->ldn, h->d_vecM, h->d_partial, h->M, h->ldn);
+                           h->ldn, h->d_vecM, h->d_partial, h->M, h->ldn, chunk);
         hipLaunchKernelGGL(k_gemv_t_stage2, dim3((unsigned)((h->ldn + 255) / 256)), dim3(256), 0, h->stream, h->d_partial,
                            h->d_vecN, R, h->ldn);
         end(id);
@@ -229,15 +233,15 @@ struct Dev {
         hipLaunchKernelGGL(k_diag_prepare, dim3(1), dim3(1024), 0, h->stream, h->d_S, h->Mp, Ms, h->d_diag0, mode, rel, absv);
     }
     // in-place blocked right-looking Cholesky of S[0:Ms,0:Ms] (lower)
-    void chol(int Ms) {
+    void chol(int Ms, double thr = 1e-14) {
         int id = begin(ASM_K_CHOL, (double)Ms * Ms * Ms / 3.0, 8.0 * 1.5 * Ms * (double)Ms);
         for (int k0 = 0; k0 < Ms; k0 += ASM_NB) {
             int nb = std::min(ASM_NB, Ms - k0);
-            hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, h->stream, h->d_S, h->Mp, k0, nb, h->d_diag0);
+            hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, h->stream, h->d_S, h->Mp, k0, nb, h->d_diag0, thr);
             int k1 = k0 + nb;
             if (k1 < Ms) {
                 int rem = Ms - k1;
-                hipLaunchKernelGGL(k_trsm_panel, dim3((unsigned)((rem + 63) / 64)), dim3(64), 0, h->stream, h->d_S, h->Mp, k0, nb, Ms);
+                hipLaunchKernelGGL(k_trsm_panel, dim3((unsigned)((rem + 63) / 64)), dim3(256), 0, h->stream, h->d_S, h->Mp, k0, nb, Ms);
                 launch_syrk(pick_tile(rem), h->d_S + k0, h->Mp, nullptr, k1, rem, nb, nullptr, nullptr, h->d_S, h->Mp, k1, 1);
             }
         }
@@ -254,13 +258,13 @@ struct Dev {
             if (k0 > 0)
                 hipLaunchKernelGGL(k_trsv_panel_dot, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, h->stream, h->d_S, h->Mp, k0, nb, z,
                                    h->d_part);
-            hipLaunchKernelGGL(k_trsv_diag_fwd, dim3(1), dim3(64), 0, h->stream, h->d_S, h->Mp, k0, nb, h->d_vecM2, h->d_part, z,
+            hipLaunchKernelGGL(k_trsv_diag_fwd, dim3(1), dim3(256), 0, h->stream, h->d_S, h->Mp, k0, nb, h->d_vecM2, h->d_part, z,
                                k0 > 0 ? 1 : 0);
         }
         int last = ((Ms - 1) / ASM_NB) * ASM_NB;
         for (int k0 = last; k0 >= 0; k0 -= ASM_NB) {
             int nb = std::min(ASM_NB, Ms - k0);
-            hipLaunchKernelGGL(k_trsv_diag_bwd, dim3(1), dim3(64), 0, h->stream, h->d_S, h->Mp, k0, nb, z);
+            hipLaunchKernelGGL(k_trsv_diag_bwd, dim3(1), dim3(256), 0, h->stream, h->d_S, h->Mp, k0, nb, z);
             if (k0 > 0)
                 hipLaunchKernelGGL(k_trsv_panel_axpy, dim3((unsigned)((k0 + 255) / 256)), dim3(256), 0, h->stream, h->d_S, h->Mp, k0, nb,
                                    z);
@@ -282,6 +286,20 @@ struct Dev {
                                h->d_adjoff, h->d_J, h->nu);
         }
         end(id);
+    }
+    // rel[j] = max_i |J_ij| / max_k |J_ik|   (host, n) - matrix-based cap of the column scale
+    void col_relmax(double* rel) {
+        int64_t R = std::min<int64_t>((h->M + 31) / 32, ASM_TMAXCHUNKS);
+        int64_t chunk = (h->M + R - 1) / R;
+        R = (h->M + chunk - 1) / chunk;
+        int id = begin(ASM_K_SCALE, 0.0, 8.0 * 2.0 * h->M * h->ldn);
+        hipLaunchKernelGGL(k_row_absmax, dim3((unsigned)((h->M + 3) / 4)), dim3(256), 0, h->stream, h->d_J, h->ldn, h->d_rho, h->M, h->ldn);
+        hipLaunchKernelGGL(k_col_relmax_stage1, dim3((unsigned)((h->ldn + 255) / 256), (unsigned)R), dim3(256), 0, h->stream, h->d_J,
+                           h->ldn, h->d_rho, h->d_partial, h->M, h->ldn, chunk);
+        hipLaunchKernelGGL(k_col_relmax_stage2, dim3((unsigned)((h->ldn + 255) / 256)), dim3(256), 0, h->stream, h->d_partial, h->d_vecN, R,
+                           h->ldn);
+        end(id);
+        d2h(rel, h->d_vecN, h->n);
     }
     // Ah = diag(1/rho) J diag(c);  rho (host, M)
     void scale(const double* c, double* rho) {
@@ -508,7 +526,7 @@ struct Solver {
             if (done >= max_more) return ip.status = ASM_OTHER;
             vec thp_inv(n), ths_inv(ns), dS(M);
             for (int64_t j = 0; j < n; ++j)
-                thp_inv[j] = ip.free_[j] ? 1.0 / (ip.muL[j] / ip.tL[j] + ip.muU[j] / ip.tU[j]) : 0.0;
+                thp_inv[j] = ip.free_[j] ? 1.0 / (ip.muL[j] / ip.tL[j] + ip.muU[j] / ip.tU[j] + IPM_RHO_P) : 0.0;
             for (int64_t k = 0; k < ns; ++k) ths_inv[k] = ip.ts[k] / ip.mus[k];
             for (int64_t i = 0; i < M; ++i) dS[i] = ip.ineq[i] ? ip.g[i] / ip.pi[i] : 0.0;
             for (int64_t k = 0; k < ns; ++k) dS[lp.srow[k]] += ths_inv[k];
@@ -626,8 +644,8 @@ struct Solver {
                 for (int64_t j = 0; j < n; ++j) cF[j] = as.bst[j] == 0 ? lp.q[j] : 0.0;
             }
             dev.syrk(H.data(), Ms, mask.data(), nullptr);
-            dev.diag_prepare(Ms, 1, 1e-12, 0.0);
-            dev.chol(Ms);
+            dev.diag_prepare(Ms, 1, 0.0, 0.0);
+            dev.chol(Ms, 1e-10);
             vec pF(n), yH(Ms), v(Ms), u(Ms), yfull(M), rd(n);
             for (int64_t j = 0; j < n; ++j) pF[j] = as.bst[j] == 0 ? p_ref[j] : 0.0;
             for (int a = 0; a < Ms; ++a) yH[a] = y_ref[H[a]];
@@ -900,8 +918,7 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     dmalloc(&h->d_c, h->ldn); dmalloc(&h->d_rho, h->Mp); dmalloc(&h->d_theta, h->ldn);
     dmalloc(&h->d_diag, h->Mp); dmalloc(&h->d_diag0, h->Mp);
     dmalloc(&h->d_vecN, h->ldn); dmalloc(&h->d_vecM, h->Mp); dmalloc(&h->d_vecM2, h->Mp); dmalloc(&h->d_part, ASM_NB);
-    int64_t R = (h->M + ASM_TCHUNK - 1) / ASM_TCHUNK;
-    dmalloc(&h->d_partial, std::max<int64_t>(R, 1) * h->ldn);
+    dmalloc(&h->d_partial, (int64_t)ASM_TMAXCHUNKS * h->ldn);
     dmalloc(&h->d_idx, h->Mp);
     h->pin_len = std::max(h->ldn, h->Mp);
     HIPCHK(hipHostMalloc((void**)&h->h_pin, 2 * h->pin_len * sizeof(double)));
@@ -947,14 +964,16 @@ void do_solve(asm_handle* h, double delta, int feasibility, double* p_out, doubl
     h->stats.M = (int)M; h->stats.n = (int)n; h->stats.ns = (int)lp.ns;
 
     // trust region intersected with the variable bounds (subproblem.jl:427-434)
-    vec lb(n), ub(n), c(n);
+    vec lb(n), ub(n), c(n), rel(n);
+    // Jacobian -> dense rows incl. range rows; scaled copy (column scale = min(box, matrix cap), oracle: scale_lp)
+    sv.dev.assemble();
+    sv.dev.col_relmax(rel.data());
     for (int64_t j = 0; j < n; ++j) {
         ub[j] = std::min(delta, h->v_ub[j] - h->x_k[j]);
         lb[j] = std::max(-delta, h->v_lb[j] - h->x_k[j]);
-        c[j] = pow2_round(std::max(ub[j], -lb[j]));
+        double c_mat = rel[j] > 0.0 ? 1.0 / rel[j] : 1.0;
+        c[j] = pow2_round(std::min(std::max(ub[j], -lb[j]), c_mat));
     }
-    // Jacobian -> dense rows incl. range rows; scaled copy
-    sv.dev.assemble();
     vec rho(M);
     sv.dev.scale(c.data(), rho.data());
 
@@ -1089,6 +1108,8 @@ int asm_create(int device, asm_handle** out) {
     }
     std::memset(&h->kstats, 0, sizeof(h->kstats));
     std::memset(&h->stats, 0, sizeof(h->stats));
+    const char* tm = std::getenv("ASM_HIP_TIMING");
+    h->timing = !(tm && tm[0] == '0');
     *out = h;
     return ASM_OK;
 }

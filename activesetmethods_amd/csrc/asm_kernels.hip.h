@@ -117,12 +117,12 @@ __global__ __launch_bounds__(256) void k_gemv_n(const double* __restrict__ A, in
 }
 
 // partial[r][j] = sum_{i in row chunk r} A[i,j] y[i]   ; second stage sums the chunks in order (deterministic).
-#define ASM_TCHUNK 128
+#define ASM_TMAXCHUNKS 128
 __global__ __launch_bounds__(256) void k_gemv_t_stage1(const double* __restrict__ A, int64_t ld, const double* __restrict__ y,
-                                                       double* __restrict__ partial, int64_t M, int64_t ncols) {
+                                                       double* __restrict__ partial, int64_t M, int64_t ncols, int64_t chunk) {
     int64_t j = blockIdx.x * 256 + threadIdx.x;
     int64_t r = blockIdx.y;
-    int64_t i0 = r * ASM_TCHUNK, i1 = i0 + ASM_TCHUNK;
+    int64_t i0 = r * chunk, i1 = i0 + chunk;
     if (i1 > M) i1 = M;
     if (j >= ncols) return;
     double acc = 0.0;
@@ -268,69 +268,60 @@ __global__ __launch_bounds__(1024) void k_diag_prepare(double* __restrict__ S, i
 // Cholesky of one NB x NB diagonal block, staged in LDS.  Pivot guard: d <= 1e-14*diag0 -> d := 1e256.
 #define ASM_DP (ASM_NB + 1)
 __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int64_t ldS, int k0, int nb,
-                                                    const double* __restrict__ diag0) {
+                                                    const double* __restrict__ diag0, double thr) {
     __shared__ double D[ASM_NB * ASM_DP];
-    __shared__ double s_piv;
-    const int tid = threadIdx.x;
-    for (int e = tid; e < nb * nb; e += 256) {
-        int r = e / nb, c = e - r * nb;
-        D[r * ASM_DP + c] = (c <= r) ? S[(int64_t)(k0 + r) * ldS + k0 + c] : 0.0;
+    __shared__ double d0[ASM_NB];
+    const int tid = threadIdx.x, r = tid & 63, g = tid >> 6;
+    for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
+        int rr = e >> 6, c = e & 63;
+        D[rr * ASM_DP + c] = (rr < nb && c <= rr) ? S[(int64_t)(k0 + rr) * ldS + k0 + c] : (rr == c ? 1.0 : 0.0);
     }
+    if (tid < ASM_NB) d0[tid] = tid < nb ? diag0[k0 + tid] : 1.0;
     __syncthreads();
     for (int j = 0; j < nb; ++j) {
-        if (tid == 0) {
-            double d = D[j * ASM_DP + j];
-            if (!(d > 1e-14 * diag0[k0 + j])) d = 1e256;
-            s_piv = sqrt(d);
-            D[j * ASM_DP + j] = s_piv;
-        }
+        // every thread derives the same pivot (static guard), then updates its share of the trailing triangle
+        double d = D[j * ASM_DP + j];
+        if (!(d > thr * d0[j])) d = 1e256;
+        double ljj = sqrt(d);
+        double inv = 1.0 / ljj;
+        double lr = D[r * ASM_DP + j] * inv;
+        for (int c = j + 1 + g; c <= r; c += 4) D[r * ASM_DP + c] -= lr * (D[c * ASM_DP + j] * inv);
         __syncthreads();
-        double ljj = s_piv;
-        if (tid > j && tid < nb) D[tid * ASM_DP + j] = D[tid * ASM_DP + j] / ljj;
-        __syncthreads();
-        // trailing update of the lower triangle: rows r > j, cols j < c <= r
-        int rem = nb - j - 1;
-        for (int e = tid; e < rem * rem; e += 256) {
-            int rr = e / rem, cc = e - rr * rem;
-            if (cc <= rr) {
-                int r = j + 1 + rr, c = j + 1 + cc;
-                D[r * ASM_DP + c] -= D[r * ASM_DP + j] * D[c * ASM_DP + j];
-            }
-        }
+        if (g == 0 && r >= j) D[r * ASM_DP + j] = (r == j) ? ljj : lr;
         __syncthreads();
     }
-    for (int e = tid; e < nb * nb; e += 256) {
-        int r = e / nb, c = e - r * nb;
-        if (c <= r) S[(int64_t)(k0 + r) * ldS + k0 + c] = D[r * ASM_DP + c];
+    for (int e = tid; e < nb * ASM_NB; e += 256) {
+        int rr = e >> 6, c = e & 63;
+        if (c <= rr && c < nb) S[(int64_t)(k0 + rr) * ldS + k0 + c] = D[rr * ASM_DP + c];
     }
 }
 
-// Panel solve: for every row i >= k1,  S[i, k0:k1] <- S[i, k0:k1] * L11^-T   (one thread per row, L11 broadcast from LDS)
-__global__ __launch_bounds__(64) void k_trsm_panel(double* __restrict__ S, int64_t ldS, int k0, int nb, int Ms) {
+// Panel solve: S[i, k0:k1] <- S[i, k0:k1] * L11^-T for the 64 rows of this workgroup's tile; the tile and L11 are
+// staged in LDS (coalesced 512-B row segments), right-looking substitution with the columns split over 4 wavefronts.
+__global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ S, int64_t ldS, int k0, int nb, int Ms) {
     __shared__ double Lk[ASM_NB * ASM_DP];
-    for (int e = threadIdx.x; e < nb * nb; e += 64) {
-        int r = e / nb, c = e - r * nb;
-        Lk[r * ASM_DP + c] = (c <= r) ? S[(int64_t)(k0 + r) * ldS + k0 + c] : 0.0;
+    __shared__ double X[ASM_NB * ASM_DP];
+    const int tid = threadIdx.x, r = tid & 63, g = tid >> 6;
+    const int i0 = k0 + nb + blockIdx.x * ASM_NB;
+    for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
+        int rr = e >> 6, c = e & 63;
+        Lk[rr * ASM_DP + c] = (rr < nb && c <= rr) ? S[(int64_t)(k0 + rr) * ldS + k0 + c] : (rr == c ? 1.0 : 0.0);
+        int gi = i0 + rr;
+        X[rr * ASM_DP + c] = (gi < Ms && c < nb) ? S[(int64_t)gi * ldS + k0 + c] : 0.0;
     }
     __syncthreads();
-    int i = k0 + nb + blockIdx.x * 64 + threadIdx.x;
-    if (i >= Ms) return;
-    double* row = S + (int64_t)i * ldS + k0;
-    double x[ASM_NB];
-#pragma unroll
-    for (int c = 0; c < ASM_NB; ++c) x[c] = (c < nb) ? row[c] : 0.0;
-#pragma unroll
-    for (int c = 0; c < ASM_NB; ++c) {
-        if (c < nb) {
-            double v = x[c];
-#pragma unroll
-            for (int q = 0; q < c; ++q) v -= x[q] * Lk[c * ASM_DP + q];
-            x[c] = v / Lk[c * ASM_DP + c];
-        }
+    for (int c = 0; c < nb; ++c) {
+        double xc = X[r * ASM_DP + c] / Lk[c * ASM_DP + c];
+        for (int c2 = c + 1 + g; c2 < nb; c2 += 4) X[r * ASM_DP + c2] -= xc * Lk[c2 * ASM_DP + c];
+        __syncthreads();
+        if (g == 0) X[r * ASM_DP + c] = xc;
+        __syncthreads();
     }
-#pragma unroll
-    for (int c = 0; c < ASM_NB; ++c)
-        if (c < nb) row[c] = x[c];
+    for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
+        int rr = e >> 6, c = e & 63;
+        int gi = i0 + rr;
+        if (gi < Ms && c < nb) S[(int64_t)gi * ldS + k0 + c] = X[rr * ASM_DP + c];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -351,32 +342,47 @@ __global__ __launch_bounds__(256) void k_trsv_panel_dot(const double* __restrict
     if (lane == 0) part[r] = acc;
 }
 
-__global__ __launch_bounds__(64) void k_trsv_diag_fwd(const double* __restrict__ L, int64_t ld, int k0, int nb,
-                                                      const double* __restrict__ b, const double* __restrict__ part,
-                                                      double* __restrict__ z, int use_part) {
-    // one wavefront; lane r owns unknown r.  Column-oriented substitution with a wave broadcast per step.
-    int r = threadIdx.x;
+__global__ __launch_bounds__(256) void k_trsv_diag_fwd(const double* __restrict__ L, int64_t ld, int k0, int nb,
+                                                       const double* __restrict__ b, const double* __restrict__ part,
+                                                       double* __restrict__ z, int use_part) {
+    // L11 staged in LDS by the whole workgroup; wavefront 0 then runs the column-oriented substitution
+    // (lane r owns unknown r, one wave broadcast per step).
+    __shared__ double D[ASM_NB * ASM_DP];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
+        int rr = e >> 6, c = e & 63;
+        D[rr * ASM_DP + c] = (rr < nb && c <= rr) ? L[(int64_t)(k0 + rr) * ld + k0 + c] : (rr == c ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    int r = tid;
     double v = 0.0;
     if (r < nb) v = b[k0 + r] - (use_part ? part[r] : 0.0);
     for (int c = 0; c < nb; ++c) {
-        double lcc = L[(int64_t)(k0 + c) * ld + k0 + c];
-        double xc = __shfl(v, c, 64) / lcc;
+        double xc = __shfl(v, c, 64) / D[c * ASM_DP + c];
         if (r == c) v = xc;
-        else if (r > c && r < nb) v -= L[(int64_t)(k0 + r) * ld + k0 + c] * xc;
+        else if (r > c) v -= D[r * ASM_DP + c] * xc;
     }
     if (r < nb) z[k0 + r] = v;
 }
 
-__global__ __launch_bounds__(64) void k_trsv_diag_bwd(const double* __restrict__ L, int64_t ld, int k0, int nb,
-                                                      double* __restrict__ z) {
-    // x = L11^-T z  in place; lane r owns unknown r; step c from nb-1 down: x_c = v_c / L_cc ; v_r -= L[c][r] x_c (r < c)
-    int r = threadIdx.x;
+__global__ __launch_bounds__(256) void k_trsv_diag_bwd(const double* __restrict__ L, int64_t ld, int k0, int nb,
+                                                       double* __restrict__ z) {
+    // x = L11^-T z in place; step c from nb-1 down: x_c = v_c / L_cc ; v_r -= L[c][r] x_c (r < c)
+    __shared__ double D[ASM_NB * ASM_DP];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
+        int rr = e >> 6, c = e & 63;
+        D[rr * ASM_DP + c] = (rr < nb && c <= rr) ? L[(int64_t)(k0 + rr) * ld + k0 + c] : (rr == c ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    int r = tid;
     double v = (r < nb) ? z[k0 + r] : 0.0;
     for (int c = nb - 1; c >= 0; --c) {
-        double lcc = L[(int64_t)(k0 + c) * ld + k0 + c];
-        double xc = __shfl(v, c, 64) / lcc;
+        double xc = __shfl(v, c, 64) / D[c * ASM_DP + c];
         if (r == c) v = xc;
-        else if (r < c) v -= L[(int64_t)(k0 + c) * ld + k0 + r] * xc;
+        else if (r < c) v -= D[c * ASM_DP + r] * xc;
     }
     if (r < nb) z[k0 + r] = v;
 }
@@ -401,4 +407,37 @@ __global__ __launch_bounds__(256) void k_row_norms(const double* __restrict__ A,
     for (int64_t j = lane; j < ncols; j += 64) acc = fma(row[j], row[j], acc);
     acc = wave_sum(acc);
     if (lane == 0) out[i] = sqrt(acc);
+}
+
+// Scaling helpers (oracle/lp_solver.py: scale_lp): rmax[i] = max_j |J_ij| (1 if the row is empty), then
+// rel[j] = max_i |J_ij| / rmax[i] with the same deterministic two-stage column reduction as k_gemv_t.
+__global__ __launch_bounds__(256) void k_row_absmax(const double* __restrict__ A, int64_t ld, double* __restrict__ out, int64_t M,
+                                                    int64_t ncols) {
+    int64_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= M) return;
+    int lane = threadIdx.x & 63;
+    const double* row = A + i * ld;
+    double mx = 0.0;
+    for (int64_t j = lane; j < ncols; j += 64) mx = fmax(mx, fabs(row[j]));
+    mx = wave_max(mx);
+    if (lane == 0) out[i] = mx > 0.0 ? mx : 1.0;
+}
+__global__ __launch_bounds__(256) void k_col_relmax_stage1(const double* __restrict__ A, int64_t ld, const double* __restrict__ rmax,
+                                                           double* __restrict__ partial, int64_t M, int64_t ncols, int64_t chunk) {
+    int64_t j = blockIdx.x * 256 + threadIdx.x;
+    int64_t r = blockIdx.y;
+    int64_t i0 = r * chunk, i1 = i0 + chunk;
+    if (i1 > M) i1 = M;
+    if (j >= ncols) return;
+    double mx = 0.0;
+    for (int64_t i = i0; i < i1; ++i) mx = fmax(mx, fabs(A[i * ld + j]) / rmax[i]);
+    partial[r * ncols + j] = mx;
+}
+__global__ __launch_bounds__(256) void k_col_relmax_stage2(const double* __restrict__ partial, double* __restrict__ out, int64_t R,
+                                                           int64_t ncols) {
+    int64_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= ncols) return;
+    double mx = 0.0;
+    for (int64_t r = 0; r < R; ++r) mx = fmax(mx, partial[r * ncols + j]);
+    out[j] = mx;
 }

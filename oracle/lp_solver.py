@@ -34,6 +34,7 @@ TOL_D = 1e-6      # dual feasibility of the accepted vertex (scaled units)
 IPM_TOL = 1e-8
 IPM_MAXIT = 60
 IPM_REFINE = 0
+IPM_RHO_P = 1e-8     # primal proximal regularisation of the Newton system (bounds Theta^-1 for effectively free variables)
 CHOL_NB = 64
 PIV_BIG = 1e128
 
@@ -69,7 +70,15 @@ def pow2_round(x):
 
 
 def scale_lp(lp):
-    c = pow2_round(np.maximum(lp.ub, -lp.lb))
+    """Column scale = min(box half-width, matrix-based cap): the box scale makes the LP live at the
+    scale of the trust region; the cap c_mat_j = 1 / max_i(|a_ij| / max_k |a_ik|) (>= 1) keeps effectively
+    free variables (box = the Line-Search radius 1000, subproblem.jl:427-434 with slp.jl:23) from being
+    inflated.  Row scale = max |entry| of the column-scaled row.  All factors are powers of two."""
+    rmax0 = np.abs(lp.A).max(axis=1) if lp.n > 0 else np.ones(lp.M)
+    rmax0 = np.where(rmax0 > 0, rmax0, 1.0)
+    rel = (np.abs(lp.A) / rmax0[:, None]).max(axis=0) if lp.M > 0 else np.zeros(lp.n)
+    c_mat = np.where(rel > 0, 1.0 / np.where(rel > 0, rel, 1.0), 1.0)
+    c = pow2_round(np.minimum(np.maximum(lp.ub, -lp.lb), c_mat))
     Ah = lp.A * c
     rho = pow2_round(np.abs(Ah).max(axis=1)) if lp.n > 0 else np.ones(lp.M)
     Ah = Ah / rho[:, None]
@@ -82,9 +91,12 @@ def scale_lp(lp):
 
 
 # ----------------------------------------------------------------------------- Cholesky
-def chol_guard(S, diag0):
-    """Lower Cholesky factor of SPD S (blocked, right-looking).  A pivot <= 1e-14*diag0[j] is replaced
-    by PIV_BIG**2 (row j is then effectively dropped from the solve) - static, order-independent rule."""
+def chol_guard(S, diag0, thr=1e-14):
+    """Lower Cholesky factor of SPD S (blocked, right-looking).  A pivot <= thr*diag0[j] is replaced
+    by PIV_BIG**2 (row j is then effectively dropped from the solve: its unknown comes out as 0) -
+    a static rule in elimination (index) order.  thr = 1e-14 inside the IPM (S is regularised there);
+    thr = 1e-10 for the active-set solve, where a linearly dependent active row must be dropped cleanly
+    so that the multipliers form a basic (not a noise-amplified least-norm) solution."""
     S = S.copy()
     N = S.shape[0]
     for k0 in range(0, N, CHOL_NB):
@@ -92,7 +104,7 @@ def chol_guard(S, diag0):
         D = S[k0:k1, k0:k1]
         for j in range(k1 - k0):
             d = D[j, j] - D[j, :j] @ D[j, :j]
-            if not (d > 1e-14 * diag0[k0 + j]):
+            if not (d > thr * diag0[k0 + j]):
                 d = PIV_BIG * PIV_BIG
             ljj = np.sqrt(d)
             D[j, j] = ljj
@@ -201,7 +213,7 @@ class IPM:
                 return self.status
             tL, tU, ts, g, pi, muL, muU, mus = self.tL, self.tU, self.ts, self.g, self.pi, self.muL, self.muU, self.mus
             rp, rdp, rds, mu = self.rp, self.rdp, self.rds, self.mu
-            thp_inv = np.where(free, 1.0 / np.where(free, muL / tL + muU / tU, 1.0), 0.0)
+            thp_inv = np.where(free, 1.0 / np.where(free, muL / tL + muU / tU + IPM_RHO_P, 1.0), 0.0)
             ths_inv = ts / mus
             dS = np.where(ineq, g / np.where(ineq, pi, 1.0), 0.0)
             if ns:
@@ -290,7 +302,7 @@ def eqp(lp, sets, p_ref, y_ref, refine=4):
     """Equality-constrained solve on the active set (rowst, bst, sst):
        rows H (active, no basic slack) hold with equality, bound-active variables sit on their bound,
        rows with a basic slack carry the known multiplier w_k*scoef_k.
-       primal:  p_F = p_ref + A_HF' S^-1 (b_H - A_HF p_ref)     S = A_HF A_HF' + delta I
+       primal:  p_F = p_ref + A_HF' S^-1 (b_H - A_HF p_ref)     S = A_HF A_HF'  (dependent rows dropped by the pivot guard)
        dual:    y_H = y_ref + S^-1 A_HF (c_F - A_HF' y_ref)
     with `refine` proximal-refinement sweeps (same factor)."""
     rowst, bst, sst = sets
@@ -320,8 +332,7 @@ def eqp(lp, sets, p_ref, y_ref, refine=4):
         S = AHF @ AHF.T
         idx = np.arange(len(H))
         diag0 = S[idx, idx].copy()
-        S[idx, idx] += 1e-12 * max(diag0.max(initial=0.0), 1e-300)
-        L = chol_guard(S, diag0)
+        L = chol_guard(S, diag0, 1e-10)
         nfact = 1
         pF = p_ref[F].copy()
         yH = y_ref[H].copy()

@@ -136,3 +136,27 @@ def test_norm_helpers():
     lam = np.array([2.0, -1.0, 7.0])
     c = O.norm_complementarity(E, gL, gU, lam)
     assert c == pytest.approx(2.0 / (1 + np.sqrt(5.0)))              # max|min(3,-1)*2|, |min(-1,inf)*-1| ; eq row skipped
+
+
+@pytest.mark.parametrize("alg", ["Line Search", "Trust Region"])
+def test_acopf_case3_known_objective(alg):
+    """test/runtests.jl:18-19 (via test/opf.jl): ACOPF on examples/acopf/case3.m, max_iter 100 ->
+    objective 5906.87949 (rtol 1e-3).  Data: tests/golden/case3.json; formulation: activesetmethods_amd/acopf.py."""
+    from activesetmethods_amd import acopf
+    d = json.load(open(os.path.join(GOLD, "case3.json")))
+    pr = acopf.acopf_problem(acopf.case_from_tables(d["baseMVA"], d["bus"], d["gen"], d["gencost"], d["branch"], d["dcline"]), "case3")
+    assert (pr.n, pr.m) == (28, 32)
+    # analytic Jacobian vs central differences
+    x = pr.x0 + 0.05 * np.random.default_rng(0).standard_normal(pr.n)
+    J = np.zeros((pr.m, pr.n))
+    np.add.at(J, (pr.j_row - 1, pr.j_col - 1), pr.eval_jac_g(x, np.zeros(pr.nnz)))
+    for j in range(pr.n):
+        e = np.zeros(pr.n); e[j] = 1e-6
+        fd = (pr.eval_g(x + e, np.zeros(pr.m)) - pr.eval_g(x - e, np.zeros(pr.m))) / 2e-6
+        assert np.abs(fd - J[:, j]).max() < 1e-7
+    m = O.Model(pr.n, pr.m, pr.x_L, pr.x_U, pr.g_L, pr.g_U, pr.j_str, pr.eval_f, pr.eval_g, pr.eval_grad_f, pr.eval_jac_g,
+                O.Parameters(algorithm=alg, max_iter=100))
+    m.x[:] = pr.x0
+    O.optimize(m)
+    assert m.status == 0
+    assert abs(m.obj_val - d["expected_objective"]) <= 1e-3 * d["expected_objective"]

@@ -76,3 +76,41 @@ def test_reductions_on_resident_jacobian():
     assert abs(opt.kt_residuals(df, lam, mu, ml) - O.KT_residuals(df, lam, mu, ml, J)) < 1e-12
     assert rel_err(opt.jac_row_norms(), np.linalg.norm(J, axis=1)) < 1e-13
     opt.close()
+
+
+def _case3():
+    import json, os
+    from activesetmethods_amd import acopf
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "case3.json")))
+    return acopf.acopf_problem(acopf.case_from_tables(d["baseMVA"], d["bus"], d["gen"], d["gencost"], d["branch"], d["dcline"]), "case3"), d
+
+
+@pytest.mark.parametrize("alg", ["Line Search", "Trust Region"])
+def test_acopf_case3_known_objective(alg):
+    """test/runtests.jl:18-19: ACOPF case3 objective 5906.87949 (rtol 1e-3), max_iter 100."""
+    pr, d = _case3()
+    mh, sh = _hip_run(pr, algorithm=alg, max_iter=100)
+    assert mh.status == 0
+    assert abs(mh.obj_val - d["expected_objective"]) <= 1e-3 * d["expected_objective"]
+    mo, so = _oracle_run(pr, algorithm=alg, max_iter=100)
+    assert so.lp_solves == sh.lp_solves
+    _compare_traces(so, sh)
+    assert abs(mh.obj_val - mo.obj_val) < 1e-6
+
+
+def test_acopf_case118_sized_lp_parity():
+    """One normal-phase sub-LP of the case118-sized synthetic grid (sparse pattern, unbounded angle
+    variables, 1725 rows, Line-Search radius 1000)."""
+    from activesetmethods_amd import acopf
+    from tests.util import oracle_solve, hip_solve
+    pr = acopf.acopf_problem(acopf.synthetic_case("case118", 1), "case118")
+    x = pr.x0.copy()
+    sp = dict(n=pr.n, m=pr.m, j_row=pr.j_row, j_col=pr.j_col, dE=pr.eval_jac_g(x, np.zeros(pr.nnz)), df=pr.eval_grad_f(x, np.zeros(pr.n)),
+              f=pr.eval_f(x), E=pr.eval_g(x, np.zeros(pr.m)), x_k=x, c_lb=pr.g_L, c_ub=pr.g_U, v_lb=pr.x_L, v_ub=pr.x_U, delta=1000.0)
+    qp, o_out = oracle_solve(sp)
+    opt, h_out = hip_solve(sp)
+    assert o_out[5] == h_out[5] == 1
+    rows, bnd, sl = opt.active_set()
+    assert np.array_equal(rows, o_out[6]['sets'][0]) and np.array_equal(bnd, o_out[6]['sets'][1])
+    assert rel_err(h_out[0], o_out[0]) < 1e-9 and rel_err(h_out[1], o_out[1]) < 1e-9
+    opt.close()
