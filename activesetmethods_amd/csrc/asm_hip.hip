@@ -108,6 +108,7 @@ struct asm_handle {
     std::vector<TimedRegion> regions;
     std::vector<hipEvent_t> event_pool;
     bool timing = true;
+    bool verbose = false;
 };
 
 namespace {
@@ -349,6 +350,8 @@ struct Solver {
         std::vector<char> ineq, free_;
         vec sg;
         int64_t ncomp = 1;
+        vec pinf_hist;
+        bool stalled = false;
         int iters = 0;
         int status = ASM_OTHER;
         double mu = 0, pinf = 0, dinf = 0, gap = 0;
@@ -468,7 +471,7 @@ struct Solver {
     };
 
     // one Newton solve with the current factor (oracle: IPM.run.solve)
-    void ipm_solve(const vec& thp_inv, const vec& ths_inv, const vec& rcL, const vec& rcU, const vec& rcs, const vec& rcg, Dir& d) {
+    void ipm_solve(const vec& thp_inv, const vec& ths_inv, const vec& dS, const vec& rcL, const vec& rcU, const vec& rcs, const vec& rcg, Dir& d) {
         const int64_t n = lp.n, M = lp.M, ns = lp.ns;
         vec hp(n), hs(ns), tmp(n), rhs(M), t2;
         for (int64_t j = 0; j < n; ++j) {
@@ -486,6 +489,24 @@ struct Solver {
         }
         d.dy.resize(M);
         dev.chol_solve(rhs.data(), d.dy.data(), (int)M);
+        {   // adaptive iterative refinement on the unregularised Schur system (oracle: IPM.run.solve)
+            double rmax = 1.0;
+            for (double v : rhs) rmax = std::max(rmax, std::fabs(v));
+            vec res(M), sres(M), corr(M);
+            for (int it = 0; it < 2; ++it) {
+                atv(d.dy, t2);
+                for (int64_t j = 0; j < n; ++j) t2[j] *= thp_inv[j];
+                dev.gemv_n(h->d_Ah, t2.data(), sres.data());
+                double emax = 0.0;
+                for (int64_t i = 0; i < M; ++i) {
+                    res[i] = rhs[i] - (sres[i] + dS[i] * d.dy[i]);
+                    emax = std::max(emax, std::fabs(res[i]));
+                }
+                if (emax <= 1e-10 * rmax) break;
+                dev.chol_solve(res.data(), corr.data(), (int)M);
+                for (int64_t i = 0; i < M; ++i) d.dy[i] += corr[i];
+            }
+        }
         atv(d.dy, t2);
         d.dp.resize(n); d.dmuL.resize(n); d.dmuU.resize(n);
         for (int64_t j = 0; j < n; ++j) {
@@ -517,6 +538,7 @@ struct Solver {
         int done = 0;
         while (true) {
             ipm_measures();
+            if (h->verbose) std::fprintf(stderr, "[asm] ipm %3d pinf %.3e dinf %.3e gap %.3e\n", ip.iters, ip.pinf, ip.dinf, ip.gap);
             if (ip.pinf <= tol && ip.dinf <= tol && ip.gap <= tol) return ip.status = ASM_OPTIMAL;
             double ymax = 0.0;
             for (double v : ip.y) ymax = std::max(ymax, std::fabs(v));
@@ -524,6 +546,12 @@ struct Solver {
                 if (farkas_margin(ip.y) > 1e-9) return ip.status = ASM_INFEASIBLE;
             }
             if (done >= max_more) return ip.status = ASM_OTHER;
+            // jammed: complementarity collapsed but the primal residual no longer decreases (oracle: IPM.run)
+            ip.pinf_hist.push_back(ip.pinf);
+            if (ip.iters >= 10 && ip.gap <= 1e-2 * ip.pinf && ip.pinf > 0.5 * ip.pinf_hist[ip.pinf_hist.size() - 4]) {
+                ip.stalled = true;
+                return ip.status = ASM_OTHER;
+            }
             vec thp_inv(n), ths_inv(ns), dS(M);
             for (int64_t j = 0; j < n; ++j)
                 thp_inv[j] = ip.free_[j] ? 1.0 / (ip.muL[j] / ip.tL[j] + ip.muU[j] / ip.tU[j] + IPM_RHO_P) : 0.0;
@@ -535,13 +563,28 @@ struct Solver {
             dev.chol((int)M);
             ip.iters += 1;
             done += 1;
+            if (h->verbose) {
+                HIPCHK(hipStreamSynchronize(h->stream));
+                int ndrop = 0, first[4] = {-1, -1, -1, -1};
+                double dmin = 1e300, dmax = 0;
+                for (int64_t i = 0; i < M; ++i) {
+                    double lii;
+                    HIPCHK(hipMemcpy(&lii, h->d_S + i * h->Mp + i, sizeof(double), hipMemcpyDeviceToHost));
+                    if (lii > 1e100) { if (ndrop < 4) first[ndrop] = (int)i; ++ndrop; }
+                    else { dmin = std::min(dmin, lii); dmax = std::max(dmax, lii); }
+                }
+                int worst = 0;
+                for (int64_t i = 0; i < M; ++i) if (std::fabs(ip.rp[i]) / (1 + std::fabs(lp.r[i])) > std::fabs(ip.rp[worst]) / (1 + std::fabs(lp.r[worst]))) worst = (int)i;
+                std::fprintf(stderr, "[asm]     chol: dropped %d rows (first %d %d %d %d), Lii range %.3e .. %.3e ; worst rp row %d (type %d, r %.3e, rp %.3e, dS %.3e)\n",
+                             ndrop, first[0], first[1], first[2], first[3], dmin, dmax, worst, lp.rtype[worst], lp.r[worst], ip.rp[worst], dS[worst]);
+            }
 
             vec rcL(n), rcU(n), rcs(ns), rcg(M);
             for (int64_t j = 0; j < n; ++j) { rcL[j] = -ip.tL[j] * ip.muL[j]; rcU[j] = -ip.tU[j] * ip.muU[j]; }
             for (int64_t k = 0; k < ns; ++k) rcs[k] = -ip.ts[k] * ip.mus[k];
             for (int64_t i = 0; i < M; ++i) rcg[i] = -ip.g[i] * ip.pi[i];
             Dir a;
-            ipm_solve(thp_inv, ths_inv, rcL, rcU, rcs, rcg, a);
+            ipm_solve(thp_inv, ths_inv, dS, rcL, rcU, rcs, rcg, a);
             double ap, ad;
             steps(a, ap, ad);
             double mu_aff = 0.0;
@@ -562,7 +605,7 @@ struct Solver {
             for (int64_t k = 0; k < ns; ++k) rcs[k] = sm - ip.ts[k] * ip.mus[k] - a.ds[k] * a.dmus[k];
             for (int64_t i = 0; i < M; ++i) rcg[i] = sm - ip.g[i] * ip.pi[i] - a.dg[i] * a.dpi[i];
             Dir c;
-            ipm_solve(thp_inv, ths_inv, rcL, rcU, rcs, rcg, c);
+            ipm_solve(thp_inv, ths_inv, dS, rcL, rcU, rcs, rcg, c);
             double eta = ip.mu >= 1.0 ? 0.995 : std::min(std::max(0.995, 1.0 - ip.mu / lp.scale_q), 0.999999);
             steps(c, ap, ad);
             double al = std::min(1.0, eta * std::min(ap, ad));
@@ -771,6 +814,26 @@ struct Solver {
         return false;
     }
 
+    // oracle: phase1_infeasible - elastic LP over the same rows/box; its optimal multipliers are a Farkas
+    // certificate of the original LP, verified rigorously before INFEASIBLE is reported.
+    bool phase1_infeasible() {
+        SLP saved = lp;
+        IpmState saved_ip = ip;
+        lp.ns = h->ns;
+        std::fill(lp.q.begin(), lp.q.end(), 0.0);
+        lp.w.assign(lp.ns, 1.0);
+        lp.slo.assign(lp.ns, 0.0);
+        lp.scale_q = 1.0;
+        ipm_init();
+        ipm_run(1e-8, IPM_MAXIT);
+        vec y1 = ip.y;
+        int its = ip.iters;
+        lp = saved;
+        ip = saved_ip;
+        h->stats.ipm_iters += its;
+        return farkas_margin(y1) > 1e-9;
+    }
+
     // oracle: solve_scaled
     int solve_scaled(const ActiveSet* warm, EqpOut& o, ActiveSet& out_as) {
         const int64_t n = lp.n, M = lp.M, ns = lp.ns;
@@ -791,7 +854,17 @@ struct Solver {
             h->stats.ipm_iters = ip.iters;
             h->stats.ipm_pinf = ip.pinf; h->stats.ipm_dinf = ip.dinf; h->stats.ipm_gap = ip.gap;
             if (st == ASM_INFEASIBLE) { h->stats.path = 6; return ASM_INFEASIBLE; }
-            if (st == ASM_OTHER && stage == 0) break;
+            if (st == ASM_OTHER && stage == 0) {
+                // the IPM is only the identifier: a jammed / slow run that is already close is still handed to
+                // the active-set solve, whose LP optimality test decides (oracle: solve_scaled)
+                if (ip.pinf <= 1e-3 && ip.dinf <= 1e-3 && ip.gap <= 1e-4) {
+                    identify(sets0);
+                    have_sets = true;
+                    if (eqp_loop(sets0, zero_p, zero_y, 3, o, out_as)) { h->stats.path = 8; return ASM_OPTIMAL; }
+                }
+                if (lp.ns == 0 && phase1_infeasible()) { h->stats.path = 7; return ASM_INFEASIBLE; }
+                break;
+            }
             identify(sets0);
             have_sets = true;
             if (eqp_loop(sets0, zero_p, zero_y, 2, o, out_as)) { h->stats.path = 1 + stage; return ASM_OPTIMAL; }
@@ -1110,6 +1183,8 @@ int asm_create(int device, asm_handle** out) {
     std::memset(&h->stats, 0, sizeof(h->stats));
     const char* tm = std::getenv("ASM_HIP_TIMING");
     h->timing = !(tm && tm[0] == '0');
+    const char* vb = std::getenv("ASM_HIP_VERBOSE");
+    h->verbose = vb && vb[0] == '1';
     *out = h;
     return ASM_OK;
 }

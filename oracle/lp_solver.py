@@ -33,7 +33,7 @@ TOL_P = 1e-9      # primal feasibility of the accepted vertex (scaled units)
 TOL_D = 1e-6      # dual feasibility of the accepted vertex (scaled units)
 IPM_TOL = 1e-8
 IPM_MAXIT = 60
-IPM_REFINE = 0
+IPM_REFINE = 2
 IPM_RHO_P = 1e-8     # primal proximal regularisation of the Newton system (bounds Theta^-1 for effectively free variables)
 CHOL_NB = 64
 PIV_BIG = 1e128
@@ -178,6 +178,8 @@ class IPM:
         self.iters = 0            # factorizations performed
         self.status = OTHER
         self.log = []
+        self.pinf_hist = []
+        self.stalled = False
 
     def measures(self):
         lp, ineq, sg, free = self.lp, self.ineq, self.sg, self.free
@@ -211,6 +213,13 @@ class IPM:
             if done >= max_more:
                 self.status = OTHER
                 return self.status
+            # jammed: complementarity has collapsed but the primal residual no longer decreases (the
+            # signature of a slightly infeasible LP) -> give up, the caller runs the elastic phase-1 LP
+            self.pinf_hist.append(pinf)
+            if self.iters >= 10 and gap <= 1e-2 * pinf and pinf > 0.5 * self.pinf_hist[-4]:
+                self.status = OTHER
+                self.stalled = True
+                return self.status
             tL, tU, ts, g, pi, muL, muU, mus = self.tL, self.tU, self.ts, self.g, self.pi, self.muL, self.muU, self.mus
             rp, rdp, rds, mu = self.rp, self.rdp, self.rds, self.mu
             thp_inv = np.where(free, 1.0 / np.where(free, muL / tL + muU / tU + IPM_RHO_P, 1.0), 0.0)
@@ -236,8 +245,11 @@ class IPM:
                     np.add.at(tmp, lp.srow, lp.scoef * ths_inv * hs)
                     rhs -= tmp
                 dy = chol_solve(L, rhs)
-                for _ in range(IPM_REFINE):              # iterative refinement on S dy = rhs
-                    dy = dy + chol_solve(L, rhs - S @ dy)
+                for _ in range(IPM_REFINE):              # adaptive iterative refinement on the unregularised S
+                    res = rhs - (A @ (thp_inv * (A.T @ dy)) + dS * dy)
+                    if np.abs(res).max(initial=0.0) <= 1e-10 * max(1.0, np.abs(rhs).max(initial=0.0)):
+                        break
+                    dy = dy + chol_solve(L, res)
                 dp = thp_inv * (hp + A.T @ dy)
                 ds = ths_inv * (hs + lp.scoef * dy[lp.srow])
                 dmuL = np.where(free, (rcL - muL * dp) / tL, 0.0)
@@ -429,6 +441,34 @@ def eqp_loop(lp, sets, p_ref, y_ref, rounds, stats):
 IPM_STAGES = ((1e-8, IPM_MAXIT), (1e-10, 6), (1e-12, 6))
 
 
+def elastic_layout(rtype):
+    """Slack layout of the elastic (phase-1) LP: the reference's restoration layout (subproblem.jl:83-112)
+    with zero lower bounds - EQ rows get s+ - s-, GE rows +s, LE rows -s."""
+    srow, scoef = [], []
+    for i, t in enumerate(rtype):
+        if t == 0:
+            srow += [i, i]; scoef += [1.0, -1.0]
+        elif t == 1:
+            srow += [i]; scoef += [1.0]
+        else:
+            srow += [i]; scoef += [-1.0]
+    return np.array(srow, np.int64), np.array(scoef, float)
+
+
+def phase1_infeasible(lp, stats):
+    """min sum of elastic slacks over the same rows and box.  The optimum is positive iff `lp` is
+    infeasible, and then the optimal row multipliers are a Farkas certificate, which is verified
+    rigorously with farkas_margin before INFEASIBLE is reported."""
+    srow, scoef = elastic_layout(lp.rtype)
+    ns = len(srow)
+    lp1 = LP(np.zeros(lp.n), lp.A, lp.rtype, lp.r, lp.lb, lp.ub, srow, scoef, np.ones(ns), np.zeros(ns))
+    ip = IPM(lp1)
+    ip.run(1e-8, IPM_MAXIT)
+    stats['nfact'] += ip.iters
+    stats['phase1_iters'] = ip.iters
+    return farkas_margin(lp, ip.y) > 1e-9
+
+
 def solve_scaled(lp, warm=None, stats=None):
     if stats is None:
         stats = {}
@@ -450,6 +490,18 @@ def solve_scaled(lp, warm=None, stats=None):
             stats['path'] = 'ipm-infeasible'
             return INFEASIBLE, None, None, None, None
         if st == OTHER and stage == 0:
+            # the IPM is only the identifier: a jammed / slow run that is already close is still handed to the
+            # active-set solve, whose LP optimality test decides
+            pinf, dinf, gap = ip.log[-1][1:]
+            if pinf <= 1e-3 and dinf <= 1e-3 and gap <= 1e-4:
+                sets0 = identify(lp, ip)
+                ok, p, s, y, sets = eqp_loop(lp, sets0, zero_p, zero_y, 3, stats)
+                if ok:
+                    stats['path'] = 'ipm~+ln'
+                    return OPTIMAL, p, s, y, sets
+            if lp.ns == 0 and phase1_infeasible(lp, stats):
+                stats['path'] = 'phase1-infeasible'
+                return INFEASIBLE, None, None, None, None
             break                                   # never reached 1e-8: no identification attempt
         sets0 = identify(lp, ip)
         ok, p, s, y, sets = eqp_loop(lp, sets0, zero_p, zero_y, 2, stats)
