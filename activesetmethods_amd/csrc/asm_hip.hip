@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <numeric>
 #include <stdexcept>
 #include <string>
@@ -90,6 +91,8 @@ struct asm_handle {
     double *d_dE = nullptr, *d_J = nullptr, *d_Ah = nullptr, *d_S = nullptr;
     double *d_c = nullptr, *d_rho = nullptr, *d_theta = nullptr, *d_diag = nullptr, *d_diag0 = nullptr;
     double *d_vecN = nullptr, *d_vecM = nullptr, *d_vecM2 = nullptr, *d_part = nullptr, *d_partial = nullptr;
+    double *d_Linv = nullptr, *d_tpart = nullptr;
+    int64_t tpart_len = 0;
     int* d_idx = nullptr;
     double* h_pin = nullptr;        // pinned staging (max(ldn, Mp) doubles) x 2
     int64_t pin_len = 0;
@@ -107,6 +110,8 @@ struct asm_handle {
     asm_kernel_stats kstats;
     std::vector<TimedRegion> regions;
     std::vector<hipEvent_t> event_pool;
+    std::map<std::pair<int, int>, hipGraphExec_t> graphs;   // (kind, Ms) -> captured launch sequence
+    bool use_graphs = false;
     bool timing = true;
     bool verbose = false;
 };
@@ -234,11 +239,36 @@ struct Dev {
         hipLaunchKernelGGL(k_diag_prepare, dim3(1), dim3(1024), 0, h->stream, h->d_S, h->Mp, Ms, h->d_diag0, mode, rel, absv);
     }
     // in-place blocked right-looking Cholesky of S[0:Ms,0:Ms] (lower)
+    // Replays a captured launch sequence (hipGraph) for the sizes that recur every IPM iteration; the
+    // sequence is static for a given (kind, Ms), so host launch latency is paid once.
+    template <class F>
+    void run_sequence(int kind, int Ms, bool cacheable, F&& launches) {
+        if (!h->use_graphs || !cacheable) { launches(); return; }
+        auto key = std::make_pair(kind, Ms);
+        auto it = h->graphs.find(key);
+        if (it == h->graphs.end()) {
+            hipGraph_t g = nullptr;
+            hipGraphExec_t ex = nullptr;
+            HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            launches();
+            HIPCHK(hipStreamEndCapture(h->stream, &g));
+            HIPCHK(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+            HIPCHK(hipGraphDestroy(g));
+            it = h->graphs.emplace(key, ex).first;
+        }
+        HIPCHK(hipGraphLaunch(it->second, h->stream));
+    }
+
     void chol(int Ms, double thr = 1e-14) {
         int id = begin(ASM_K_CHOL, (double)Ms * Ms * Ms / 3.0, 8.0 * 1.5 * Ms * (double)Ms);
+        run_sequence(thr == 1e-14 ? 1 : 2, Ms, Ms == (int)h->M, [&] { chol_launches(Ms, thr); });
+        end(id);
+        h->stats.nfact += 1;
+    }
+    void chol_launches(int Ms, double thr) {
         for (int k0 = 0; k0 < Ms; k0 += ASM_NB) {
             int nb = std::min(ASM_NB, Ms - k0);
-            hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, h->stream, h->d_S, h->Mp, k0, nb, h->d_diag0, thr);
+            hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, h->stream, h->d_S, h->Mp, k0, nb, h->d_diag0, thr, h->d_Linv);
             int k1 = k0 + nb;
             if (k1 < Ms) {
                 int rem = Ms - k1;
@@ -246,32 +276,39 @@ struct Dev {
                 launch_syrk(pick_tile(rem), h->d_S + k0, h->Mp, nullptr, k1, rem, nb, nullptr, nullptr, h->d_S, h->Mp, k1, 1);
             }
         }
-        end(id);
-        h->stats.nfact += 1;
     }
     // out = (L L')^-1 rhs   (compact vectors of length Ms)
     void chol_solve(const double* rhs, double* out, int Ms) {
         h2d(h->d_vecM2, rhs, Ms, Ms);
         int id = begin(ASM_K_TRSV, 2.0 * Ms * (double)Ms, 8.0 * Ms * (double)Ms);
         double* z = h->d_vecM;
+        run_sequence(3, Ms, Ms == (int)h->M, [&] { solve_launches(Ms); });
+        end(id);
+        d2h(out, h->d_vecM2, Ms);
+    }
+    void solve_launches(int Ms) {
+        // forward: w = copy of rhs (d_vecM2, updated in place), z -> d_vecM ; backward: x -> d_vecM2 (w is dead by then)
+        double* w = h->d_vecM2;
+        double* z = h->d_vecM;
         for (int k0 = 0; k0 < Ms; k0 += ASM_NB) {
             int nb = std::min(ASM_NB, Ms - k0);
-            if (k0 > 0)
-                hipLaunchKernelGGL(k_trsv_panel_dot, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, h->stream, h->d_S, h->Mp, k0, nb, z,
-                                   h->d_part);
-            hipLaunchKernelGGL(k_trsv_diag_fwd, dim3(1), dim3(256), 0, h->stream, h->d_S, h->Mp, k0, nb, h->d_vecM2, h->d_part, z,
-                               k0 > 0 ? 1 : 0);
+            int rem = Ms - (k0 + nb);
+            unsigned g = (unsigned)std::max(1, (rem + ASM_TRSV_ROWS - 1) / ASM_TRSV_ROWS);
+            hipLaunchKernelGGL(k_trsv_fwd_step, dim3(g), dim3(256), 0, h->stream, h->d_S, h->Mp, h->d_Linv, k0, nb, Ms, w, z);
         }
         int last = ((Ms - 1) / ASM_NB) * ASM_NB;
+        int n_in = 0;
+        int flip = 0;
         for (int k0 = last; k0 >= 0; k0 -= ASM_NB) {
             int nb = std::min(ASM_NB, Ms - k0);
-            hipLaunchKernelGGL(k_trsv_diag_bwd, dim3(1), dim3(256), 0, h->stream, h->d_S, h->Mp, k0, nb, z);
-            if (k0 > 0)
-                hipLaunchKernelGGL(k_trsv_panel_axpy, dim3((unsigned)((k0 + 255) / 256)), dim3(256), 0, h->stream, h->d_S, h->Mp, k0, nb,
-                                   z);
+            unsigned g = (unsigned)std::max(1, (Ms - k0 + ASM_TRSV_ROWS - 1) / ASM_TRSV_ROWS);
+            double* pin = h->d_tpart + (int64_t)flip * h->tpart_len;
+            double* pout = h->d_tpart + (int64_t)(1 - flip) * h->tpart_len;
+            hipLaunchKernelGGL(k_trsv_bwd_step, dim3(g), dim3(256), 0, h->stream, h->d_S, h->Mp, h->d_Linv, k0, nb, Ms, z, w, pin, n_in,
+                               pout);
+            n_in = (int)g;
+            flip = 1 - flip;
         }
-        end(id);
-        d2h(out, z, Ms);
     }
 
     // COO values (device resident) -> dense J incl. the extra range rows (common.jl:12-20, subproblem.jl:438-457)
@@ -901,14 +938,17 @@ int row_kind(double lb, double ub) {
 }
 
 void free_device(asm_handle* h) {
+    for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+    h->graphs.clear();
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(h->d_perm); F(h->d_ustart); F(h->d_uoff); F(h->d_adjoff);
     F(h->d_dE); F(h->d_J); F(h->d_Ah); F(h->d_S); F(h->d_c); F(h->d_rho); F(h->d_theta); F(h->d_diag); F(h->d_diag0);
-    F(h->d_vecN); F(h->d_vecM); F(h->d_vecM2); F(h->d_part); F(h->d_partial); F(h->d_idx);
+    F(h->d_vecN); F(h->d_vecM); F(h->d_vecM2); F(h->d_part); F(h->d_partial); F(h->d_idx); F(h->d_Linv); F(h->d_tpart);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
     h->d_perm = h->d_ustart = h->d_uoff = h->d_adjoff = nullptr;
     h->d_dE = h->d_J = h->d_Ah = h->d_S = h->d_c = h->d_rho = h->d_theta = h->d_diag = h->d_diag0 = nullptr;
     h->d_vecN = h->d_vecM = h->d_vecM2 = h->d_part = h->d_partial = nullptr;
+    h->d_Linv = h->d_tpart = nullptr;
     h->d_idx = nullptr;
     h->h_pin = nullptr;
 }
@@ -993,6 +1033,9 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     dmalloc(&h->d_vecN, h->ldn); dmalloc(&h->d_vecM, h->Mp); dmalloc(&h->d_vecM2, h->Mp); dmalloc(&h->d_part, ASM_NB);
     dmalloc(&h->d_partial, (int64_t)ASM_TMAXCHUNKS * h->ldn);
     dmalloc(&h->d_idx, h->Mp);
+    dmalloc(&h->d_Linv, (h->Mp / ASM_NB + 1) * ASM_NB * ASM_NB);
+    h->tpart_len = (h->Mp / ASM_TRSV_ROWS + 2) * ASM_NB;
+    dmalloc(&h->d_tpart, 2 * h->tpart_len);
     h->pin_len = std::max(h->ldn, h->Mp);
     HIPCHK(hipHostMalloc((void**)&h->h_pin, 2 * h->pin_len * sizeof(double)));
     HIPCHK(hipMemsetAsync(h->d_J, 0, h->Mp * h->ldn * sizeof(double), h->stream));
@@ -1185,6 +1228,8 @@ int asm_create(int device, asm_handle** out) {
     h->timing = !(tm && tm[0] == '0');
     const char* vb = std::getenv("ASM_HIP_VERBOSE");
     h->verbose = vb && vb[0] == '1';
+    const char* gr = std::getenv("ASM_HIP_GRAPHS");
+    h->use_graphs = gr && gr[0] == '1';      // opt-in: no measured gain on this ROCm build, and rocprofv3 crashes on captured streams
     *out = h;
     return ASM_OK;
 }

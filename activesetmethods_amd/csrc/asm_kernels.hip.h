@@ -268,9 +268,11 @@ __global__ __launch_bounds__(1024) void k_diag_prepare(double* __restrict__ S, i
 // Cholesky of one NB x NB diagonal block, staged in LDS.  Pivot guard: d <= 1e-14*diag0 -> d := 1e256.
 #define ASM_DP (ASM_NB + 1)
 __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int64_t ldS, int k0, int nb,
-                                                    const double* __restrict__ diag0, double thr) {
+                                                    const double* __restrict__ diag0, double thr, double* __restrict__ Linv) {
     __shared__ double D[ASM_NB * ASM_DP];
+    __shared__ double W[ASM_NB * ASM_DP];
     __shared__ double d0[ASM_NB];
+    __shared__ double red[4][ASM_NB];
     const int tid = threadIdx.x, r = tid & 63, g = tid >> 6;
     for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
         int rr = e >> 6, c = e & 63;
@@ -293,6 +295,25 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int6
     for (int e = tid; e < nb * ASM_NB; e += 256) {
         int rr = e >> 6, c = e & 63;
         if (c <= rr && c < nb) S[(int64_t)(k0 + rr) * ldS + k0 + c] = D[rr * ASM_DP + c];
+    }
+    // explicit inverse of the diagonal block (used by the one-launch-per-block triangular solves):
+    // thread (c, g) solves L x = e_c by forward substitution, the inner products split over the 4 wavefronts.
+    // Rows/cols >= nb of D hold the identity, so the padded inverse is the identity there.
+    {
+        const int c = r;                       // column of the inverse owned by this lane
+        for (int rr = 0; rr < ASM_NB; ++rr) {
+            double part = 0.0;
+            for (int q = c + g; q < rr; q += 4) part += D[rr * ASM_DP + q] * W[q * ASM_DP + c];
+            red[g][c] = part;
+            __syncthreads();
+            if (g == 0) {
+                double sum = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+                double rhs = (rr == c) ? 1.0 : 0.0;
+                W[rr * ASM_DP + c] = (rr < c) ? 0.0 : (rhs - sum) / D[rr * ASM_DP + rr];
+            }
+            __syncthreads();
+        }
+        for (int e = tid; e < ASM_NB * ASM_NB; e += 256) Linv[(int64_t)(k0 / ASM_NB) * ASM_NB * ASM_NB + e] = W[(e >> 6) * ASM_DP + (e & 63)];
     }
 }
 
@@ -325,75 +346,80 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ S, int6
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Blocked triangular solves with the row-major lower factor.
-// forward, step k:   part[r] = sum_{j<k0} L[k0+r, j] z[j]          (k_trsv_panel_dot: one wavefront per row)
-//                    z[k0:k1] = L11^-1 (b[k0:k1] - part)            (k_trsv_diag_fwd)
-// backward, step k:  x[k0:k1] = L11^-T z[k0:k1]                     (k_trsv_diag_bwd)
-//                    z[j] -= sum_r L[k0+r, j] x[k0+r]   for j < k0  (k_trsv_panel_axpy: one thread per column)
-__global__ __launch_bounds__(256) void k_trsv_panel_dot(const double* __restrict__ L, int64_t ld, int k0, int nb,
-                                                        const double* __restrict__ z, double* __restrict__ part) {
-    int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= nb) return;
-    int lane = threadIdx.x & 63;
-    const double* row = L + (int64_t)(k0 + r) * ld;
-    double acc = 0.0;
-    for (int j = lane; j < k0; j += 64) acc = fma(row[j], z[j], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) part[r] = acc;
-}
-
-__global__ __launch_bounds__(256) void k_trsv_diag_fwd(const double* __restrict__ L, int64_t ld, int k0, int nb,
-                                                       const double* __restrict__ b, const double* __restrict__ part,
-                                                       double* __restrict__ z, int use_part) {
-    // L11 staged in LDS by the whole workgroup; wavefront 0 then runs the column-oriented substitution
-    // (lane r owns unknown r, one wave broadcast per step).
-    __shared__ double D[ASM_NB * ASM_DP];
-    const int tid = threadIdx.x;
-    for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
-        int rr = e >> 6, c = e & 63;
-        D[rr * ASM_DP + c] = (rr < nb && c <= rr) ? L[(int64_t)(k0 + rr) * ld + k0 + c] : (rr == c ? 1.0 : 0.0);
+// Blocked triangular solves with the row-major lower factor: ONE launch per 64-wide block and direction.
+// The diagonal blocks are applied through their explicit inverses (k_potrf_diag), so a step has no
+// sequential 64-stage substitution; every workgroup recomputes the 64 new unknowns redundantly from LDS.
+//
+// forward  (L z = b), step k, right-looking:   z_k = Linv_kk w[k0:k1] ;  w[i] -= L[i,k0:k1] . z_k   (i >= k1)
+//          one wavefront per row of the tall panel: a coalesced 512-B row segment and a wave-shuffle reduction.
+// backward (L' x = z), step k, left-looking:   x_k = Linv_kk' (z_k - s_k),  s_k[c] = sum_{i>=k1} L[i,k0+c] x[i]
+//          s_k arrives as per-workgroup partial sums written by step k+1 (summed in index order:
+//          deterministic); the same launch then produces the partial sums of block k-1 over rows >= k0.
+#define ASM_TRSV_ROWS 64      // rows of the tall panel per workgroup
+__global__ __launch_bounds__(256) void k_trsv_fwd_step(const double* __restrict__ L, int64_t ld, const double* __restrict__ Linv,
+                                                       int k0, int nb, int Ms, double* __restrict__ w, double* __restrict__ z) {
+    __shared__ double Li[ASM_NB * ASM_DP];
+    __shared__ double bk[ASM_NB], zk[ASM_NB];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double* Lb = Linv + (int64_t)(k0 / ASM_NB) * ASM_NB * ASM_NB;
+    for (int e = tid; e < ASM_NB * ASM_NB; e += 256) Li[(e >> 6) * ASM_DP + (e & 63)] = Lb[e];
+    if (tid < ASM_NB) bk[tid] = tid < nb ? w[k0 + tid] : 0.0;
+    __syncthreads();
+    if (tid < ASM_NB) {
+        double acc = 0.0;
+        for (int c = 0; c <= tid; ++c) acc = fma(Li[tid * ASM_DP + c], bk[c], acc);
+        zk[tid] = acc;
+        if (blockIdx.x == 0 && tid < nb) z[k0 + tid] = acc;
     }
     __syncthreads();
-    if (tid >= 64) return;
-    int r = tid;
-    double v = 0.0;
-    if (r < nb) v = b[k0 + r] - (use_part ? part[r] : 0.0);
-    for (int c = 0; c < nb; ++c) {
-        double xc = __shfl(v, c, 64) / D[c * ASM_DP + c];
-        if (r == c) v = xc;
-        else if (r > c) v -= D[r * ASM_DP + c] * xc;
+    const int k1 = k0 + nb;
+    const double zl = lane < nb ? zk[lane] : 0.0;
+    const int base = k1 + blockIdx.x * ASM_TRSV_ROWS;
+    for (int rr = wv; rr < ASM_TRSV_ROWS; rr += 4) {
+        int i = base + rr;
+        if (i >= Ms) break;
+        double v = lane < nb ? L[(int64_t)i * ld + k0 + lane] * zl : 0.0;
+        v = wave_sum(v);
+        if (lane == 0) w[i] -= v;
     }
-    if (r < nb) z[k0 + r] = v;
 }
 
-__global__ __launch_bounds__(256) void k_trsv_diag_bwd(const double* __restrict__ L, int64_t ld, int k0, int nb,
-                                                       double* __restrict__ z) {
-    // x = L11^-T z in place; step c from nb-1 down: x_c = v_c / L_cc ; v_r -= L[c][r] x_c (r < c)
-    __shared__ double D[ASM_NB * ASM_DP];
-    const int tid = threadIdx.x;
-    for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
-        int rr = e >> 6, c = e & 63;
-        D[rr * ASM_DP + c] = (rr < nb && c <= rr) ? L[(int64_t)(k0 + rr) * ld + k0 + c] : (rr == c ? 1.0 : 0.0);
+__global__ __launch_bounds__(256) void k_trsv_bwd_step(const double* __restrict__ L, int64_t ld, const double* __restrict__ Linv,
+                                                       int k0, int nb, int Ms, const double* __restrict__ z, double* __restrict__ x,
+                                                       const double* __restrict__ part_in, int n_in, double* __restrict__ part_out) {
+    __shared__ double Li[ASM_NB * ASM_DP];
+    __shared__ double tk[ASM_NB], xk[ASM_NB];
+    __shared__ double red[4][ASM_NB];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double* Lb = Linv + (int64_t)(k0 / ASM_NB) * ASM_NB * ASM_NB;
+    for (int e = tid; e < ASM_NB * ASM_NB; e += 256) Li[(e >> 6) * ASM_DP + (e & 63)] = Lb[e];
+    if (tid < ASM_NB) {
+        double s = 0.0;
+        for (int g = 0; g < n_in; ++g) s += part_in[(int64_t)g * ASM_NB + tid];
+        tk[tid] = tid < nb ? z[k0 + tid] - s : 0.0;
     }
     __syncthreads();
-    if (tid >= 64) return;
-    int r = tid;
-    double v = (r < nb) ? z[k0 + r] : 0.0;
-    for (int c = nb - 1; c >= 0; --c) {
-        double xc = __shfl(v, c, 64) / D[c * ASM_DP + c];
-        if (r == c) v = xc;
-        else if (r < c) v -= D[c * ASM_DP + r] * xc;
+    if (tid < ASM_NB) {                              // x_k = Linv' t : x_c = sum_{r >= c} Linv[r][c] t[r]
+        double acc = 0.0;
+        for (int r = tid; r < ASM_NB; ++r) acc = fma(Li[r * ASM_DP + tid], tk[r], acc);
+        xk[tid] = acc;
+        if (blockIdx.x == 0 && tid < nb) x[k0 + tid] = acc;
     }
-    if (r < nb) z[k0 + r] = v;
-}
-
-__global__ __launch_bounds__(256) void k_trsv_panel_axpy(const double* __restrict__ L, int64_t ld, int k0, int nb,
-                                                         double* __restrict__ z) {
-    int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= k0) return;
+    __syncthreads();
+    if (k0 == 0) return;
+    // partial sums for block k-1 (columns k0-64 .. k0-1) over this workgroup's rows i >= k0
+    const int cprev = k0 - ASM_NB;
+    const int base = k0 + blockIdx.x * ASM_TRSV_ROWS;
     double acc = 0.0;
-    for (int r = 0; r < nb; ++r) acc = fma(L[(int64_t)(k0 + r) * ld + j], z[k0 + r], acc);
-    z[j] -= acc;
+    for (int rr = wv; rr < ASM_TRSV_ROWS; rr += 4) {
+        int i = base + rr;
+        if (i >= Ms) break;
+        double xi = (i < k0 + nb) ? xk[i - k0] : x[i];
+        acc = fma(L[(int64_t)i * ld + cprev + lane], xi, acc);
+    }
+    red[wv][lane] = acc;
+    __syncthreads();
+    if (tid < ASM_NB) part_out[(int64_t)blockIdx.x * ASM_NB + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
 // out[i] = || A[i, :] ||_2   (one wavefront per row) - KT_residuals / compute_nu! (common.jl:41, slp.jl:58)
