@@ -206,20 +206,27 @@ struct Dev {
     static int pick_tile(int64_t Ms) { return Ms >= 3072 ? 4 : (Ms >= 768 ? 2 : 1); }
 
     void launch_syrk(int T, const double* A, int64_t ld, const int* idx, int64_t row0, int Ms, int K, const double* theta,
-                     const double* diag, double* S, int64_t ldS, int64_t srow0, int mode) {
+                     const double* diag, double* S, int64_t ldS, int64_t srow0, int mode, int MsB = -1) {
         int TS = 32 * T;
         int64_t nt = (Ms + TS - 1) / TS;
+        int ntj = 0;
         int64_t blocks = nt * (nt + 1) / 2;
+        if (MsB >= 0) {                       // rectangular: all row tiles x the column tiles covering MsB columns
+            ntj = (int)((MsB + TS - 1) / TS);
+            blocks = nt * ntj;
+        } else {
+            MsB = Ms;
+        }
         if (blocks <= 0) return;
         if (T == 4)
             hipLaunchKernelGGL(k_syrk<4>, dim3((unsigned)blocks), dim3(256), 0, h->stream, A, ld, idx, row0, Ms, K, theta, diag, S,
-                               ldS, srow0, mode);
+                               ldS, srow0, mode, MsB, ntj);
         else if (T == 2)
             hipLaunchKernelGGL(k_syrk<2>, dim3((unsigned)blocks), dim3(256), 0, h->stream, A, ld, idx, row0, Ms, K, theta, diag, S,
-                               ldS, srow0, mode);
+                               ldS, srow0, mode, MsB, ntj);
         else
             hipLaunchKernelGGL(k_syrk<1>, dim3((unsigned)blocks), dim3(256), 0, h->stream, A, ld, idx, row0, Ms, K, theta, diag, S,
-                               ldS, srow0, mode);
+                               ldS, srow0, mode, MsB, ntj);
     }
 
     // S[0:Ms,0:Ms] (lower) = Ah[idx,:] diag(theta) Ah[idx,:]' + diag     idx == nullptr -> identity
@@ -266,14 +273,26 @@ struct Dev {
         h->stats.nfact += 1;
     }
     void chol_launches(int Ms, double thr) {
-        for (int k0 = 0; k0 < Ms; k0 += ASM_NB) {
-            int nb = std::min(ASM_NB, Ms - k0);
-            hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, h->stream, h->d_S, h->Mp, k0, nb, h->d_diag0, thr, h->d_Linv);
-            int k1 = k0 + nb;
-            if (k1 < Ms) {
-                int rem = Ms - k1;
-                hipLaunchKernelGGL(k_trsm_panel, dim3((unsigned)((rem + 63) / 64)), dim3(256), 0, h->stream, h->d_S, h->Mp, k0, nb, Ms);
-                launch_syrk(pick_tile(rem), h->d_S + k0, h->Mp, nullptr, k1, rem, nb, nullptr, nullptr, h->d_S, h->Mp, k1, 1);
+        // two-level right-looking blocking: 64-wide steps inside a 256-wide outer panel touch only the panel's
+        // own columns; the large trailing matrix is read-modify-written once per outer panel (K = 256).
+        const int NBO = 4 * ASM_NB;
+        for (int K0 = 0; K0 < Ms; K0 += NBO) {
+            int K1 = std::min(K0 + NBO, Ms);
+            for (int k0 = K0; k0 < K1; k0 += ASM_NB) {
+                int nb = std::min(ASM_NB, Ms - k0);
+                hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(64), 0, h->stream, h->d_S, h->Mp, k0, nb, h->d_diag0, thr, h->d_Linv);
+                int k1 = k0 + nb;
+                if (k1 < Ms) {
+                    int rem = Ms - k1;
+                    hipLaunchKernelGGL(k_trsm_panel, dim3((unsigned)((rem + 63) / 64)), dim3(256), 0, h->stream, h->d_S, h->Mp, k0, nb, Ms,
+                                       h->d_Linv);
+                    if (k1 < K1)   // update the remaining columns of this outer panel only
+                        launch_syrk(pick_tile(rem), h->d_S + k0, h->Mp, nullptr, k1, rem, nb, nullptr, nullptr, h->d_S, h->Mp, k1, 1, K1 - k1);
+                }
+            }
+            if (K1 < Ms) {
+                int rem = Ms - K1;
+                launch_syrk(pick_tile(rem), h->d_S + K0, h->Mp, nullptr, K1, rem, K1 - K0, nullptr, nullptr, h->d_S, h->Mp, K1, 1);
             }
         }
     }
@@ -281,7 +300,6 @@ struct Dev {
     void chol_solve(const double* rhs, double* out, int Ms) {
         h2d(h->d_vecM2, rhs, Ms, Ms);
         int id = begin(ASM_K_TRSV, 2.0 * Ms * (double)Ms, 8.0 * Ms * (double)Ms);
-        double* z = h->d_vecM;
         run_sequence(3, Ms, Ms == (int)h->M, [&] { solve_launches(Ms); });
         end(id);
         d2h(out, h->d_vecM2, Ms);
@@ -301,7 +319,7 @@ struct Dev {
         int flip = 0;
         for (int k0 = last; k0 >= 0; k0 -= ASM_NB) {
             int nb = std::min(ASM_NB, Ms - k0);
-            unsigned g = (unsigned)std::max(1, (Ms - k0 + ASM_TRSV_ROWS - 1) / ASM_TRSV_ROWS);
+            unsigned g = (unsigned)std::max(1, (Ms - k0 + ASM_TRSV_BROWS - 1) / ASM_TRSV_BROWS);
             double* pin = h->d_tpart + (int64_t)flip * h->tpart_len;
             double* pout = h->d_tpart + (int64_t)(1 - flip) * h->tpart_len;
             hipLaunchKernelGGL(k_trsv_bwd_step, dim3(g), dim3(256), 0, h->stream, h->d_S, h->Mp, h->d_Linv, k0, nb, Ms, z, w, pin, n_in,

@@ -149,16 +149,24 @@ __global__ __launch_bounds__(256) void k_gemv_t_stage2(const double* __restrict_
 template <int T>
 __global__ __launch_bounds__(256) void k_syrk(const double* __restrict__ A, int64_t ld, const int* __restrict__ idx, int64_t row0,
                                               int Ms, int K, const double* __restrict__ theta, const double* __restrict__ diag,
-                                              double* __restrict__ S, int64_t ldS, int64_t srow0, int mode) {
+                                              double* __restrict__ S, int64_t ldS, int64_t srow0, int mode, int MsB, int ntj) {
     constexpr int TS = 32 * T;
     __shared__ double As[TS * ASM_PITCH];
     __shared__ double Bs[TS * ASM_PITCH];
-    // lower-triangular tile pair (bi >= bj) from the linear block id
-    int t = blockIdx.x;
-    int bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-    while ((int64_t)(bi + 1) * (bi + 2) / 2 <= t) ++bi;
-    while ((int64_t)bi * (bi + 1) / 2 > t) --bi;
-    int bj = t - (int)((int64_t)bi * (bi + 1) / 2);
+    int bi, bj;
+    if (ntj > 0) {
+        // rectangular enumeration (Cholesky in-panel update): all row tiles x the first ntj column tiles
+        bi = blockIdx.x / ntj;
+        bj = blockIdx.x - bi * ntj;
+        if (bj > bi) return;
+    } else {
+        // lower-triangular tile pair (bi >= bj) from the linear block id
+        int t = blockIdx.x;
+        bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((int64_t)(bi + 1) * (bi + 2) / 2 <= t) ++bi;
+        while ((int64_t)bi * (bi + 1) / 2 > t) --bi;
+        bj = t - (int)((int64_t)bi * (bi + 1) / 2);
+    }
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 1, wc = w & 1;
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(256) void k_syrk(const double* __restrict__ A, int6
         arow[ps] = nullptr;
         brow[ps] = nullptr;
         if (r < TS && ga < Ms) arow[ps] = A + (idx ? (int64_t)idx[ga] : row0 + ga) * ld;
-        if (r < TS && gb < Ms) brow[ps] = A + (idx ? (int64_t)idx[gb] : row0 + gb) * ld;
+        if (r < TS && gb < MsB) brow[ps] = A + (idx ? (int64_t)idx[gb] : row0 + gb) * ld;
     }
 
     for (int k0 = 0; k0 < K; k0 += ASM_KC) {
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(256) void k_syrk(const double* __restrict__ A, int6
             for (int r = 0; r < 4; ++r) {
                 int row = bi * TS + wr * 16 * T + i * 16 + (lane >> 4) + 4 * r;
                 int col = bj * TS + wc * 16 * T + j * 16 + (lane & 15);
-                if (row < Ms && col <= row) {
+                if (row < Ms && col < MsB && col <= row) {
                     double* dst = S + (srow0 + row) * ldS + (srow0 + col);
                     double v = acc[i][j][r];
                     if (mode == 0) {
@@ -267,77 +275,90 @@ __global__ __launch_bounds__(1024) void k_diag_prepare(double* __restrict__ S, i
 // ---------------------------------------------------------------------------------------------------
 // Cholesky of one NB x NB diagonal block, staged in LDS.  Pivot guard: d <= 1e-14*diag0 -> d := 1e256.
 #define ASM_DP (ASM_NB + 1)
-__global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int64_t ldS, int k0, int nb,
-                                                    const double* __restrict__ diag0, double thr, double* __restrict__ Linv) {
+// One wavefront factors the 64x64 diagonal block: lane r keeps row r in registers (fully unrolled, compile-time
+// register indices), each new column is broadcast through LDS.  Then the explicit inverse of L11 is formed the same
+// way (lane c owns column c of the inverse) and stored for the panel solve and the triangular solves.
+__global__ __launch_bounds__(64) void k_potrf_diag(double* __restrict__ S, int64_t ldS, int k0, int nb,
+                                                   const double* __restrict__ diag0, double thr, double* __restrict__ Linv) {
     __shared__ double D[ASM_NB * ASM_DP];
-    __shared__ double W[ASM_NB * ASM_DP];
-    __shared__ double d0[ASM_NB];
-    __shared__ double red[4][ASM_NB];
-    const int tid = threadIdx.x, r = tid & 63, g = tid >> 6;
-    for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
-        int rr = e >> 6, c = e & 63;
-        D[rr * ASM_DP + c] = (rr < nb && c <= rr) ? S[(int64_t)(k0 + rr) * ldS + k0 + c] : (rr == c ? 1.0 : 0.0);
-    }
-    if (tid < ASM_NB) d0[tid] = tid < nb ? diag0[k0 + tid] : 1.0;
+    __shared__ double col[ASM_NB];
+    const int r = threadIdx.x;
+    double a[ASM_NB];
+    // coalesced load through LDS, then row r -> registers
+    for (int rr = 0; rr < ASM_NB; ++rr)
+        D[rr * ASM_DP + r] = (rr < nb && r <= rr) ? S[(int64_t)(k0 + rr) * ldS + k0 + r] : (rr == r ? 1.0 : 0.0);
     __syncthreads();
-    for (int j = 0; j < nb; ++j) {
-        // every thread derives the same pivot (static guard), then updates its share of the trailing triangle
-        double d = D[j * ASM_DP + j];
-        if (!(d > thr * d0[j])) d = 1e256;
+#pragma unroll
+    for (int c = 0; c < ASM_NB; ++c) a[c] = D[r * ASM_DP + c];
+    const double d0r = r < nb ? diag0[k0 + r] : 1.0;
+#pragma unroll
+    for (int j = 0; j < ASM_NB; ++j) {
+        double d = __shfl(a[j], j, 64);
+        double g0 = __shfl(d0r, j, 64);
+        if (!(d > thr * g0)) d = 1e256;
         double ljj = sqrt(d);
-        double inv = 1.0 / ljj;
-        double lr = D[r * ASM_DP + j] * inv;
-        for (int c = j + 1 + g; c <= r; c += 4) D[r * ASM_DP + c] -= lr * (D[c * ASM_DP + j] * inv);
+        double l = a[j] / ljj;
+        if (r == j) l = ljj;
+        a[j] = l;
+        col[r] = l;
         __syncthreads();
-        if (g == 0 && r >= j) D[r * ASM_DP + j] = (r == j) ? ljj : lr;
+#pragma unroll
+        for (int c = j + 1; c < ASM_NB; ++c)
+            if (c <= r) a[c] -= l * col[c];
         __syncthreads();
     }
-    for (int e = tid; e < nb * ASM_NB; e += 256) {
-        int rr = e >> 6, c = e & 63;
-        if (c <= rr && c < nb) S[(int64_t)(k0 + rr) * ldS + k0 + c] = D[rr * ASM_DP + c];
+    // write back (through LDS for coalescing) and keep L11 in LDS for the inversion
+#pragma unroll
+    for (int c = 0; c < ASM_NB; ++c) D[r * ASM_DP + c] = (c <= r) ? a[c] : 0.0;
+    __syncthreads();
+    for (int rr = 0; rr < nb; ++rr)
+        if (r <= rr && r < nb) S[(int64_t)(k0 + rr) * ldS + k0 + r] = D[rr * ASM_DP + r];
+    // inverse: lane c solves L x = e_c ; x kept in registers, L rows broadcast from LDS
+    double x[ASM_NB];
+#pragma unroll
+    for (int rr = 0; rr < ASM_NB; ++rr) {
+        double sum = 0.0;
+#pragma unroll
+        for (int q = 0; q < rr; ++q) sum = fma(D[rr * ASM_DP + q], x[q], sum);
+        double rhs = (rr == r) ? 1.0 : 0.0;
+        x[rr] = (rr < r) ? 0.0 : (rhs - sum) / D[rr * ASM_DP + rr];
     }
-    // explicit inverse of the diagonal block (used by the one-launch-per-block triangular solves):
-    // thread (c, g) solves L x = e_c by forward substitution, the inner products split over the 4 wavefronts.
-    // Rows/cols >= nb of D hold the identity, so the padded inverse is the identity there.
-    {
-        const int c = r;                       // column of the inverse owned by this lane
-        for (int rr = 0; rr < ASM_NB; ++rr) {
-            double part = 0.0;
-            for (int q = c + g; q < rr; q += 4) part += D[rr * ASM_DP + q] * W[q * ASM_DP + c];
-            red[g][c] = part;
-            __syncthreads();
-            if (g == 0) {
-                double sum = red[0][c] + red[1][c] + red[2][c] + red[3][c];
-                double rhs = (rr == c) ? 1.0 : 0.0;
-                W[rr * ASM_DP + c] = (rr < c) ? 0.0 : (rhs - sum) / D[rr * ASM_DP + rr];
-            }
-            __syncthreads();
-        }
-        for (int e = tid; e < ASM_NB * ASM_NB; e += 256) Linv[(int64_t)(k0 / ASM_NB) * ASM_NB * ASM_NB + e] = W[(e >> 6) * ASM_DP + (e & 63)];
-    }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < ASM_NB; ++rr) D[rr * ASM_DP + r] = x[rr];
+    __syncthreads();
+    double* out = Linv + (int64_t)(k0 / ASM_NB) * ASM_NB * ASM_NB;
+    for (int rr = 0; rr < ASM_NB; ++rr) out[rr * ASM_NB + r] = D[rr * ASM_DP + r];
 }
 
-// Panel solve: S[i, k0:k1] <- S[i, k0:k1] * L11^-T for the 64 rows of this workgroup's tile; the tile and L11 are
-// staged in LDS (coalesced 512-B row segments), right-looking substitution with the columns split over 4 wavefronts.
-__global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ S, int64_t ldS, int k0, int nb, int Ms) {
-    __shared__ double Lk[ASM_NB * ASM_DP];
+// Panel solve through the explicit inverse:  S[i, k0:k1] <- S[i, k0:k1] * Linv11'  for the 64 rows of this tile.
+// X[r][c] = sum_{q<=c} tile[r][q] * Linv[c][q] ; thread (r, g) produces 16 columns, no barrier inside the loops.
+__global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ S, int64_t ldS, int k0, int nb, int Ms,
+                                                    const double* __restrict__ Linv) {
+    __shared__ double Li[ASM_NB * ASM_DP];
     __shared__ double X[ASM_NB * ASM_DP];
     const int tid = threadIdx.x, r = tid & 63, g = tid >> 6;
     const int i0 = k0 + nb + blockIdx.x * ASM_NB;
+    const double* Lb = Linv + (int64_t)(k0 / ASM_NB) * ASM_NB * ASM_NB;
     for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
         int rr = e >> 6, c = e & 63;
-        Lk[rr * ASM_DP + c] = (rr < nb && c <= rr) ? S[(int64_t)(k0 + rr) * ldS + k0 + c] : (rr == c ? 1.0 : 0.0);
+        Li[rr * ASM_DP + c] = Lb[e];
         int gi = i0 + rr;
         X[rr * ASM_DP + c] = (gi < Ms && c < nb) ? S[(int64_t)gi * ldS + k0 + c] : 0.0;
     }
     __syncthreads();
-    for (int c = 0; c < nb; ++c) {
-        double xc = X[r * ASM_DP + c] / Lk[c * ASM_DP + c];
-        for (int c2 = c + 1 + g; c2 < nb; c2 += 4) X[r * ASM_DP + c2] -= xc * Lk[c2 * ASM_DP + c];
-        __syncthreads();
-        if (g == 0) X[r * ASM_DP + c] = xc;
-        __syncthreads();
+    double out[16];
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+        int c = g * 16 + cc;
+        double acc = 0.0;
+        for (int q = 0; q <= c; ++q) acc = fma(X[r * ASM_DP + q], Li[c * ASM_DP + q], acc);
+        out[cc] = acc;
     }
+    __syncthreads();
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) X[r * ASM_DP + g * 16 + cc] = out[cc];
+    __syncthreads();
     for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
         int rr = e >> 6, c = e & 63;
         int gi = i0 + rr;
@@ -355,32 +376,49 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ S, int6
 // backward (L' x = z), step k, left-looking:   x_k = Linv_kk' (z_k - s_k),  s_k[c] = sum_{i>=k1} L[i,k0+c] x[i]
 //          s_k arrives as per-workgroup partial sums written by step k+1 (summed in index order:
 //          deterministic); the same launch then produces the partial sums of block k-1 over rows >= k0.
-#define ASM_TRSV_ROWS 64      // rows of the tall panel per workgroup
+#define ASM_TRSV_ROWS 64      // rows of the tall panel per workgroup (forward)
+#define ASM_TRSV_BROWS 256    // rows per workgroup for the backward partial sums
 __global__ __launch_bounds__(256) void k_trsv_fwd_step(const double* __restrict__ L, int64_t ld, const double* __restrict__ Linv,
                                                        int k0, int nb, int Ms, double* __restrict__ w, double* __restrict__ z) {
-    __shared__ double Li[ASM_NB * ASM_DP];
+    __shared__ double Li[ASM_NB * ASM_DP];      // Linv_kk, then re-used for the 64x64 tile of the panel
     __shared__ double bk[ASM_NB], zk[ASM_NB];
+    __shared__ double red[4][ASM_NB];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const double* Lb = Linv + (int64_t)(k0 / ASM_NB) * ASM_NB * ASM_NB;
     for (int e = tid; e < ASM_NB * ASM_NB; e += 256) Li[(e >> 6) * ASM_DP + (e & 63)] = Lb[e];
     if (tid < ASM_NB) bk[tid] = tid < nb ? w[k0 + tid] : 0.0;
     __syncthreads();
-    if (tid < ASM_NB) {
+    {   // z_k = Linv_kk b_k : row `lane`, the 64 columns split over the 4 wavefronts
         double acc = 0.0;
-        for (int c = 0; c <= tid; ++c) acc = fma(Li[tid * ASM_DP + c], bk[c], acc);
+        for (int c = wv * 16; c < wv * 16 + 16; ++c) acc = fma(Li[lane * ASM_DP + c], bk[c], acc);
+        red[wv][lane] = acc;
+    }
+    __syncthreads();
+    if (tid < ASM_NB) {
+        double acc = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
         zk[tid] = acc;
         if (blockIdx.x == 0 && tid < nb) z[k0 + tid] = acc;
     }
     __syncthreads();
     const int k1 = k0 + nb;
-    const double zl = lane < nb ? zk[lane] : 0.0;
     const int base = k1 + blockIdx.x * ASM_TRSV_ROWS;
-    for (int rr = wv; rr < ASM_TRSV_ROWS; rr += 4) {
+    if (base >= Ms) return;
+    // stage this workgroup's 64 x 64 tile of the panel (coalesced 512-B row segments)
+    for (int e = tid; e < ASM_TRSV_ROWS * ASM_NB; e += 256) {
+        int rr = e >> 6, c = e & 63;
         int i = base + rr;
-        if (i >= Ms) break;
-        double v = lane < nb ? L[(int64_t)i * ld + k0 + lane] * zl : 0.0;
-        v = wave_sum(v);
-        if (lane == 0) w[i] -= v;
+        Li[rr * ASM_DP + c] = (i < Ms && c < nb) ? L[(int64_t)i * ld + k0 + c] : 0.0;
+    }
+    __syncthreads();
+    {
+        double acc = 0.0;
+        for (int c = wv * 16; c < wv * 16 + 16; ++c) acc = fma(Li[lane * ASM_DP + c], zk[c], acc);
+        red[wv][lane] = acc;
+    }
+    __syncthreads();
+    if (tid < ASM_TRSV_ROWS) {
+        int i = base + tid;
+        if (i < Ms) w[i] -= (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
     }
 }
 
@@ -393,15 +431,23 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_step(const double* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const double* Lb = Linv + (int64_t)(k0 / ASM_NB) * ASM_NB * ASM_NB;
     for (int e = tid; e < ASM_NB * ASM_NB; e += 256) Li[(e >> 6) * ASM_DP + (e & 63)] = Lb[e];
-    if (tid < ASM_NB) {
+    {   // s_k = sum of the partial sums of step k+1 (fixed order: group g = wv, wv+4, ... then the 4 wavefronts)
         double s = 0.0;
-        for (int g = 0; g < n_in; ++g) s += part_in[(int64_t)g * ASM_NB + tid];
-        tk[tid] = tid < nb ? z[k0 + tid] - s : 0.0;
+        for (int g = wv; g < n_in; g += 4) s += part_in[(int64_t)g * ASM_NB + lane];
+        red[wv][lane] = s;
     }
     __syncthreads();
-    if (tid < ASM_NB) {                              // x_k = Linv' t : x_c = sum_{r >= c} Linv[r][c] t[r]
+    if (tid < ASM_NB) tk[tid] = tid < nb ? z[k0 + tid] - ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) : 0.0;
+    __syncthreads();
+    {   // x_k = Linv' t : x_c = sum_r Linv[r][c] t[r], rows split over the 4 wavefronts
         double acc = 0.0;
-        for (int r = tid; r < ASM_NB; ++r) acc = fma(Li[r * ASM_DP + tid], tk[r], acc);
+        for (int r = wv * 16; r < wv * 16 + 16; ++r) acc = fma(Li[r * ASM_DP + lane], tk[r], acc);
+        __syncthreads();
+        red[wv][lane] = acc;
+    }
+    __syncthreads();
+    if (tid < ASM_NB) {
+        double acc = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
         xk[tid] = acc;
         if (blockIdx.x == 0 && tid < nb) x[k0 + tid] = acc;
     }
@@ -409,9 +455,9 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_step(const double* __restrict_
     if (k0 == 0) return;
     // partial sums for block k-1 (columns k0-64 .. k0-1) over this workgroup's rows i >= k0
     const int cprev = k0 - ASM_NB;
-    const int base = k0 + blockIdx.x * ASM_TRSV_ROWS;
+    const int base = k0 + blockIdx.x * ASM_TRSV_BROWS;
     double acc = 0.0;
-    for (int rr = wv; rr < ASM_TRSV_ROWS; rr += 4) {
+    for (int rr = wv; rr < ASM_TRSV_BROWS; rr += 4) {
         int i = base + rr;
         if (i >= Ms) break;
         double xi = (i < k0 + nb) ? xk[i - k0] : x[i];
