@@ -995,7 +995,7 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     h->nadj = (int64_t)h->adj.size();
     h->M = m + h->nadj;
     h->Mp = round_up(std::max<int64_t>(h->M, 1), 16);
-    h->ldn = round_up(n, 16);
+    h->ldn = round_up(n, 32);              // multiple of the SYRK k-chunk (ASM_KC)
     h->rtype.assign(h->M, 0);
     for (int64_t i = 0; i < m; ++i) h->rtype[i] = h->kind[i] == 0 ? 0 : (h->kind[i] == -1 ? -1 : 1);
     for (int64_t k = 0; k < h->nadj; ++k) h->rtype[m + k] = -1;

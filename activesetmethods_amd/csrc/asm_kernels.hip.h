@@ -21,8 +21,8 @@
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 #define ASM_NB 64          // Cholesky panel width
-#define ASM_KC 16          // k-chunk staged through LDS by k_syrk
-#define ASM_PITCH 18       // LDS row pitch in doubles: KC + 2  (pitch = 2 mod 32 -> conflict-free ds_read_b64 fragments)
+#define ASM_KC 32          // k-chunk staged through LDS by k_syrk
+#define ASM_PITCH 34       // LDS row pitch in doubles: KC + 2  (pitch = 2 mod 32 -> conflict-free ds_read_b64 fragments)
 
 // ---------------------------------------------------------------------------------------------------
 // Assembly.  One thread per distinct (row, col) of the pattern; its duplicates are summed in the
@@ -151,8 +151,10 @@ __global__ __launch_bounds__(256) void k_syrk(const double* __restrict__ A, int6
                                               int Ms, int K, const double* __restrict__ theta, const double* __restrict__ diag,
                                               double* __restrict__ S, int64_t ldS, int64_t srow0, int mode, int MsB, int ntj) {
     constexpr int TS = 32 * T;
-    __shared__ double As[TS * ASM_PITCH];
-    __shared__ double Bs[TS * ASM_PITCH];
+    // two LDS stages: the global loads of chunk c+1 are issued before the MFMAs of chunk c and written to the
+    // other stage afterwards, so HBM/L2 latency hides under 16*T*T/4 matrix instructions; one barrier per chunk.
+    __shared__ __attribute__((aligned(16))) double As[2][TS * ASM_PITCH];
+    __shared__ __attribute__((aligned(16))) double Bs[2][TS * ASM_PITCH];
     int bi, bj;
     if (ntj > 0) {
         // rectangular enumeration (Cholesky in-panel update): all row tiles x the first ntj column tiles
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256) void k_syrk(const double* __restrict__ A, int6
     // staging assignment: TS rows x KC doubles per operand; each thread moves 2 doubles (16 B) per pass
     constexpr int PER_ROW = ASM_KC / 2;                 // threads per row
     constexpr int ROWS_PER_PASS = 256 / PER_ROW;        // 32
-    constexpr int PASSES = (TS + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
+    constexpr int PASSES = TS / ROWS_PER_PASS;          // = 2T
     const int lr = tid / PER_ROW, lk = (tid % PER_ROW) * 2;
     const double* arow[PASSES];
     const double* brow[PASSES];
@@ -189,37 +191,47 @@ __global__ __launch_bounds__(256) void k_syrk(const double* __restrict__ A, int6
         int ga = bi * TS + r, gb = bj * TS + r;
         arow[ps] = nullptr;
         brow[ps] = nullptr;
-        if (r < TS && ga < Ms) arow[ps] = A + (idx ? (int64_t)idx[ga] : row0 + ga) * ld;
-        if (r < TS && gb < MsB) brow[ps] = A + (idx ? (int64_t)idx[gb] : row0 + gb) * ld;
+        if (ga < Ms) arow[ps] = A + (idx ? (int64_t)idx[ga] : row0 + ga) * ld;
+        if (gb < MsB) brow[ps] = A + (idx ? (int64_t)idx[gb] : row0 + gb) * ld;
     }
-
-    for (int k0 = 0; k0 < K; k0 += ASM_KC) {
+    double2 ra[PASSES], rb[PASSES];
+    auto gload = [&](int k0) {
         double2 th = theta ? *reinterpret_cast<const double2*>(theta + k0 + lk) : make_double2(1.0, 1.0);
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
-            int r = ps * ROWS_PER_PASS + lr;
-            if (r < TS) {
-                double2 a = arow[ps] ? *reinterpret_cast<const double2*>(arow[ps] + k0 + lk) : make_double2(0.0, 0.0);
-                double2 b = brow[ps] ? *reinterpret_cast<const double2*>(brow[ps] + k0 + lk) : make_double2(0.0, 0.0);
-                As[r * ASM_PITCH + lk] = a.x;
-                As[r * ASM_PITCH + lk + 1] = a.y;
-                Bs[r * ASM_PITCH + lk] = b.x * th.x;
-                Bs[r * ASM_PITCH + lk + 1] = b.y * th.y;
-            }
+            ra[ps] = arow[ps] ? *reinterpret_cast<const double2*>(arow[ps] + k0 + lk) : make_double2(0.0, 0.0);
+            double2 b = brow[ps] ? *reinterpret_cast<const double2*>(brow[ps] + k0 + lk) : make_double2(0.0, 0.0);
+            rb[ps] = make_double2(b.x * th.x, b.y * th.y);
         }
-        __syncthreads();
+    };
+    auto lstore = [&](int st) {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            int r = ps * ROWS_PER_PASS + lr;
+            *reinterpret_cast<double2*>(&As[st][r * ASM_PITCH + lk]) = ra[ps];
+            *reinterpret_cast<double2*>(&Bs[st][r * ASM_PITCH + lk]) = rb[ps];
+        }
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int nchunks = K / ASM_KC;
+    for (int c = 0; c < nchunks; ++c) {
+        const int st = c & 1;
+        if (c + 1 < nchunks) gload((c + 1) * ASM_KC);
 #pragma unroll
         for (int kk = 0; kk < ASM_KC; kk += 4) {
             double af[T], bf[T];
 #pragma unroll
-            for (int i = 0; i < T; ++i) af[i] = As[(wr * 16 * T + i * 16 + (lane & 15)) * ASM_PITCH + kk + (lane >> 4)];
+            for (int i = 0; i < T; ++i) af[i] = As[st][(wr * 16 * T + i * 16 + (lane & 15)) * ASM_PITCH + kk + (lane >> 4)];
 #pragma unroll
-            for (int j = 0; j < T; ++j) bf[j] = Bs[(wc * 16 * T + j * 16 + (lane & 15)) * ASM_PITCH + kk + (lane >> 4)];
+            for (int j = 0; j < T; ++j) bf[j] = Bs[st][(wc * 16 * T + j * 16 + (lane & 15)) * ASM_PITCH + kk + (lane >> 4)];
 #pragma unroll
             for (int i = 0; i < T; ++i)
 #pragma unroll
                 for (int j = 0; j < T; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
+        if (c + 1 < nchunks) lstore(st ^ 1);
         __syncthreads();
     }
 #pragma unroll
