@@ -309,7 +309,8 @@ __global__ __launch_bounds__(64) void k_potrf_diag(double* __restrict__ S, int64
         double g0 = __shfl(d0r, j, 64);
         if (!(d > thr * g0)) d = 1e256;
         double ljj = sqrt(d);
-        double l = a[j] / ljj;
+        double inv = 1.0 / ljj;
+        double l = a[j] * inv;
         if (r == j) l = ljj;
         a[j] = l;
         col[r] = l;
@@ -469,11 +470,17 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_step(const double* __restrict_
     const int cprev = k0 - ASM_NB;
     const int base = k0 + blockIdx.x * ASM_TRSV_BROWS;
     double acc = 0.0;
-    for (int rr = wv; rr < ASM_TRSV_BROWS; rr += 4) {
-        int i = base + rr;
-        if (i >= Ms) break;
-        double xi = (i < k0 + nb) ? xk[i - k0] : x[i];
-        acc = fma(L[(int64_t)i * ld + cprev + lane], xi, acc);
+    for (int r0 = wv; r0 < ASM_TRSV_BROWS; r0 += 32) {       // 8 rows per batch: the loads are issued together
+        double lv[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            int i = base + r0 + 4 * u;
+            bool ok = i < Ms;
+            lv[u] = ok ? L[(int64_t)i * ld + cprev + lane] : 0.0;
+            xv[u] = ok ? ((i < k0 + nb) ? xk[i - k0] : x[i]) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fma(lv[u], xv[u], acc);
     }
     red[wv][lane] = acc;
     __syncthreads();
