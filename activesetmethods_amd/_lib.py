@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libasmhip.so")
 
 OPTIMAL, INFEASIBLE, DUAL_INFEASIBLE, OTHER = 1, 2, 3, 4
-K_NAMES = ("assemble", "scale", "gemv", "syrk", "chol", "trsv")
+K_NAMES = ("assemble", "scale", "gemv", "syrk", "chol", "trsv", "syrk_kernel")
 
 
 class SolveStats(C.Structure):
@@ -18,7 +18,7 @@ class SolveStats(C.Structure):
 
 
 class KernelStats(C.Structure):
-    _fields_ = [("ms", C.c_double * 6), ("calls", C.c_int64 * 6), ("flops", C.c_double * 6), ("bytes", C.c_double * 6)]
+    _fields_ = [("ms", C.c_double * 7), ("calls", C.c_int64 * 7), ("flops", C.c_double * 7), ("bytes", C.c_double * 7)]
 
 
 _P = C.c_void_p

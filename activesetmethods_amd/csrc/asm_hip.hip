@@ -218,6 +218,10 @@ struct Dev {
             MsB = Ms;
         }
         if (blocks <= 0) return;
+        // per-launch timing of the MFMA kernel itself (algorithmic flops: Ms*MsB*K over the stored triangle/rectangle)
+        double fl = (MsB == Ms && ntj == 0) ? (double)Ms * (Ms + 1) * K : 2.0 * ((double)Ms * MsB - 0.5 * (double)MsB * MsB) * K;
+        int kid = h->use_graphs ? -1 : begin(ASM_K_SYRK_KERNEL, fl, 8.0 * ((double)(Ms + MsB) * K + (double)Ms * MsB));
+        struct EndGuard { Dev* d; int id; ~EndGuard() { d->end(id); } } guard_{this, kid};
         if (T == 4)
             hipLaunchKernelGGL(k_syrk<4>, dim3((unsigned)blocks), dim3(256), 0, h->stream, A, ld, idx, row0, Ms, K, theta, diag, S,
                                ldS, srow0, mode, MsB, ntj);
