@@ -223,13 +223,13 @@ struct Dev {
         int kid = h->use_graphs ? -1 : begin(ASM_K_SYRK_KERNEL, fl, 8.0 * ((double)(Ms + MsB) * K + (double)Ms * MsB));
         struct EndGuard { Dev* d; int id; ~EndGuard() { d->end(id); } } guard_{this, kid};
         if (T == 4)
-            hipLaunchKernelGGL(k_syrk<4>, dim3((unsigned)blocks), dim3(256), 0, h->stream, A, ld, idx, row0, Ms, K, theta, diag, S,
+            hipLaunchKernelGGL((k_syrk<4, 8>), dim3((unsigned)blocks), dim3(512), 0, h->stream, A, ld, idx, row0, Ms, K, theta, diag, S,
                                ldS, srow0, mode, MsB, ntj);
         else if (T == 2)
-            hipLaunchKernelGGL(k_syrk<2>, dim3((unsigned)blocks), dim3(256), 0, h->stream, A, ld, idx, row0, Ms, K, theta, diag, S,
+            hipLaunchKernelGGL((k_syrk<2, 4>), dim3((unsigned)blocks), dim3(256), 0, h->stream, A, ld, idx, row0, Ms, K, theta, diag, S,
                                ldS, srow0, mode, MsB, ntj);
         else
-            hipLaunchKernelGGL(k_syrk<1>, dim3((unsigned)blocks), dim3(256), 0, h->stream, A, ld, idx, row0, Ms, K, theta, diag, S,
+            hipLaunchKernelGGL((k_syrk<1, 4>), dim3((unsigned)blocks), dim3(256), 0, h->stream, A, ld, idx, row0, Ms, K, theta, diag, S,
                                ldS, srow0, mode, MsB, ntj);
     }
 

@@ -146,8 +146,8 @@ __global__ __launch_bounds__(256) void k_gemv_t_stage2(const double* __restrict_
 // the four wavefronts form a 2x2 grid and each owns T x T MFMA tiles of 16x16.
 // v_mfma_f64_16x16x4_f64 operand maps (cdna_hip_programming.md:161): lane l holds A[i=l&15][k=l>>4] and
 // B[k=l>>4][j=l&15]; result register r of lane l is D[row=(l>>4)+4r][col=l&15].
-template <int T>
-__global__ __launch_bounds__(256) void k_syrk(const double* __restrict__ A, int64_t ld, const int* __restrict__ idx, int64_t row0,
+template <int T, int NW>
+__global__ __launch_bounds__(64 * NW) void k_syrk(const double* __restrict__ A, int64_t ld, const int* __restrict__ idx, int64_t row0,
                                               int Ms, int K, const double* __restrict__ theta, const double* __restrict__ diag,
                                               double* __restrict__ S, int64_t ldS, int64_t srow0, int mode, int MsB, int ntj) {
     constexpr int TS = 32 * T;
@@ -170,17 +170,21 @@ __global__ __launch_bounds__(256) void k_syrk(const double* __restrict__ A, int6
         bj = t - (int)((int64_t)bi * (bi + 1) / 2);
     }
 
+    // NW wavefronts as a 2 x (NW/2) grid; each owns TI x TJ MFMA tiles (NW = 8: two wavefronts per SIMD, so one
+    // can issue matrix instructions while the other waits at the barrier or on LDS)
+    constexpr int WCOLS = NW / 2;
+    constexpr int TI = TS / 32, TJ = TS / (16 * WCOLS);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wr = w >> 1, wc = w & 1;
-    v4f64 acc[T][T];
+    const int wr = w / WCOLS, wc = w % WCOLS;
+    v4f64 acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < T; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < T; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < TJ; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
 
     // staging assignment: TS rows x KC doubles per operand; each thread moves 2 doubles (16 B) per pass
     constexpr int PER_ROW = ASM_KC / 2;                 // threads per row
-    constexpr int ROWS_PER_PASS = 256 / PER_ROW;        // 32
+    constexpr int ROWS_PER_PASS = 64 * NW / PER_ROW;
     constexpr int PASSES = TS / ROWS_PER_PASS;          // = 2T
     const int lr = tid / PER_ROW, lk = (tid % PER_ROW) * 2;
     const double* arow[PASSES];
@@ -221,27 +225,27 @@ __global__ __launch_bounds__(256) void k_syrk(const double* __restrict__ A, int6
         if (c + 1 < nchunks) gload((c + 1) * ASM_KC);
 #pragma unroll
         for (int kk = 0; kk < ASM_KC; kk += 4) {
-            double af[T], bf[T];
+            double af[TI], bf[TJ];
 #pragma unroll
-            for (int i = 0; i < T; ++i) af[i] = As[st][(wr * 16 * T + i * 16 + (lane & 15)) * ASM_PITCH + kk + (lane >> 4)];
+            for (int i = 0; i < TI; ++i) af[i] = As[st][(wr * 16 * TI + i * 16 + (lane & 15)) * ASM_PITCH + kk + (lane >> 4)];
 #pragma unroll
-            for (int j = 0; j < T; ++j) bf[j] = Bs[st][(wc * 16 * T + j * 16 + (lane & 15)) * ASM_PITCH + kk + (lane >> 4)];
+            for (int j = 0; j < TJ; ++j) bf[j] = Bs[st][(wc * 16 * TJ + j * 16 + (lane & 15)) * ASM_PITCH + kk + (lane >> 4)];
 #pragma unroll
-            for (int i = 0; i < T; ++i)
+            for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < T; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
         if (c + 1 < nchunks) lstore(st ^ 1);
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < T; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < T; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                int row = bi * TS + wr * 16 * T + i * 16 + (lane >> 4) + 4 * r;
-                int col = bj * TS + wc * 16 * T + j * 16 + (lane & 15);
+                int row = bi * TS + wr * 16 * TI + i * 16 + (lane >> 4) + 4 * r;
+                int col = bj * TS + wc * 16 * TJ + j * 16 + (lane & 15);
                 if (row < Ms && col < MsB && col <= row) {
                     double* dst = S + (srow0 + row) * ldS + (srow0 + col);
                     double v = acc[i][j][r];
