@@ -300,6 +300,7 @@ __global__ __launch_bounds__(64) void k_potrf_diag(double* __restrict__ S, int64
     __shared__ double col[ASM_NB];
     const int r = threadIdx.x;
     double a[ASM_NB];
+    double my_inv = 1.0;
     // coalesced load through LDS, then row r -> registers
     for (int rr = 0; rr < ASM_NB; ++rr)
         D[rr * ASM_DP + r] = (rr < nb && r <= rr) ? S[(int64_t)(k0 + rr) * ldS + k0 + r] : (rr == r ? 1.0 : 0.0);
@@ -315,13 +316,13 @@ __global__ __launch_bounds__(64) void k_potrf_diag(double* __restrict__ S, int64
         double ljj = sqrt(d);
         double inv = 1.0 / ljj;
         double l = a[j] * inv;
-        if (r == j) l = ljj;
+        if (r == j) { l = ljj; my_inv = inv; }
         a[j] = l;
         col[r] = l;
         __syncthreads();
+        // no predicate: lanes r < c update entries of the (unused) upper triangle with harmless garbage
 #pragma unroll
-        for (int c = j + 1; c < ASM_NB; ++c)
-            if (c <= r) a[c] -= l * col[c];
+        for (int c = j + 1; c < ASM_NB; ++c) a[c] = fma(-l, col[c], a[c]);
         __syncthreads();
     }
     // write back (through LDS for coalescing) and keep L11 in LDS for the inversion
@@ -330,15 +331,23 @@ __global__ __launch_bounds__(64) void k_potrf_diag(double* __restrict__ S, int64
     __syncthreads();
     for (int rr = 0; rr < nb; ++rr)
         if (r <= rr && r < nb) S[(int64_t)(k0 + rr) * ldS + k0 + r] = D[rr * ASM_DP + r];
-    // inverse: lane c solves L x = e_c ; x kept in registers, L rows broadcast from LDS
+    col[r] = my_inv;                       // reciprocals of the diagonal for the inversion
+    __syncthreads();
+    // inverse: lane c solves L x = e_c ; x kept in registers, L rows broadcast from LDS; four independent partial
+    // sums break the dependent fma chain and the diagonal enters through its stored reciprocal
     double x[ASM_NB];
 #pragma unroll
     for (int rr = 0; rr < ASM_NB; ++rr) {
-        double sum = 0.0;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-        for (int q = 0; q < rr; ++q) sum = fma(D[rr * ASM_DP + q], x[q], sum);
+        for (int q = 0; q < rr; q += 4) {
+            s0 = fma(D[rr * ASM_DP + q], x[q], s0);
+            if (q + 1 < rr) s1 = fma(D[rr * ASM_DP + q + 1], x[q + 1], s1);
+            if (q + 2 < rr) s2 = fma(D[rr * ASM_DP + q + 2], x[q + 2], s2);
+            if (q + 3 < rr) s3 = fma(D[rr * ASM_DP + q + 3], x[q + 3], s3);
+        }
         double rhs = (rr == r) ? 1.0 : 0.0;
-        x[rr] = (rr < r) ? 0.0 : (rhs - sum) / D[rr * ASM_DP + rr];
+        x[rr] = (rr < r) ? 0.0 : (rhs - ((s0 + s1) + (s2 + s3))) * col[rr];
     }
     __syncthreads();
 #pragma unroll
