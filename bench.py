@@ -202,6 +202,13 @@ def main():
                     traffic=None, avg_launch_ms=d["ms"] / max(d["calls"], 1), launches=d["calls"])
 
     nfact = ks["chol"]["calls"]
+    # HBM bytes per launch of the dominant kernel from the committed PMC passes (cannot be collected inside bench)
+    tpath = os.path.join(ROOT, "profiles", "r01_%s_pmc_traffic.json" % args.workload)
+    if roof["bound"] == "mfma" and os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        roof["traffic"] = tj["traffic_bytes_per_launch"]
+        roof["traffic_source"] = "profiles/" + os.path.basename(tpath)
+        roof["algorithmic_bytes_per_launch"] = d["bytes"] / max(d["calls"], 1)
     if rank == 0:
         w = WORKLOADS[args.workload]
         out = {

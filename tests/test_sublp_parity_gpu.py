@@ -90,3 +90,65 @@ def test_c_abi_argument_errors(hip_lib):
     p = x.ctypes.data_as(C.POINTER(C.c_double))
     assert hip_lib.asm_sublp_solve_resident(h, 1.0, 0, p, p, p, p, p, C.byref(st)) == -3      # ASM_ERR_STATE: no setup
     hip_lib.asm_destroy(h)
+
+
+def _lp_properties(sp, out, opt, feasibility=False):
+    """Size-independent checks of an OPTIMAL sub-LP solution against the LP it solves (normal phase):
+    primal feasibility of rows and box, dual sign feasibility, stationarity df - J'lambda - mult = 0 on the
+    variables whose own bound (not the trust region) is active or that are free, complementarity, and
+    primal objective == dual objective."""
+    X, lam, mU, mL, ps, st = out
+    assert st == 1
+    n, m = sp['n'], sp['m']
+    J = np.zeros((m, n))
+    np.add.at(J, (sp['j_row'] - 1, sp['j_col'] - 1), sp['dE'])
+    lb = np.maximum(-sp['delta'], sp['v_lb'] - sp['x_k']); ub = np.minimum(sp['delta'], sp['v_ub'] - sp['x_k'])
+    act = sp['E'] + J @ X
+    scale = 1.0 + np.abs(act)
+    assert np.all(X >= lb - 1e-12) and np.all(X <= ub + 1e-12)
+    assert np.all(act <= sp['c_ub'] + 1e-8 * scale) and np.all(act >= sp['c_lb'] - 1e-8 * scale)
+    rows, bnd, sl = opt.active_set()
+    assert np.array_equal(X[bnd < 0], lb[bnd < 0]) and np.array_equal(X[bnd > 0], ub[bnd > 0])     # exactly on the bound
+    # reduced costs (before the trust-region zeroing of subproblem.jl:522-529)
+    z = sp['df'] - J.T @ lam
+    zs = max(1.0, np.abs(sp['df']).max())
+    free = bnd == 0
+    assert np.abs(z[free]).max(initial=0.0) <= 2e-6 * zs
+    assert np.all(z[bnd < 0] >= -2e-6 * zs) and np.all(z[bnd > 0] <= 2e-6 * zs)
+    ineq_lo = (sp['c_lb'] > -np.inf) & (sp['c_lb'] < sp['c_ub']); ineq_up = (sp['c_ub'] < np.inf) & (sp['c_lb'] < sp['c_ub'])
+    only_lo = ineq_lo & ~ineq_up; only_up = ineq_up & ~ineq_lo
+    assert np.all(lam[only_lo] >= 0) and np.all(lam[only_up] <= 0)
+    # complementarity and strong duality
+    gap_rows = np.where(lam > 0, act - sp['c_lb'], np.where(lam < 0, sp['c_ub'] - act, 0.0))
+    assert np.abs(gap_rows * lam).max(initial=0.0) <= 1e-7 * zs * scale.max()
+    primal = sp['df'] @ X
+    r_lo = sp['c_lb'] - sp['E']; r_up = sp['c_ub'] - sp['E']
+    dual = np.sum(np.where(lam > 0, lam * np.where(np.isfinite(r_lo), r_lo, 0.0), np.where(lam < 0, lam * np.where(np.isfinite(r_up), r_up, 0.0), 0.0)))
+    dual += np.sum(np.where(z > 0, z * lb, z * ub)[~free])
+    assert abs(primal - dual) <= 1e-6 * max(1.0, abs(primal))
+
+
+def test_full_size_c2_lp_properties():
+    """BASELINE.json configs[1] at full size (n=1000, m=500 dense): LP optimality certificates recomputed in NumPy."""
+    from activesetmethods_amd import problems
+    pr = problems.synthetic_dense_nlp(1000, 500)
+    x = pr.x0.copy()
+    sp = dict(n=pr.n, m=pr.m, j_row=pr.j_row, j_col=pr.j_col, dE=pr.eval_jac_g(x, np.zeros(pr.nnz)), df=pr.eval_grad_f(x, np.zeros(pr.n)),
+              f=pr.eval_f(x), E=pr.eval_g(x, np.zeros(pr.m)), x_k=x, c_lb=pr.g_L, c_ub=pr.g_U, v_lb=pr.x_L, v_ub=pr.x_U, delta=0.4)
+    opt, out = hip_solve(sp)
+    _lp_properties(sp, out, opt)
+    assert opt.last_stats()['polished'] == 1
+    opt.close()
+
+
+def test_full_size_c4_lp_properties():
+    """BASELINE.json configs[3] size (case1354pegase-sized synthetic ACOPF, 18637 x 11192): the oracle cannot run
+    this size in seconds, so the solution is checked through the LP's own optimality certificates."""
+    from activesetmethods_amd import acopf
+    pr = acopf.acopf_problem(acopf.synthetic_case("case1354pegase", 1), "c4")
+    x = pr.x0.copy()
+    sp = dict(n=pr.n, m=pr.m, j_row=pr.j_row, j_col=pr.j_col, dE=pr.eval_jac_g(x, np.zeros(pr.nnz)), df=pr.eval_grad_f(x, np.zeros(pr.n)),
+              f=pr.eval_f(x), E=pr.eval_g(x, np.zeros(pr.m)), x_k=x, c_lb=pr.g_L, c_ub=pr.g_U, v_lb=pr.x_L, v_ub=pr.x_U, delta=1000.0)
+    opt, out = hip_solve(sp)
+    _lp_properties(sp, out, opt)
+    opt.close()
