@@ -7,6 +7,7 @@
 // SYRK, the Cholesky factorisation and the triangular solves) runs on the GPU; the O(M+n) vector
 // algebra between them runs on the host and exchanges vectors through pinned staging buffers.
 #include "asm_kernels.hip.h"
+#include "asm_ipm_kernels.hip.h"
 #include "../../include/asm_hip.h"
 
 #include <algorithm>
@@ -93,6 +94,10 @@ struct asm_handle {
     double *d_vecN = nullptr, *d_vecM = nullptr, *d_vecM2 = nullptr, *d_part = nullptr, *d_partial = nullptr;
     double *d_Linv = nullptr, *d_tpart = nullptr;
     int64_t tpart_len = 0;
+    double* d_ipm = nullptr;        // arena of the device-resident interior-point state
+    int* d_ipm_i = nullptr;
+    int64_t nsp = 0;
+    double* h_scal = nullptr;       // pinned scalar read-back
     int* d_idx = nullptr;
     double* h_pin = nullptr;        // pinned staging (max(ldn, Mp) doubles) x 2
     int64_t pin_len = 0;
@@ -201,6 +206,35 @@ struct Dev {
                            h->d_vecN, R, h->ldn);
         end(id);
         d2h(out, h->d_vecN, h->n);
+    }
+
+    // device-pointer variants (the IPM keeps its vectors in HBM)
+    void gemv_n_dev(const double* A, const double* x, double* out) {
+        int id = begin(ASM_K_GEMV, 2.0 * h->M * h->n, 8.0 * h->M * h->ldn);
+        hipLaunchKernelGGL(k_gemv_n, dim3((unsigned)((h->M + 3) / 4)), dim3(256), 0, h->stream, A, h->ldn, x, out, h->M, h->ldn);
+        end(id);
+    }
+    void gemv_t_dev(const double* A, const double* y, double* out) {
+        int64_t R = std::min<int64_t>((h->M + 31) / 32, ASM_TMAXCHUNKS);
+        int64_t chunk = (h->M + R - 1) / R;
+        R = (h->M + chunk - 1) / chunk;
+        int id = begin(ASM_K_GEMV, 2.0 * h->M * h->n, 8.0 * h->M * h->ldn);
+        hipLaunchKernelGGL(k_gemv_t_stage1, dim3((unsigned)((h->ldn + 255) / 256), (unsigned)R), dim3(256), 0, h->stream, A, h->ldn, y,
+                           h->d_partial, h->M, h->ldn, chunk);
+        hipLaunchKernelGGL(k_gemv_t_stage2, dim3((unsigned)((h->ldn + 255) / 256)), dim3(256), 0, h->stream, h->d_partial, out, R, h->ldn);
+        end(id);
+    }
+    void syrk_dev(const int* idx_dev, int Ms, const double* theta_dev, const double* diag_dev) {
+        int id = begin(ASM_K_SYRK, (double)Ms * (Ms + 1) * h->ldn, 8.0 * (Ms * (double)h->ldn + 0.5 * Ms * (double)Ms));
+        launch_syrk(pick_tile(Ms), h->d_Ah, h->ldn, idx_dev, 0, Ms, (int)h->ldn, theta_dev, diag_dev, h->d_S, h->Mp, 0, 0);
+        end(id);
+    }
+    void chol_solve_dev(const double* rhs_dev, double* out_dev, int Ms) {
+        HIPCHK(hipMemcpyAsync(h->d_vecM2, rhs_dev, Ms * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        int id = begin(ASM_K_TRSV, 2.0 * Ms * (double)Ms, 8.0 * Ms * (double)Ms);
+        run_sequence(3, Ms, Ms == (int)h->M, [&] { solve_launches(Ms); });
+        end(id);
+        HIPCHK(hipMemcpyAsync(out_dev, h->d_vecM2, Ms * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     }
 
     static int pick_tile(int64_t Ms) { return Ms >= 3072 ? 4 : (Ms >= 768 ? 2 : 1); }
@@ -413,80 +447,96 @@ struct Solver {
         bool stalled = false;
         int iters = 0;
         int status = ASM_OTHER;
-        double mu = 0, pinf = 0, dinf = 0, gap = 0;
+        double mu = 0, pinf = 0, dinf = 0, gap = 0, ymax = 0;
     } ip;
 
+    // ---- device-resident IPM state (asm_ipm_kernels.hip.h) ---------------------------------------------------
+    IpmPtrs P;
+    IpmDir dirA, dirC;
+    double *d_sres = nullptr, *d_corr = nullptr, *d_tN = nullptr;
+
+    void ipm_bind() {
+        double* a = h->d_ipm;
+        const int64_t ln = h->ldn, lm = h->Mp, ls = h->nsp;
+        auto N = [&]() { double* r_ = a; a += ln; return r_; };
+        auto Mv = [&]() { double* r_ = a; a += lm; return r_; };
+        auto Sv = [&]() { double* r_ = a; a += ls; return r_; };
+        double *q = N(), *lb = N(), *ub = N();
+        P.q = q; P.lb = lb; P.ub = ub;
+        P.p = N(); P.tL = N(); P.tU = N(); P.muL = N(); P.muU = N(); P.aty = N(); P.rdp = N(); P.thp_inv = N();
+        P.hp = N(); P.tmpn = N(); P.rcL = N(); P.rcU = N();
+        dirA.dp = N(); dirA.dmuL = N(); dirA.dmuU = N(); dirC.dp = N(); dirC.dmuL = N(); dirC.dmuU = N();
+        d_tN = N();
+        double* r = Mv();
+        P.r = r;
+        P.g = Mv(); P.y = Mv(); P.pi = Mv(); P.act = Mv(); P.rp = Mv(); P.dS = Mv(); P.t1 = Mv(); P.rhs = Mv(); P.res = Mv(); P.rcg = Mv();
+        dirA.dg = Mv(); dirA.dy = Mv(); dirA.dpi = Mv(); dirC.dg = Mv(); dirC.dy = Mv(); dirC.dpi = Mv();
+        d_sres = Mv(); d_corr = Mv();
+        double *w = Sv(), *slo = Sv(), *scoef = Sv();
+        P.w = w; P.slo = slo; P.scoef = scoef;
+        P.s = Sv(); P.ts = Sv(); P.mus = Sv(); P.rds = Sv(); P.ths_inv = Sv(); P.hs = Sv(); P.rcs = Sv();
+        dirA.ds = Sv(); dirA.dmus = Sv(); dirC.ds = Sv(); dirC.dmus = Sv();
+        P.scal = a;
+        P.rtype = h->d_ipm_i; P.rs0 = h->d_ipm_i + lm; P.rs1 = h->d_ipm_i + 2 * lm; P.srow = h->d_ipm_i + 3 * lm;
+    }
+    void up(const double* dst, const vec& v) {
+        if (!v.empty()) HIPCHK(hipMemcpyAsync((void*)dst, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    void down(vec& v, const double* src, int64_t cnt) {
+        v.resize(cnt);
+        if (cnt) HIPCHK(hipMemcpyAsync(v.data(), src, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    // push the (scaled) LP data of `lp` to the device
+    void ipm_upload_lp() {
+        ipm_bind();
+        P.n = lp.n; P.M = lp.M; P.ns = lp.ns; P.scale_q = lp.scale_q;
+        up(P.q, lp.q); up(P.lb, lp.lb); up(P.ub, lp.ub); up(P.r, lp.r);
+        up(P.w, lp.w); up(P.slo, lp.slo);
+        vec sc(h->scoef.begin(), h->scoef.begin() + lp.ns);
+        up(P.scoef, sc);
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    unsigned grid_all() const { return (unsigned)((std::max(std::max(lp.n, lp.M), std::max<int64_t>(lp.ns, 1)) + 255) / 256); }
+    void read_scal() {
+        HIPCHK(hipMemcpyAsync(h->h_scal, P.scal, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+
     void ipm_init() {
-        const int64_t n = lp.n, M = lp.M, ns = lp.ns;
-        ip = IpmState();
-        ip.ineq.resize(M);
-        ip.sg.resize(M);
-        ip.free_.resize(n);
+        const int64_t n = lp.n, M = lp.M;
+        IpmState fresh;
+        ip = fresh;
         int64_t nfree = 0, nineq = 0;
-        for (int64_t i = 0; i < M; ++i) {
-            ip.ineq[i] = lp.rtype[i] != 0;
-            ip.sg[i] = (double)lp.rtype[i];
-            nineq += ip.ineq[i];
-        }
-        for (int64_t j = 0; j < n; ++j) {
-            ip.free_[j] = lp.ub[j] > lp.lb[j];
-            nfree += ip.free_[j];
-        }
-        ip.p.resize(n);
-        for (int64_t j = 0; j < n; ++j) ip.p[j] = 0.5 * (lp.lb[j] + lp.ub[j]);
-        ip.s.resize(ns);
-        for (int64_t k = 0; k < ns; ++k) ip.s[k] = lp.slo[k] + 1.0;
-        vec act;
-        rowact(ip.p, ip.s, act);
-        ip.g.resize(M);
-        for (int64_t i = 0; i < M; ++i) ip.g[i] = ip.ineq[i] ? std::max(ip.sg[i] * (act[i] - lp.r[i]), 1.0) : 1.0;
-        double mu0 = lp.scale_q;
-        ip.tL.resize(n); ip.tU.resize(n); ip.muL.resize(n); ip.muU.resize(n);
-        for (int64_t j = 0; j < n; ++j) {
-            ip.tL[j] = ip.free_[j] ? ip.p[j] - lp.lb[j] : 1.0;
-            ip.tU[j] = ip.free_[j] ? lp.ub[j] - ip.p[j] : 1.0;
-            ip.muL[j] = ip.free_[j] ? mu0 / ip.tL[j] : 0.0;
-            ip.muU[j] = ip.free_[j] ? mu0 / ip.tU[j] : 0.0;
-        }
-        ip.ts.resize(ns); ip.mus.resize(ns);
-        for (int64_t k = 0; k < ns; ++k) {
-            ip.ts[k] = ip.s[k] - lp.slo[k];
-            ip.mus[k] = mu0 / ip.ts[k];
-        }
-        ip.pi.resize(M); ip.y.resize(M);
-        for (int64_t i = 0; i < M; ++i) {
-            ip.pi[i] = ip.ineq[i] ? mu0 / ip.g[i] : 0.0;
-            ip.y[i] = ip.sg[i] * ip.pi[i];
-        }
-        ip.ncomp = std::max<int64_t>(2 * nfree + ns + nineq, 1);
+        for (int64_t i = 0; i < M; ++i) nineq += lp.rtype[i] != 0;
+        for (int64_t j = 0; j < n; ++j) nfree += lp.ub[j] > lp.lb[j];
+        ip.ncomp = std::max<int64_t>(2 * nfree + lp.ns + nineq, 1);
+        ipm_upload_lp();
+        P.ncomp = ip.ncomp;
+        hipLaunchKernelGGL(k_ipm_init_p, dim3(grid_all()), dim3(256), 0, h->stream, P);
+        dev.gemv_n_dev(h->d_Ah, P.p, P.act);
+        hipLaunchKernelGGL(k_ipm_init_rest, dim3(grid_all()), dim3(256), 0, h->stream, P);
     }
 
     void ipm_measures() {
-        const int64_t n = lp.n, M = lp.M, ns = lp.ns;
-        vec act, aty;
-        rowact(ip.p, ip.s, act);
-        atv(ip.y, aty);
-        ip.rp.resize(M); ip.rdp.resize(n); ip.rds.resize(ns);
-        double pinf = 0.0, dinf = 0.0, mu = 0.0;
-        for (int64_t i = 0; i < M; ++i) {
-            ip.rp[i] = act[i] - (lp.r[i] + ip.sg[i] * (ip.ineq[i] ? ip.g[i] : 0.0));
-            pinf = std::max(pinf, std::fabs(ip.rp[i]) / (1.0 + std::fabs(lp.r[i])));
-            if (ip.ineq[i]) mu += ip.g[i] * ip.pi[i];
-        }
-        for (int64_t j = 0; j < n; ++j) {
-            ip.rdp[j] = ip.free_[j] ? lp.q[j] - aty[j] - ip.muL[j] + ip.muU[j] : 0.0;
-            dinf = std::max(dinf, std::fabs(ip.rdp[j]));
-            if (ip.free_[j]) mu += ip.tL[j] * ip.muL[j] + ip.tU[j] * ip.muU[j];
-        }
-        for (int64_t k = 0; k < ns; ++k) {
-            ip.rds[k] = lp.w[k] - lp.scoef[k] * ip.y[lp.srow[k]] - ip.mus[k];
-            dinf = std::max(dinf, std::fabs(ip.rds[k]));
-            mu += ip.ts[k] * ip.mus[k];
-        }
-        ip.mu = mu / (double)ip.ncomp;
-        ip.pinf = pinf;
-        ip.dinf = dinf / lp.scale_q;
+        dev.gemv_n_dev(h->d_Ah, P.p, P.act);
+        dev.gemv_t_dev(h->d_Ah, P.y, P.aty);
+        hipLaunchKernelGGL(k_ipm_measures, dim3(1), dim3(1024), 0, h->stream, P);
+        read_scal();
+        ip.pinf = h->h_scal[SC_PINF];
+        ip.dinf = h->h_scal[SC_DINF];
+        ip.mu = h->h_scal[SC_MU];
         ip.gap = ip.mu / lp.scale_q;
+        ip.ymax = h->h_scal[SC_YMAX];
+    }
+
+    // pull the iterate back to the host (identification, certificates, unpolished fallback)
+    void ipm_download() {
+        down(ip.p, P.p, lp.n); down(ip.tL, P.tL, lp.n); down(ip.tU, P.tU, lp.n); down(ip.muL, P.muL, lp.n); down(ip.muU, P.muU, lp.n);
+        down(ip.g, P.g, lp.M); down(ip.pi, P.pi, lp.M); down(ip.y, P.y, lp.M);
+        down(ip.s, P.s, lp.ns); down(ip.ts, P.ts, lp.ns); down(ip.mus, P.mus, lp.ns);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        ip.free_.resize(lp.n);
+        for (int64_t j = 0; j < lp.n; ++j) ip.free_[j] = lp.ub[j] > lp.lb[j];
     }
 
     // rigorous primal-infeasibility certificate test (oracle: farkas_margin)
@@ -510,98 +560,38 @@ struct Solver {
         return ynr - lhs;
     }
 
-    static double maxstep(const vec& x, const vec& dx, const std::vector<char>* mask, double sign = 1.0) {
-        double a = 1.0;
-        bool any = false;
-        for (size_t i = 0; i < x.size(); ++i) {
-            if (mask && !(*mask)[i]) continue;
-            double d = sign * dx[i];
-            if (d < 0) {
-                double v = -x[i] / d;
-                if (!any || v < a) a = v;
-                any = true;
-            }
+    // one Newton solve with the current factor (oracle: IPM.run.solve); mode 0 affine, 1 corrector
+    void ipm_solve(int mode, IpmDir& D) {
+        const unsigned g = grid_all();
+        const int M = (int)lp.M;
+        hipLaunchKernelGGL(k_ipm_rhs1, dim3(g), dim3(256), 0, h->stream, P, dirA, mode);
+        dev.gemv_n_dev(h->d_Ah, P.tmpn, P.t1);
+        hipLaunchKernelGGL(k_ipm_rhs2, dim3(g), dim3(256), 0, h->stream, P);
+        dev.chol_solve_dev(P.rhs, D.dy, M);
+        for (int it = 0; it < 2; ++it) {      // adaptive iterative refinement on the unregularised Schur system
+            dev.gemv_t_dev(h->d_Ah, D.dy, d_tN);
+            hipLaunchKernelGGL(k_vec_mul, dim3((unsigned)((lp.n + 255) / 256)), dim3(256), 0, h->stream, d_tN, P.thp_inv, lp.n);
+            dev.gemv_n_dev(h->d_Ah, d_tN, d_sres);
+            hipLaunchKernelGGL(k_ipm_res, dim3(1), dim3(1024), 0, h->stream, P, d_sres, D.dy);
+            read_scal();
+            if (h->h_scal[SC_EMAX] <= 1e-10 * h->h_scal[SC_RMAX]) break;
+            dev.chol_solve_dev(P.res, d_corr, M);
+            hipLaunchKernelGGL(k_vec_add, dim3((unsigned)((lp.M + 255) / 256)), dim3(256), 0, h->stream, D.dy, d_corr, lp.M);
         }
-        return any ? std::min(1.0, a) : 1.0;
-    }
-
-    struct Dir {
-        vec dp, ds, dg, dy, dmuL, dmuU, dmus, dpi;
-    };
-
-    // one Newton solve with the current factor (oracle: IPM.run.solve)
-    void ipm_solve(const vec& thp_inv, const vec& ths_inv, const vec& dS, const vec& rcL, const vec& rcU, const vec& rcs, const vec& rcg, Dir& d) {
-        const int64_t n = lp.n, M = lp.M, ns = lp.ns;
-        vec hp(n), hs(ns), tmp(n), rhs(M), t2;
-        for (int64_t j = 0; j < n; ++j) {
-            hp[j] = ip.free_[j] ? -ip.rdp[j] + rcL[j] / ip.tL[j] - rcU[j] / ip.tU[j] : 0.0;
-            tmp[j] = thp_inv[j] * hp[j];
-        }
-        for (int64_t k = 0; k < ns; ++k) hs[k] = -ip.rds[k] + rcs[k] / ip.ts[k];
-        dev.gemv_n(h->d_Ah, tmp.data(), rhs.data());
-        for (int64_t i = 0; i < M; ++i)
-            rhs[i] = -ip.rp[i] - rhs[i] + (ip.ineq[i] ? ip.sg[i] * rcg[i] / ip.pi[i] : 0.0);
-        if (ns) {
-            vec acc(M, 0.0);
-            for (int64_t k = 0; k < ns; ++k) acc[lp.srow[k]] += lp.scoef[k] * ths_inv[k] * hs[k];
-            for (int64_t i = 0; i < M; ++i) rhs[i] -= acc[i];
-        }
-        d.dy.resize(M);
-        dev.chol_solve(rhs.data(), d.dy.data(), (int)M);
-        {   // adaptive iterative refinement on the unregularised Schur system (oracle: IPM.run.solve)
-            double rmax = 1.0;
-            for (double v : rhs) rmax = std::max(rmax, std::fabs(v));
-            vec res(M), sres(M), corr(M);
-            for (int it = 0; it < 2; ++it) {
-                atv(d.dy, t2);
-                for (int64_t j = 0; j < n; ++j) t2[j] *= thp_inv[j];
-                dev.gemv_n(h->d_Ah, t2.data(), sres.data());
-                double emax = 0.0;
-                for (int64_t i = 0; i < M; ++i) {
-                    res[i] = rhs[i] - (sres[i] + dS[i] * d.dy[i]);
-                    emax = std::max(emax, std::fabs(res[i]));
-                }
-                if (emax <= 1e-10 * rmax) break;
-                dev.chol_solve(res.data(), corr.data(), (int)M);
-                for (int64_t i = 0; i < M; ++i) d.dy[i] += corr[i];
-            }
-        }
-        atv(d.dy, t2);
-        d.dp.resize(n); d.dmuL.resize(n); d.dmuU.resize(n);
-        for (int64_t j = 0; j < n; ++j) {
-            d.dp[j] = thp_inv[j] * (hp[j] + t2[j]);
-            d.dmuL[j] = ip.free_[j] ? (rcL[j] - ip.muL[j] * d.dp[j]) / ip.tL[j] : 0.0;
-            d.dmuU[j] = ip.free_[j] ? (rcU[j] + ip.muU[j] * d.dp[j]) / ip.tU[j] : 0.0;
-        }
-        d.ds.resize(ns); d.dmus.resize(ns);
-        for (int64_t k = 0; k < ns; ++k) {
-            d.ds[k] = ths_inv[k] * (hs[k] + lp.scoef[k] * d.dy[lp.srow[k]]);
-            d.dmus[k] = (rcs[k] - ip.mus[k] * d.ds[k]) / ip.ts[k];
-        }
-        d.dpi.resize(M); d.dg.resize(M);
-        for (int64_t i = 0; i < M; ++i) {
-            d.dpi[i] = ip.ineq[i] ? ip.sg[i] * d.dy[i] : 0.0;
-            d.dg[i] = ip.ineq[i] ? (rcg[i] - ip.g[i] * d.dpi[i]) / ip.pi[i] : 0.0;
-        }
-    }
-
-    void steps(const Dir& d, double& ap, double& ad) {
-        ap = std::min(std::min(maxstep(ip.tL, d.dp, &ip.free_), maxstep(ip.tU, d.dp, &ip.free_, -1.0)),
-                      std::min(maxstep(ip.ts, d.ds, nullptr), maxstep(ip.g, d.dg, &ip.ineq)));
-        ad = std::min(std::min(maxstep(ip.muL, d.dmuL, &ip.free_), maxstep(ip.muU, d.dmuU, &ip.free_)),
-                      std::min(maxstep(ip.mus, d.dmus, nullptr), maxstep(ip.pi, d.dpi, &ip.ineq)));
+        dev.gemv_t_dev(h->d_Ah, D.dy, d_tN);
+        hipLaunchKernelGGL(k_ipm_dir, dim3(g), dim3(256), 0, h->stream, P, D, d_tN);
     }
 
     int ipm_run(double tol, int max_more) {
-        const int64_t n = lp.n, M = lp.M, ns = lp.ns;
+        const int M = (int)lp.M;
         int done = 0;
         while (true) {
             ipm_measures();
             if (h->verbose) std::fprintf(stderr, "[asm] ipm %3d pinf %.3e dinf %.3e gap %.3e\n", ip.iters, ip.pinf, ip.dinf, ip.gap);
             if (ip.pinf <= tol && ip.dinf <= tol && ip.gap <= tol) return ip.status = ASM_OPTIMAL;
-            double ymax = 0.0;
-            for (double v : ip.y) ymax = std::max(ymax, std::fabs(v));
-            if (ip.iters >= 3 && ymax > 1e3 * lp.scale_q) {
+            if (ip.iters >= 3 && ip.ymax > 1e3 * lp.scale_q) {
+                down(ip.y, P.y, lp.M);
+                HIPCHK(hipStreamSynchronize(h->stream));
                 if (farkas_margin(ip.y) > 1e-9) return ip.status = ASM_INFEASIBLE;
             }
             if (done >= max_more) return ip.status = ASM_OTHER;
@@ -611,80 +601,18 @@ struct Solver {
                 ip.stalled = true;
                 return ip.status = ASM_OTHER;
             }
-            vec thp_inv(n), ths_inv(ns), dS(M);
-            for (int64_t j = 0; j < n; ++j)
-                thp_inv[j] = ip.free_[j] ? 1.0 / (ip.muL[j] / ip.tL[j] + ip.muU[j] / ip.tU[j] + IPM_RHO_P) : 0.0;
-            for (int64_t k = 0; k < ns; ++k) ths_inv[k] = ip.ts[k] / ip.mus[k];
-            for (int64_t i = 0; i < M; ++i) dS[i] = ip.ineq[i] ? ip.g[i] / ip.pi[i] : 0.0;
-            for (int64_t k = 0; k < ns; ++k) dS[lp.srow[k]] += ths_inv[k];
-            dev.syrk(nullptr, (int)M, thp_inv.data(), dS.data());
-            dev.diag_prepare((int)M, 0, 1e-13, 1e-30);
-            dev.chol((int)M);
+            hipLaunchKernelGGL(k_ipm_theta, dim3(grid_all()), dim3(256), 0, h->stream, P, IPM_RHO_P);
+            dev.syrk_dev(nullptr, M, P.thp_inv, P.dS);
+            dev.diag_prepare(M, 0, 1e-13, 1e-30);
+            dev.chol(M);
             ip.iters += 1;
             done += 1;
-            if (h->verbose) {
-                HIPCHK(hipStreamSynchronize(h->stream));
-                int ndrop = 0, first[4] = {-1, -1, -1, -1};
-                double dmin = 1e300, dmax = 0;
-                for (int64_t i = 0; i < M; ++i) {
-                    double lii;
-                    HIPCHK(hipMemcpy(&lii, h->d_S + i * h->Mp + i, sizeof(double), hipMemcpyDeviceToHost));
-                    if (lii > 1e100) { if (ndrop < 4) first[ndrop] = (int)i; ++ndrop; }
-                    else { dmin = std::min(dmin, lii); dmax = std::max(dmax, lii); }
-                }
-                int worst = 0;
-                for (int64_t i = 0; i < M; ++i) if (std::fabs(ip.rp[i]) / (1 + std::fabs(lp.r[i])) > std::fabs(ip.rp[worst]) / (1 + std::fabs(lp.r[worst]))) worst = (int)i;
-                std::fprintf(stderr, "[asm]     chol: dropped %d rows (first %d %d %d %d), Lii range %.3e .. %.3e ; worst rp row %d (type %d, r %.3e, rp %.3e, dS %.3e)\n",
-                             ndrop, first[0], first[1], first[2], first[3], dmin, dmax, worst, lp.rtype[worst], lp.r[worst], ip.rp[worst], dS[worst]);
-            }
-
-            vec rcL(n), rcU(n), rcs(ns), rcg(M);
-            for (int64_t j = 0; j < n; ++j) { rcL[j] = -ip.tL[j] * ip.muL[j]; rcU[j] = -ip.tU[j] * ip.muU[j]; }
-            for (int64_t k = 0; k < ns; ++k) rcs[k] = -ip.ts[k] * ip.mus[k];
-            for (int64_t i = 0; i < M; ++i) rcg[i] = -ip.g[i] * ip.pi[i];
-            Dir a;
-            ipm_solve(thp_inv, ths_inv, dS, rcL, rcU, rcs, rcg, a);
-            double ap, ad;
-            steps(a, ap, ad);
-            double mu_aff = 0.0;
-            for (int64_t j = 0; j < n; ++j)
-                if (ip.free_[j])
-                    mu_aff += (ip.tL[j] + ap * a.dp[j]) * (ip.muL[j] + ad * a.dmuL[j]) +
-                              (ip.tU[j] - ap * a.dp[j]) * (ip.muU[j] + ad * a.dmuU[j]);
-            for (int64_t k = 0; k < ns; ++k) mu_aff += (ip.ts[k] + ap * a.ds[k]) * (ip.mus[k] + ad * a.dmus[k]);
-            for (int64_t i = 0; i < M; ++i)
-                if (ip.ineq[i]) mu_aff += (ip.g[i] + ap * a.dg[i]) * (ip.pi[i] + ad * a.dpi[i]);
-            mu_aff /= (double)ip.ncomp;
-            double sig = ip.mu > 0 ? std::pow(mu_aff / ip.mu, 3.0) : 0.0;
-            double sm = sig * ip.mu;
-            for (int64_t j = 0; j < n; ++j) {
-                rcL[j] = sm - ip.tL[j] * ip.muL[j] - a.dp[j] * a.dmuL[j];
-                rcU[j] = sm - ip.tU[j] * ip.muU[j] + a.dp[j] * a.dmuU[j];
-            }
-            for (int64_t k = 0; k < ns; ++k) rcs[k] = sm - ip.ts[k] * ip.mus[k] - a.ds[k] * a.dmus[k];
-            for (int64_t i = 0; i < M; ++i) rcg[i] = sm - ip.g[i] * ip.pi[i] - a.dg[i] * a.dpi[i];
-            Dir c;
-            ipm_solve(thp_inv, ths_inv, dS, rcL, rcU, rcs, rcg, c);
-            double eta = ip.mu >= 1.0 ? 0.995 : std::min(std::max(0.995, 1.0 - ip.mu / lp.scale_q), 0.999999);
-            steps(c, ap, ad);
-            double al = std::min(1.0, eta * std::min(ap, ad));
-            for (int64_t j = 0; j < n; ++j) {
-                ip.p[j] += al * c.dp[j];
-                ip.tL[j] = ip.free_[j] ? ip.tL[j] + al * c.dp[j] : 1.0;
-                ip.tU[j] = ip.free_[j] ? ip.tU[j] - al * c.dp[j] : 1.0;
-                ip.muL[j] += al * c.dmuL[j];
-                ip.muU[j] += al * c.dmuU[j];
-            }
-            for (int64_t k = 0; k < ns; ++k) {
-                ip.s[k] += al * c.ds[k];
-                ip.ts[k] += al * c.ds[k];
-                ip.mus[k] += al * c.dmus[k];
-            }
-            for (int64_t i = 0; i < M; ++i) {
-                ip.g[i] = ip.ineq[i] ? ip.g[i] + al * c.dg[i] : 1.0;
-                ip.pi[i] += al * c.dpi[i];
-                ip.y[i] = ip.ineq[i] ? ip.sg[i] * ip.pi[i] : ip.y[i] + al * c.dy[i];
-            }
+            ipm_solve(0, dirA);
+            hipLaunchKernelGGL(k_ipm_steps, dim3(1), dim3(1024), 0, h->stream, P, dirA, 0);
+            hipLaunchKernelGGL(k_ipm_muaff, dim3(1), dim3(1024), 0, h->stream, P, dirA);
+            ipm_solve(1, dirC);
+            hipLaunchKernelGGL(k_ipm_steps, dim3(1), dim3(1024), 0, h->stream, P, dirC, 1);
+            hipLaunchKernelGGL(k_ipm_update, dim3(grid_all()), dim3(256), 0, h->stream, P, dirC);
         }
     }
 
@@ -885,23 +813,36 @@ struct Solver {
         lp.scale_q = 1.0;
         ipm_init();
         ipm_run(1e-8, IPM_MAXIT);
-        vec y1 = ip.y;
+        vec y1;
+        down(y1, P.y, lp.M);
+        HIPCHK(hipStreamSynchronize(h->stream));
         int its = ip.iters;
         lp = saved;
         ip = saved_ip;
+        ipm_upload_lp();              // the original LP again (the interrupted iterate is not resumed after phase 1)
         h->stats.ipm_iters += its;
         return farkas_margin(y1) > 1e-9;
     }
 
     // oracle: solve_scaled
+    double t_warm = 0, t_ipm = 0, t_polish = 0;
+    static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     int solve_scaled(const ActiveSet* warm, EqpOut& o, ActiveSet& out_as) {
+        int st = solve_scaled_impl(warm, o, out_as);
+        if (h->verbose) std::fprintf(stderr, "[asm] phases: warm %.2f ms, ipm %.2f ms (%d its), polish %.2f ms\n", t_warm, t_ipm, ip.iters, t_polish);
+        return st;
+    }
+    int solve_scaled_impl(const ActiveSet* warm, EqpOut& o, ActiveSet& out_as) {
         const int64_t n = lp.n, M = lp.M, ns = lp.ns;
         vec zero_p(n), zero_y(M, 0.0);
         for (int64_t j = 0; j < n; ++j) zero_p[j] = std::min(std::max(0.0, lp.lb[j]), lp.ub[j]);
         h->stats.path = -1;
         h->stats.polished = 1;
         if (warm && warm->valid && (int64_t)warm->rowst.size() == M && (int64_t)warm->bst.size() == n && (int64_t)warm->sst.size() == ns) {
-            if (eqp_loop(*warm, zero_p, zero_y, 1, o, out_as)) { h->stats.path = 0; return ASM_OPTIMAL; }
+            double t0 = now_ms();
+            bool okw = eqp_loop(*warm, zero_p, zero_y, 1, o, out_as);
+            t_warm += now_ms() - t0;
+            if (okw) { h->stats.path = 0; return ASM_OPTIMAL; }
         }
         ipm_init();
         const double tols[3] = {1e-8, 1e-10, 1e-12};
@@ -909,7 +850,9 @@ struct Solver {
         ActiveSet sets0;
         bool have_sets = false;
         for (int stage = 0; stage < 3; ++stage) {
+            double t0 = now_ms();
             int st = ipm_run(tols[stage], more[stage]);
+            t_ipm += now_ms() - t0;
             h->stats.ipm_iters = ip.iters;
             h->stats.ipm_pinf = ip.pinf; h->stats.ipm_dinf = ip.dinf; h->stats.ipm_gap = ip.gap;
             if (st == ASM_INFEASIBLE) { h->stats.path = 6; return ASM_INFEASIBLE; }
@@ -917,6 +860,7 @@ struct Solver {
                 // the IPM is only the identifier: a jammed / slow run that is already close is still handed to
                 // the active-set solve, whose LP optimality test decides (oracle: solve_scaled)
                 if (ip.pinf <= 1e-3 && ip.dinf <= 1e-3 && ip.gap <= 1e-4) {
+                    ipm_download();
                     identify(sets0);
                     have_sets = true;
                     if (eqp_loop(sets0, zero_p, zero_y, 3, o, out_as)) { h->stats.path = 8; return ASM_OPTIMAL; }
@@ -924,9 +868,13 @@ struct Solver {
                 if (lp.ns == 0 && phase1_infeasible()) { h->stats.path = 7; return ASM_INFEASIBLE; }
                 break;
             }
+            double t1 = now_ms();
+            ipm_download();
             identify(sets0);
             have_sets = true;
-            if (eqp_loop(sets0, zero_p, zero_y, 2, o, out_as)) { h->stats.path = 1 + stage; return ASM_OPTIMAL; }
+            bool okp = eqp_loop(sets0, zero_p, zero_y, 2, o, out_as);
+            t_polish += now_ms() - t1;
+            if (okp) { h->stats.path = 1 + stage; return ASM_OPTIMAL; }
         }
         if (have_sets) {
             vec pc(n);
@@ -935,6 +883,7 @@ struct Solver {
         }
         h->stats.path = 5;
         h->stats.polished = 0;
+        ipm_download();
         if (!have_sets) identify(sets0);
         out_as = sets0;
         o.p.resize(n); o.s.resize(ns); o.y = ip.y;
@@ -965,7 +914,9 @@ void free_device(asm_handle* h) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(h->d_perm); F(h->d_ustart); F(h->d_uoff); F(h->d_adjoff);
     F(h->d_dE); F(h->d_J); F(h->d_Ah); F(h->d_S); F(h->d_c); F(h->d_rho); F(h->d_theta); F(h->d_diag); F(h->d_diag0);
-    F(h->d_vecN); F(h->d_vecM); F(h->d_vecM2); F(h->d_part); F(h->d_partial); F(h->d_idx); F(h->d_Linv); F(h->d_tpart);
+    F(h->d_vecN); F(h->d_vecM); F(h->d_vecM2); F(h->d_part); F(h->d_partial); F(h->d_idx); F(h->d_Linv); F(h->d_tpart); F(h->d_ipm); F(h->d_ipm_i);
+    if (h->h_scal) (void)hipHostFree(h->h_scal);
+    h->d_ipm = nullptr; h->d_ipm_i = nullptr; h->h_scal = nullptr;
     if (h->h_pin) (void)hipHostFree(h->h_pin);
     h->d_perm = h->d_ustart = h->d_uoff = h->d_adjoff = nullptr;
     h->d_dE = h->d_J = h->d_Ah = h->d_S = h->d_c = h->d_rho = h->d_theta = h->d_diag = h->d_diag0 = nullptr;
@@ -1058,7 +1009,23 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     dmalloc(&h->d_Linv, (h->Mp / ASM_NB + 1) * ASM_NB * ASM_NB);
     h->tpart_len = (h->Mp / ASM_TRSV_ROWS + 2) * ASM_NB;
     dmalloc(&h->d_tpart, 2 * h->tpart_len);
-    h->pin_len = std::max(h->ldn, h->Mp);
+    h->nsp = round_up(std::max<int64_t>(h->ns, 1), 16);
+    {
+        int64_t nd = 24 * h->ldn + 22 * h->Mp + 16 * h->nsp + 64;
+        dmalloc(&h->d_ipm, nd);
+        HIPCHK(hipMemsetAsync(h->d_ipm, 0, nd * sizeof(double), h->stream));
+        dmalloc(&h->d_ipm_i, 3 * h->Mp + h->nsp);
+        std::vector<int> iv(3 * h->Mp + h->nsp, -1);
+        for (int64_t i = 0; i < h->M; ++i) iv[i] = h->rtype[i];
+        for (int64_t k = 0; k < h->ns; ++k) {
+            int r_ = h->srow[k];
+            if (iv[h->Mp + r_] < 0) iv[h->Mp + r_] = (int)k; else iv[2 * h->Mp + r_] = (int)k;
+            iv[3 * h->Mp + k] = r_;
+        }
+        HIPCHK(hipMemcpy(h->d_ipm_i, iv.data(), iv.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipHostMalloc((void**)&h->h_scal, 64 * sizeof(double)));
+    }
+    h->pin_len = std::max(std::max(h->ldn, h->Mp), h->nsp);
     HIPCHK(hipHostMalloc((void**)&h->h_pin, 2 * h->pin_len * sizeof(double)));
     HIPCHK(hipMemsetAsync(h->d_J, 0, h->Mp * h->ldn * sizeof(double), h->stream));
     HIPCHK(hipMemsetAsync(h->d_Ah, 0, h->Mp * h->ldn * sizeof(double), h->stream));

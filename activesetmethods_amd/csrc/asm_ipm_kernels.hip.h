@@ -1,0 +1,341 @@
+// Device-resident interior-point iteration (oracle/lp_solver.py: class IPM).  All O(M+n) state lives in HBM; the
+// host only sequences launches and reads back a handful of scalars per iteration.  Reductions run in a single
+// 1024-thread workgroup with a fixed tree, so every scalar is deterministic.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct IpmPtrs {
+    // problem data (scaled LP)
+    const double *q, *lb, *ub, *r, *w, *slo, *scoef;
+    const int *rtype, *srow, *rs0, *rs1;      // rs0/rs1: the (up to two) slack columns of a row, -1 if none
+    // iterate
+    double *p, *s, *g, *y, *tL, *tU, *muL, *muU, *ts, *mus, *pi;
+    // residuals / work
+    double *act, *aty, *rp, *rdp, *rds, *thp_inv, *ths_inv, *dS, *hp, *hs, *tmpn, *t1, *rhs, *res;
+    double *rcL, *rcU, *rcs, *rcg;
+    double* scal;                             // device scalars, see enum below
+    int64_t n, M, ns, ncomp;
+    double scale_q;
+};
+struct IpmDir {
+    double *dp, *ds, *dg, *dy, *dmuL, *dmuU, *dmus, *dpi;
+};
+enum { SC_PINF = 0, SC_DINF, SC_MU, SC_YMAX, SC_AP, SC_AD, SC_SM, SC_ALPHA, SC_EMAX, SC_RMAX, SC_COUNT };
+
+__device__ __forceinline__ double blk_reduce_max(double v, double* sh) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double out = 0.0;
+    if (threadIdx.x == 0) {
+        out = sh[0];
+        for (int k = 1; k < (int)(blockDim.x >> 6); ++k) out = fmax(out, sh[k]);
+        sh[0] = out;
+    }
+    __syncthreads();
+    out = sh[0];
+    __syncthreads();
+    return out;
+}
+__device__ __forceinline__ double blk_reduce_min(double v, double* sh) {
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double out = 0.0;
+    if (threadIdx.x == 0) {
+        out = sh[0];
+        for (int k = 1; k < (int)(blockDim.x >> 6); ++k) out = fmin(out, sh[k]);
+        sh[0] = out;
+    }
+    __syncthreads();
+    out = sh[0];
+    __syncthreads();
+    return out;
+}
+__device__ __forceinline__ double blk_reduce_sum(double v, double* sh) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double out = 0.0;
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) out += sh[k];
+        sh[0] = out;
+    }
+    __syncthreads();
+    out = sh[0];
+    __syncthreads();
+    return out;
+}
+
+__device__ __forceinline__ double slack_sum(const IpmPtrs& P, int64_t i, const double* v) {
+    double a = 0.0;
+    int k0 = P.rs0[i], k1 = P.rs1[i];
+    if (k0 >= 0) a += P.scoef[k0] * v[k0];
+    if (k1 >= 0) a += P.scoef[k1] * v[k1];
+    return a;
+}
+
+// residuals + convergence measures; act = Ah p and aty = Ah' y were produced by the gemv kernels
+__global__ __launch_bounds__(1024) void k_ipm_measures(IpmPtrs P) {
+    __shared__ double sh[16];
+    double pinf = 0.0, dinf = 0.0, mu = 0.0, ymax = 0.0;
+    for (int64_t i = threadIdx.x; i < P.M; i += 1024) {
+        bool ineq = P.rtype[i] != 0;
+        double sg = (double)P.rtype[i];
+        double a = P.act[i] + (P.ns ? slack_sum(P, i, P.s) : 0.0);
+        double rp = a - (P.r[i] + sg * (ineq ? P.g[i] : 0.0));
+        P.rp[i] = rp;
+        pinf = fmax(pinf, fabs(rp) / (1.0 + fabs(P.r[i])));
+        if (ineq) mu += P.g[i] * P.pi[i];
+        ymax = fmax(ymax, fabs(P.y[i]));
+    }
+    for (int64_t j = threadIdx.x; j < P.n; j += 1024) {
+        bool fr = P.ub[j] > P.lb[j];
+        double rd = fr ? P.q[j] - P.aty[j] - P.muL[j] + P.muU[j] : 0.0;
+        P.rdp[j] = rd;
+        dinf = fmax(dinf, fabs(rd));
+        if (fr) mu += P.tL[j] * P.muL[j] + P.tU[j] * P.muU[j];
+    }
+    for (int64_t k = threadIdx.x; k < P.ns; k += 1024) {
+        double rd = P.w[k] - P.scoef[k] * P.y[P.srow[k]] - P.mus[k];
+        P.rds[k] = rd;
+        dinf = fmax(dinf, fabs(rd));
+        mu += P.ts[k] * P.mus[k];
+    }
+    pinf = blk_reduce_max(pinf, sh);
+    dinf = blk_reduce_max(dinf, sh);
+    ymax = blk_reduce_max(ymax, sh);
+    mu = blk_reduce_sum(mu, sh);
+    if (threadIdx.x == 0) {
+        P.scal[SC_PINF] = pinf;
+        P.scal[SC_DINF] = dinf / P.scale_q;
+        P.scal[SC_MU] = mu / (double)P.ncomp;
+        P.scal[SC_YMAX] = ymax;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ipm_theta(IpmPtrs P, double rho_p) {
+    int64_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < P.n) {
+        bool fr = P.ub[t] > P.lb[t];
+        P.thp_inv[t] = fr ? 1.0 / (P.muL[t] / P.tL[t] + P.muU[t] / P.tU[t] + rho_p) : 0.0;
+    }
+    if (t < P.ns) P.ths_inv[t] = P.ts[t] / P.mus[t];
+    if (t < P.M) {
+        double d = P.rtype[t] != 0 ? P.g[t] / P.pi[t] : 0.0;
+        int k0 = P.rs0[t], k1 = P.rs1[t];
+        if (P.ns) {
+            if (k0 >= 0) d += P.ts[k0] / P.mus[k0];
+            if (k1 >= 0) d += P.ts[k1] / P.mus[k1];
+        }
+        P.dS[t] = d;
+    }
+}
+
+// complementarity right-hand sides (mode 0: affine, mode 1: corrector with the affine direction A) and hp, hs, theta*hp
+__global__ __launch_bounds__(256) void k_ipm_rhs1(IpmPtrs P, IpmDir A, int mode) {
+    int64_t t = blockIdx.x * 256 + threadIdx.x;
+    const double sm = mode ? P.scal[SC_SM] : 0.0;
+    if (t < P.n) {
+        bool fr = P.ub[t] > P.lb[t];
+        double rcL = sm - P.tL[t] * P.muL[t], rcU = sm - P.tU[t] * P.muU[t];
+        if (mode) {
+            rcL -= A.dp[t] * A.dmuL[t];
+            rcU += A.dp[t] * A.dmuU[t];
+        }
+        P.rcL[t] = rcL;
+        P.rcU[t] = rcU;
+        double hp = fr ? -P.rdp[t] + rcL / P.tL[t] - rcU / P.tU[t] : 0.0;
+        P.hp[t] = hp;
+        P.tmpn[t] = P.thp_inv[t] * hp;
+    }
+    if (t < P.ns) {
+        double rcs = sm - P.ts[t] * P.mus[t];
+        if (mode) rcs -= A.ds[t] * A.dmus[t];
+        P.rcs[t] = rcs;
+        P.hs[t] = -P.rds[t] + rcs / P.ts[t];
+    }
+    if (t < P.M) {
+        double rcg = sm - P.g[t] * P.pi[t];
+        if (mode) rcg -= A.dg[t] * A.dpi[t];
+        P.rcg[t] = rcg;
+    }
+}
+
+// rhs = -rp - Ah(theta hp) + sg rcg/pi - E(ths hs)
+__global__ __launch_bounds__(256) void k_ipm_rhs2(IpmPtrs P) {
+    int64_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.M) return;
+    bool ineq = P.rtype[i] != 0;
+    double v = -P.rp[i] - P.t1[i] + (ineq ? (double)P.rtype[i] * P.rcg[i] / P.pi[i] : 0.0);
+    if (P.ns) {
+        int k0 = P.rs0[i], k1 = P.rs1[i];
+        if (k0 >= 0) v -= P.scoef[k0] * P.ths_inv[k0] * P.hs[k0];
+        if (k1 >= 0) v -= P.scoef[k1] * P.ths_inv[k1] * P.hs[k1];
+    }
+    P.rhs[i] = v;
+}
+
+__global__ __launch_bounds__(256) void k_vec_mul(double* __restrict__ x, const double* __restrict__ a, int64_t len) {
+    int64_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < len) x[t] *= a[t];
+}
+__global__ __launch_bounds__(256) void k_vec_add(double* __restrict__ x, const double* __restrict__ a, int64_t len) {
+    int64_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < len) x[t] += a[t];
+}
+
+// res = rhs - (sres + dS dy) ; scal[EMAX] = max|res| ; scal[RMAX] = max(1, max|rhs|)
+__global__ __launch_bounds__(1024) void k_ipm_res(IpmPtrs P, const double* __restrict__ sres, const double* __restrict__ dy) {
+    __shared__ double sh[16];
+    double emax = 0.0, rmax = 1.0;
+    for (int64_t i = threadIdx.x; i < P.M; i += 1024) {
+        double v = P.rhs[i] - (sres[i] + P.dS[i] * dy[i]);
+        P.res[i] = v;
+        emax = fmax(emax, fabs(v));
+        rmax = fmax(rmax, fabs(P.rhs[i]));
+    }
+    emax = blk_reduce_max(emax, sh);
+    rmax = blk_reduce_max(rmax, sh);
+    if (threadIdx.x == 0) {
+        P.scal[SC_EMAX] = emax;
+        P.scal[SC_RMAX] = rmax;
+    }
+}
+
+// Newton direction from dy and aty2 = Ah' dy (in P.aty is NOT touched; tN holds Ah' dy)
+__global__ __launch_bounds__(256) void k_ipm_dir(IpmPtrs P, IpmDir D, const double* __restrict__ tN) {
+    int64_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < P.n) {
+        bool fr = P.ub[t] > P.lb[t];
+        double dp = P.thp_inv[t] * (P.hp[t] + tN[t]);
+        D.dp[t] = dp;
+        D.dmuL[t] = fr ? (P.rcL[t] - P.muL[t] * dp) / P.tL[t] : 0.0;
+        D.dmuU[t] = fr ? (P.rcU[t] + P.muU[t] * dp) / P.tU[t] : 0.0;
+    }
+    if (t < P.ns) {
+        double ds = P.ths_inv[t] * (P.hs[t] + P.scoef[t] * D.dy[P.srow[t]]);
+        D.ds[t] = ds;
+        D.dmus[t] = (P.rcs[t] - P.mus[t] * ds) / P.ts[t];
+    }
+    if (t < P.M) {
+        bool ineq = P.rtype[t] != 0;
+        double dpi = ineq ? (double)P.rtype[t] * D.dy[t] : 0.0;
+        D.dpi[t] = dpi;
+        D.dg[t] = ineq ? (P.rcg[t] - P.g[t] * dpi) / P.pi[t] : 0.0;
+    }
+}
+
+__device__ __forceinline__ double ratio(double x, double dx) { return dx < 0.0 ? -x / dx : 1e300; }
+
+// step lengths to the boundary (ap primal, ad dual); mode 1 additionally: alpha = min(1, eta min(ap, ad))
+__global__ __launch_bounds__(1024) void k_ipm_steps(IpmPtrs P, IpmDir D, int mode) {
+    __shared__ double sh[16];
+    double ap = 1e300, ad = 1e300;
+    for (int64_t j = threadIdx.x; j < P.n; j += 1024) {
+        if (!(P.ub[j] > P.lb[j])) continue;
+        ap = fmin(ap, fmin(ratio(P.tL[j], D.dp[j]), ratio(P.tU[j], -D.dp[j])));
+        ad = fmin(ad, fmin(ratio(P.muL[j], D.dmuL[j]), ratio(P.muU[j], D.dmuU[j])));
+    }
+    for (int64_t k = threadIdx.x; k < P.ns; k += 1024) {
+        ap = fmin(ap, ratio(P.ts[k], D.ds[k]));
+        ad = fmin(ad, ratio(P.mus[k], D.dmus[k]));
+    }
+    for (int64_t i = threadIdx.x; i < P.M; i += 1024) {
+        if (P.rtype[i] == 0) continue;
+        ap = fmin(ap, ratio(P.g[i], D.dg[i]));
+        ad = fmin(ad, ratio(P.pi[i], D.dpi[i]));
+    }
+    ap = fmin(1.0, blk_reduce_min(ap, sh));
+    ad = fmin(1.0, blk_reduce_min(ad, sh));
+    if (threadIdx.x == 0) {
+        P.scal[SC_AP] = ap;
+        P.scal[SC_AD] = ad;
+        if (mode) {
+            double mu = P.scal[SC_MU];
+            double eta = mu >= 1.0 ? 0.995 : fmin(fmax(0.995, 1.0 - mu / P.scale_q), 0.999999);
+            P.scal[SC_ALPHA] = fmin(1.0, eta * fmin(ap, ad));
+        }
+    }
+}
+
+// mu_aff -> sigma = (mu_aff/mu)^3 -> sm = sigma mu
+__global__ __launch_bounds__(1024) void k_ipm_muaff(IpmPtrs P, IpmDir A) {
+    __shared__ double sh[16];
+    const double ap = P.scal[SC_AP], ad = P.scal[SC_AD];
+    double acc = 0.0;
+    for (int64_t j = threadIdx.x; j < P.n; j += 1024) {
+        if (!(P.ub[j] > P.lb[j])) continue;
+        acc += (P.tL[j] + ap * A.dp[j]) * (P.muL[j] + ad * A.dmuL[j]) + (P.tU[j] - ap * A.dp[j]) * (P.muU[j] + ad * A.dmuU[j]);
+    }
+    for (int64_t k = threadIdx.x; k < P.ns; k += 1024) acc += (P.ts[k] + ap * A.ds[k]) * (P.mus[k] + ad * A.dmus[k]);
+    for (int64_t i = threadIdx.x; i < P.M; i += 1024)
+        if (P.rtype[i] != 0) acc += (P.g[i] + ap * A.dg[i]) * (P.pi[i] + ad * A.dpi[i]);
+    acc = blk_reduce_sum(acc, sh);
+    if (threadIdx.x == 0) {
+        double mu = P.scal[SC_MU];
+        double mu_aff = acc / (double)P.ncomp;
+        double r = mu > 0.0 ? mu_aff / mu : 0.0;
+        P.scal[SC_SM] = r * r * r * mu;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ipm_update(IpmPtrs P, IpmDir C) {
+    int64_t t = blockIdx.x * 256 + threadIdx.x;
+    const double al = P.scal[SC_ALPHA];
+    if (t < P.n) {
+        bool fr = P.ub[t] > P.lb[t];
+        P.p[t] += al * C.dp[t];
+        P.tL[t] = fr ? P.tL[t] + al * C.dp[t] : 1.0;
+        P.tU[t] = fr ? P.tU[t] - al * C.dp[t] : 1.0;
+        P.muL[t] += al * C.dmuL[t];
+        P.muU[t] += al * C.dmuU[t];
+    }
+    if (t < P.ns) {
+        P.s[t] += al * C.ds[t];
+        P.ts[t] += al * C.ds[t];
+        P.mus[t] += al * C.dmus[t];
+    }
+    if (t < P.M) {
+        bool ineq = P.rtype[t] != 0;
+        P.g[t] = ineq ? P.g[t] + al * C.dg[t] : 1.0;
+        double pi = P.pi[t] + al * C.dpi[t];
+        P.pi[t] = pi;
+        P.y[t] = ineq ? (double)P.rtype[t] * pi : P.y[t] + al * C.dy[t];
+    }
+}
+
+// starting point (oracle: IPM.__init__); act = Ah p0 must already be in P.act
+__global__ __launch_bounds__(256) void k_ipm_init_p(IpmPtrs P) {
+    int64_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < P.n) P.p[t] = 0.5 * (P.lb[t] + P.ub[t]);
+    if (t < P.ns) P.s[t] = P.slo[t] + 1.0;
+}
+__global__ __launch_bounds__(256) void k_ipm_init_rest(IpmPtrs P) {
+    int64_t t = blockIdx.x * 256 + threadIdx.x;
+    const double mu0 = P.scale_q;
+    if (t < P.n) {
+        bool fr = P.ub[t] > P.lb[t];
+        double tl = fr ? P.p[t] - P.lb[t] : 1.0, tu = fr ? P.ub[t] - P.p[t] : 1.0;
+        P.tL[t] = tl;
+        P.tU[t] = tu;
+        P.muL[t] = fr ? mu0 / tl : 0.0;
+        P.muU[t] = fr ? mu0 / tu : 0.0;
+    }
+    if (t < P.ns) {
+        double ts = P.s[t] - P.slo[t];
+        P.ts[t] = ts;
+        P.mus[t] = mu0 / ts;
+    }
+    if (t < P.M) {
+        bool ineq = P.rtype[t] != 0;
+        double sg = (double)P.rtype[t];
+        double a = P.act[t] + (P.ns ? slack_sum(P, t, P.s) : 0.0);
+        double g = ineq ? fmax(sg * (a - P.r[t]), 1.0) : 1.0;
+        P.g[t] = g;
+        double pi = ineq ? mu0 / g : 0.0;
+        P.pi[t] = pi;
+        P.y[t] = sg * pi;
+    }
+}

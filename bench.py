@@ -18,6 +18,25 @@ import os
 import sys
 import time
 
+
+def _host_cpu_quota():
+    """CPUs this process may actually use: the cgroup quota (cpu.max) if there is one, else the CPU count.  The GPU box
+    exposes 256 logical CPUs but grants 16 per 100 ms period; BLAS/OpenMP pools sized by the CPU count spin
+    through the quota and the kernel then freezes the whole process (incl. the HIP launch thread) for the rest
+    of every period - measured as 60 ms stalls every 100 ms in the rocprof timeline."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            return max(1, int(int(q) / int(per)))
+    except Exception:
+        pass
+    return os.cpu_count() or 1
+
+
+HOST_THREADS = min(16, _host_cpu_quota())
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, str(HOST_THREADS))
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -78,9 +97,9 @@ def run_steps(pr, algorithm, device, n_steps, state):
 def _cores():
     try:
         import threadpoolctl
-        return int(max((p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()), default=1))
+        return int(min(_host_cpu_quota(), max((p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()), default=1)))
     except Exception:
-        return os.cpu_count() or 1
+        return HOST_THREADS
 
 
 def cpu_baseline(pr, algorithm, budget_s, fact_per_step):

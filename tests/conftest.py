@@ -1,6 +1,10 @@
 import os
 import sys
 
+# keep BLAS / OpenMP pools inside the container's CPU quota (see bench.py:_host_cpu_quota)
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "8")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
