@@ -292,62 +292,60 @@ __global__ __launch_bounds__(1024) void k_diag_prepare(double* __restrict__ S, i
 // Cholesky of one NB x NB diagonal block, staged in LDS.  Pivot guard: d <= 1e-14*diag0 -> d := 1e256.
 #define ASM_DP (ASM_NB + 1)
 // One wavefront factors the 64x64 diagonal block: lane r keeps row r in registers (fully unrolled, compile-time
-// register indices), each new column is broadcast through LDS.  Then the explicit inverse of L11 is formed the same
-// way (lane c owns column c of the inverse) and stored for the panel solve and the triangular solves.
+// register indices).  Values needed by every lane (the pivot, the scaled column, the rows of L during the inversion)
+// are broadcast with v_readlane (constant lane index -> scalar registers): no LDS traffic and no barrier in the
+// 64-step chain.  The explicit inverse of L11 (lane c owns column c) is stored for the panel and triangular solves.
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
 __global__ __launch_bounds__(64) void k_potrf_diag(double* __restrict__ S, int64_t ldS, int k0, int nb,
                                                    const double* __restrict__ diag0, double thr, double* __restrict__ Linv) {
     __shared__ double D[ASM_NB * ASM_DP];
-    __shared__ double col[ASM_NB];
     const int r = threadIdx.x;
     double a[ASM_NB];
-    double my_inv = 1.0;
-    // coalesced load through LDS, then row r -> registers
+    // coalesced load through LDS, then row r -> registers (rows/cols >= nb are padded with the identity)
     for (int rr = 0; rr < ASM_NB; ++rr)
         D[rr * ASM_DP + r] = (rr < nb && r <= rr) ? S[(int64_t)(k0 + rr) * ldS + k0 + r] : (rr == r ? 1.0 : 0.0);
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < ASM_NB; ++c) a[c] = D[r * ASM_DP + c];
     const double d0r = r < nb ? diag0[k0 + r] : 1.0;
+    double my_inv = 1.0;
 #pragma unroll
     for (int j = 0; j < ASM_NB; ++j) {
-        double d = __shfl(a[j], j, 64);
-        double g0 = __shfl(d0r, j, 64);
+        double d = readlane_f64(a[j], j);
+        double g0 = readlane_f64(d0r, j);
         if (!(d > thr * g0)) d = 1e256;
         double ljj = sqrt(d);
         double inv = 1.0 / ljj;
         double l = a[j] * inv;
         if (r == j) { l = ljj; my_inv = inv; }
         a[j] = l;
-        col[r] = l;
-        __syncthreads();
-        // no predicate: lanes r < c update entries of the (unused) upper triangle with harmless garbage
+        // lanes r < c update entries of the (unused) upper triangle with harmless garbage: no predicate needed
 #pragma unroll
-        for (int c = j + 1; c < ASM_NB; ++c) a[c] = fma(-l, col[c], a[c]);
-        __syncthreads();
+        for (int c = j + 1; c < ASM_NB; ++c) a[c] = fma(-l, readlane_f64(l, c), a[c]);
     }
-    // write back (through LDS for coalescing) and keep L11 in LDS for the inversion
+    // write back through LDS (coalesced)
+    __syncthreads();
 #pragma unroll
     for (int c = 0; c < ASM_NB; ++c) D[r * ASM_DP + c] = (c <= r) ? a[c] : 0.0;
     __syncthreads();
     for (int rr = 0; rr < nb; ++rr)
         if (r <= rr && r < nb) S[(int64_t)(k0 + rr) * ldS + k0 + r] = D[rr * ASM_DP + r];
-    col[r] = my_inv;                       // reciprocals of the diagonal for the inversion
-    __syncthreads();
-    // inverse: lane c solves L x = e_c ; x kept in registers, L rows broadcast from LDS; four independent partial
-    // sums break the dependent fma chain and the diagonal enters through its stored reciprocal
+    // inverse: lane c solves L x = e_c ; L[rr][q] is register a[q] of lane rr -> scalar broadcast
     double x[ASM_NB];
 #pragma unroll
     for (int rr = 0; rr < ASM_NB; ++rr) {
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-        for (int q = 0; q < rr; q += 4) {
-            s0 = fma(D[rr * ASM_DP + q], x[q], s0);
-            if (q + 1 < rr) s1 = fma(D[rr * ASM_DP + q + 1], x[q + 1], s1);
-            if (q + 2 < rr) s2 = fma(D[rr * ASM_DP + q + 2], x[q + 2], s2);
-            if (q + 3 < rr) s3 = fma(D[rr * ASM_DP + q + 3], x[q + 3], s3);
+        for (int q = 0; q < rr; q += 2) {
+            s0 = fma(readlane_f64(a[q], rr), x[q], s0);
+            if (q + 1 < rr) s1 = fma(readlane_f64(a[q + 1], rr), x[q + 1], s1);
         }
         double rhs = (rr == r) ? 1.0 : 0.0;
-        x[rr] = (rr < r) ? 0.0 : (rhs - ((s0 + s1) + (s2 + s3))) * col[rr];
+        x[rr] = (rr < r) ? 0.0 : (rhs - (s0 + s1)) * readlane_f64(my_inv, rr);
     }
     __syncthreads();
 #pragma unroll

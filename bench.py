@@ -33,7 +33,7 @@ def _host_cpu_quota():
     return os.cpu_count() or 1
 
 
-HOST_THREADS = min(16, _host_cpu_quota())
+HOST_THREADS = max(1, min(8, _host_cpu_quota() // 2))      # half the quota: BLAS workers spin-wait after every call
 for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
     os.environ.setdefault(_v, str(HOST_THREADS))
 
