@@ -46,6 +46,7 @@ PROTOTYPES = {
     "asm_test_chol_solve": (C.c_int, [_P, _D, C.c_int64, _D, _D]),
     "asm_test_gemv": (C.c_int, [_P, _D, C.c_int64, C.c_int64, _D, _D, _D, _D]),
     "asm_test_assemble": (C.c_int, [_P, _D, _D]),
+    "asm_test_mfma_peak": (C.c_int, [_P, C.c_int, C.c_int, _D]),
 }
 
 _lib = None

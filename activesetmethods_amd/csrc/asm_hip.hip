@@ -1422,6 +1422,33 @@ int asm_test_gemv(asm_handle* h, const double* A, int64_t M, int64_t K, const do
     });
 }
 
+int asm_test_mfma_peak(asm_handle* h, int iters, int waves_per_simd, double* tflops) {
+    return guarded(h, [&] {
+        if (!tflops || iters <= 0 || waves_per_simd < 1 || waves_per_simd > 8) throw std::invalid_argument("asm_test_mfma_peak: bad argument");
+        HIPCHK(hipSetDevice(h->device));
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, h->device));
+        int blocks = prop.multiProcessorCount * waves_per_simd;          // 256-thread blocks: 4 wavefronts = one per SIMD
+        double* d_out = nullptr;
+        HIPCHK(hipMalloc((void**)&d_out, 64));
+        hipEvent_t e0, e1;
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k_mfma_f64_peak<4>, dim3(blocks), dim3(256), 0, h->stream, d_out, iters / 10 + 1);   // warm-up
+        HIPCHK(hipEventRecord(e0, h->stream));
+        hipLaunchKernelGGL(k_mfma_f64_peak<4>, dim3(blocks), dim3(256), 0, h->stream, d_out, iters);
+        HIPCHK(hipEventRecord(e1, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        double flops = (double)blocks * 4.0 * (double)iters * 4.0 * 2.0 * 16 * 16 * 4;
+        *tflops = flops / (ms * 1e-3) / 1e12;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipFree(d_out);
+    });
+}
+
 int asm_test_assemble(asm_handle* h, const double* dE, double* J_out) {
     return guarded(h, [&] {
         if (!h->setup_done) throw std::logic_error("setup first");

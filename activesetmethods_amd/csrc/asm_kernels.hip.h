@@ -543,3 +543,23 @@ __global__ __launch_bounds__(256) void k_col_relmax_stage2(const double* __restr
     for (int64_t r = 0; r < R; ++r) mx = fmax(mx, partial[r * ncols + j]);
     out[j] = mx;
 }
+
+// FP64 matrix-core peak probe: back-to-back v_mfma_f64_16x16x4_f64 on 8 independent accumulators per wavefront,
+// operands in registers, no memory traffic.  Used only to measure the roofline denominator on the box at hand.
+template <int NACC>
+__global__ __launch_bounds__(256) void k_mfma_f64_peak(double* __restrict__ out, int iters) {
+    v4f64 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    double a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = 1.0 + 1e-9 * (threadIdx.x + i); b[i] = 1.0 - 1e-9 * (threadIdx.x + 2 * i); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i & 3], b[(i >> 2) & 3], acc[i], 0, 0, 0);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 12345.678) out[0] = s;      // keep the accumulators alive
+}

@@ -123,6 +123,8 @@ int asm_test_chol_solve(asm_handle* h, const double* S, int64_t N, const double*
 int asm_test_gemv(asm_handle* h, const double* A, int64_t M, int64_t K, const double* x, const double* y,
                   double* Ax, double* ATy);
 int asm_test_assemble(asm_handle* h, const double* dE, double* J_out /* (m+nadj)*n */);
+/* FP64 MFMA peak probe (back-to-back v_mfma_f64_16x16x4_f64, registers only): measured roofline denominator. */
+int asm_test_mfma_peak(asm_handle* h, int iters, int waves_per_simd, double* tflops);
 
 #ifdef __cplusplus
 }

@@ -105,3 +105,10 @@ def test_assembly_bit_exact(hip_lib, seed, n, m, density, dup, nrange):
         assert hip_lib.asm_test_assemble(opt._h, _d(np.ascontiguousarray(dE)), _d(Jg)) == 0
         assert np.array_equal(Jg, lp.A)
     opt.close()
+
+
+def test_mfma_f64_probe_runs(hip_lib, handle):
+    """The FP64 matrix-core probe used for the roofline discussion (profiles/r01_mfma_f64_probe.txt)."""
+    t = C.c_double(0.0)
+    assert hip_lib.asm_test_mfma_peak(handle, 20000, 2, C.byref(t)) == 0
+    assert 5.0 < t.value < 200.0
