@@ -333,3 +333,13 @@ PUBLIC_CASE_SIZES = {"case118": (118, 54, 186), "case300": (300, 69, 411), "case
 def synthetic_case(name, seed=1, load_scale=1.0):
     nb, ng, nl = PUBLIC_CASE_SIZES[name]
     return synthetic_grid(nb, ng, nl, seed, load_scale)
+
+
+def scenario_case(base, scenario, lo=0.9, hi=1.1):
+    """Scenario `scenario` of a batch (BASELINE.json configs[4]): every bus load of `base` scaled by an independent
+    U(lo, hi) factor, seed = scenario id."""
+    c = dict(base)
+    f = lo + (hi - lo) * uniform01(1000 + int(scenario), base["n_bus"])
+    c["pd"] = base["pd"] * f
+    c["qd"] = base["qd"] * f
+    return c

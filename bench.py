@@ -51,11 +51,62 @@ WORKLOADS = {
     "c4": dict(desc="ACOPF case1354pegase-sized synthetic grid (1354 bus / 260 gen / 1991 branch; BASELINE.json configs[3], "
                     "the case the metric is quoted on; real case file not shipped with the reference), n=11192 m=18637",
                algorithm="Line Search", steps=3, warmup=1),
+    "c5": dict(desc="batch of scenario ACOPF, case300-sized synthetic grid (300 bus / 69 gen / 411 branch), loads x U(0.9,1.1) per "
+                    "scenario (BASELINE.json configs[4] has 512 scenarios over 8 GPUs = 64 per GPU; --scenarios-per-gpu sets the share), "
+                    "n=2382 m=3889; one step = one complete scenario solve",
+               algorithm="Line Search", steps=2, warmup=0),
     "c3": dict(desc="ACOPF case118-sized synthetic grid (118 bus / 54 gen / 186 branch; BASELINE.json configs[2]), n=1088 m=1725",
                algorithm="Line Search", steps=10, warmup=2),
     "c2": dict(desc="synthetic dense NLP n=1000 m=500 (BASELINE.json configs[1])", algorithm="Trust Region", steps=20, warmup=3),
     "c2small": dict(desc="synthetic dense NLP n=200 m=100 (reduced; parity-test size)", algorithm="Trust Region", steps=20, warmup=3),
 }
+
+
+def run_batch(args, rank, world, local_rank, dist, torch):
+    """Workload c5: scenarios are block-partitioned over ranks (activesetmethods_amd.batch), every rank solves its share
+    on its own GPU with one persistent handle, no data-path collective; one all-reduce merges the statistics."""
+    import activesetmethods_amd as A
+    from activesetmethods_amd import acopf, batch
+    base = acopf.synthetic_case("case300", 1)
+    per_gpu = args.steps
+    total = per_gpu * world
+    shared = {}
+
+    def factory(d, r, c):
+        if "opt" in shared:                 # constraint bounds (the loads) differ per scenario: new LP skeleton
+            shared["opt"].close()
+        shared["opt"] = A.HipSubOptimizer(d, r, c, device=local_rank)
+        return shared["opt"]
+
+    def make_model(sidx):
+        pr = acopf.acopf_problem(acopf.scenario_case(base, sidx), "case300-sized scenario %d" % sidx)
+        return A.Model.from_problem(pr, A.Parameters(algorithm=args.algorithm, max_iter=args.max_iter, external_optimizer=factory))
+
+    if args.warmup:
+        A.optimize(make_model(10 ** 6 + rank), max_lp_solves=2)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    slps, stats = batch.solve_batch(make_model, total, rank, world, reduce_device="cuda" if dist is not None else None)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        out = {"metric": "batch-NLP solves/sec", "value": total / elapsed, "unit": "solves/s", "n_gpus": world, "steps": per_gpu,
+               "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / per_gpu, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": WORKLOADS["c5"]["desc"], "algorithm": args.algorithm, "max_iter": args.max_iter,
+                          "scenarios_total": total, "parallelism": "scenarios block-partitioned, %d per GPU" % per_gpu},
+               "batch_stats": stats}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def make_problem(name):
@@ -159,6 +210,8 @@ def main():
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--algorithm", default=None)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--scenarios-per-gpu", type=int, default=None, help="workload c5: scenarios per GPU (alias of --steps)")
+    ap.add_argument("--max-iter", type=int, default=30, help="workload c5: SLP iteration cap per scenario")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
@@ -179,6 +232,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
 
+    if args.workload == "c5":
+        if args.scenarios_per_gpu is not None:
+            args.steps = args.scenarios_per_gpu
+        return run_batch(args, rank, world, local_rank, dist, torch)
     pr = make_problem(args.workload)
     state = {}
     run_steps(pr, args.algorithm, local_rank, args.warmup, state)

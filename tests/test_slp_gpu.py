@@ -114,3 +114,34 @@ def test_acopf_case118_sized_lp_parity():
     assert np.array_equal(rows, o_out[6]['sets'][0]) and np.array_equal(bnd, o_out[6]['sets'][1])
     assert rel_err(h_out[0], o_out[0]) < 1e-9 and rel_err(h_out[1], o_out[1]) < 1e-9
     opt.close()
+
+
+def test_scenario_batch_on_one_gpu():
+    """Scenario batch path on a single rank: block partition, one handle alive at a time,
+    merged statistics.  Scenarios = case3 with per-bus load factors."""
+    import activesetmethods_amd as A
+    from activesetmethods_amd import acopf, batch
+    pr0, d = _case3()
+    base = pr0.model.c
+    shared = {}
+
+    def factory(data, r, c):
+        if "opt" in shared:                 # constraint bounds (the loads) differ per scenario: new LP skeleton
+            shared["opt"].close()
+        shared["opt"] = A.HipSubOptimizer(data, r, c)
+        return shared["opt"]
+
+    def make_model(sidx):
+        pr = acopf.acopf_problem(acopf.scenario_case(base, sidx, 0.95, 1.05), "case3 scenario")
+        return A.Model.from_problem(pr, A.Parameters(algorithm="Line Search", max_iter=100, external_optimizer=factory))
+
+    slps, stats = batch.solve_batch(make_model, 4, rank=0, world=1)
+    assert stats["scenarios"] == 4 and stats["converged"] == 4
+    objs = [s.problem.obj_val for s in slps]
+    assert all(5000 < o < 7000 for o in objs) and len(set(round(o, 3) for o in objs)) == 4
+    # same scenarios through the oracle
+    from oracle import slp as O
+    for sidx, sh in zip(range(4), slps):
+        pr = acopf.acopf_problem(acopf.scenario_case(base, sidx, 0.95, 1.05), "case3 scenario")
+        mo, so = _oracle_run(pr, algorithm="Line Search", max_iter=100)
+        assert abs(mo.obj_val - sh.problem.obj_val) < 1e-6 and so.lp_solves == sh.lp_solves
