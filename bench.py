@@ -51,7 +51,7 @@ WORKLOADS = {
     "c4": dict(desc="ACOPF case1354pegase-sized synthetic grid (1354 bus / 260 gen / 1991 branch; BASELINE.json configs[3], "
                     "the case the metric is quoted on; real case file not shipped with the reference), n=11192 m=18637",
                algorithm="Line Search", steps=3, warmup=1),
-    "c5": dict(desc="batch of scenario ACOPF, case300-sized synthetic grid (300 bus / 69 gen / 411 branch), loads x U(0.9,1.1) per "
+    "c5": dict(desc="batch of scenario ACOPF, case300-sized synthetic grid (300 bus / 69 gen / 411 branch), load_scale 0.5, loads x U(0.9,1.1) per "
                     "scenario (BASELINE.json configs[4] has 512 scenarios over 8 GPUs = 64 per GPU; --scenarios-per-gpu sets the share), "
                     "n=2382 m=3889; one step = one complete scenario solve",
                algorithm="Line Search", steps=2, warmup=0),
@@ -67,7 +67,7 @@ def run_batch(args, rank, world, local_rank, dist, torch):
     on its own GPU with one persistent handle, no data-path collective; one all-reduce merges the statistics."""
     import activesetmethods_amd as A
     from activesetmethods_amd import acopf, batch
-    base = acopf.synthetic_case("case300", 1)
+    base = acopf.synthetic_case("case300", 1, 0.5)     # half the nominal synthetic load: Line-Search SLP converges in ~30 iterations
     per_gpu = args.steps
     total = per_gpu * world
     shared = {}
@@ -211,7 +211,7 @@ def main():
     ap.add_argument("--algorithm", default=None)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--scenarios-per-gpu", type=int, default=None, help="workload c5: scenarios per GPU (alias of --steps)")
-    ap.add_argument("--max-iter", type=int, default=30, help="workload c5: SLP iteration cap per scenario")
+    ap.add_argument("--max-iter", type=int, default=100, help="workload c5: SLP iteration cap per scenario")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
