@@ -94,6 +94,10 @@ struct asm_handle {
     double *d_vecN = nullptr, *d_vecM = nullptr, *d_vecM2 = nullptr, *d_part = nullptr, *d_partial = nullptr;
     double *d_Linv = nullptr, *d_tpart = nullptr;
     int64_t tpart_len = 0;
+    unsigned char* d_nz = nullptr;  // (row tile, k-chunk) non-zero flags of Ah
+    bool nz_valid = false;
+    int nz_T = 0, nz_pitch = 0;
+    double nz_fraction = 1.0;       // executed share of the (tile pair, k-chunk) products of the Schur build
     double* d_ipm = nullptr;        // arena of the device-resident interior-point state
     int* d_ipm_i = nullptr;
     int64_t nsp = 0;
@@ -225,9 +229,39 @@ struct Dev {
         end(id);
     }
     void syrk_dev(const int* idx_dev, int Ms, const double* theta_dev, const double* diag_dev) {
-        int id = begin(ASM_K_SYRK, (double)Ms * (Ms + 1) * h->ldn, 8.0 * (Ms * (double)h->ldn + 0.5 * Ms * (double)Ms));
-        launch_syrk(pick_tile(Ms), h->d_Ah, h->ldn, idx_dev, 0, Ms, (int)h->ldn, theta_dev, diag_dev, h->d_S, h->Mp, 0, 0);
+        const bool skip = h->nz_valid && idx_dev == nullptr && Ms == (int)h->M && pick_tile(Ms) == h->nz_T;
+        int id = begin(ASM_K_SYRK, (skip ? h->nz_fraction : 1.0) * (double)Ms * (Ms + 1) * h->ldn,
+                       8.0 * (Ms * (double)h->ldn + 0.5 * Ms * (double)Ms));
+        launch_syrk(pick_tile(Ms), h->d_Ah, h->ldn, idx_dev, 0, Ms, (int)h->ldn, theta_dev, diag_dev, h->d_S, h->Mp, 0, 0, -1,
+                    skip ? h->d_nz : nullptr, h->nz_pitch);
         end(id);
+    }
+    // per (row tile, k-chunk) non-zero flags of Ah for the chunk-skipping Schur build (sparse Jacobians only)
+    void tile_flags() {
+        h->nz_valid = false;
+        const int nch = (int)(h->ldn / ASM_KC);
+        if (h->dense_fast || nch > ASM_MAXCHUNKS || h->nnz * 8 > h->M * h->n) return;     // dense pattern: nothing to skip
+        h->nz_T = pick_tile(h->M);
+        const int TS = 32 * h->nz_T;
+        const int nt = (int)((h->M + TS - 1) / TS);
+        h->nz_pitch = nch;
+        hipLaunchKernelGGL(k_tile_nzflags, dim3((unsigned)nt, (unsigned)((nch + 7) / 8)), dim3(256), 0, h->stream, h->d_Ah, h->ldn, h->M, TS,
+                           nch, h->d_nz, h->nz_pitch);
+        h->nz_valid = true;
+        // fraction of (tile pair, chunk) products actually executed: keeps the flop accounting of the roofline honest
+        std::vector<unsigned char> fl((size_t)nt * nch);
+        HIPCHK(hipMemcpyAsync(fl.data(), h->d_nz, fl.size(), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        double act = 0.0, tot = 0.0;
+        for (int a = 0; a < nt; ++a)
+            for (int b = 0; b <= a; ++b) {
+                const unsigned char *fa = &fl[(size_t)a * nch], *fb = &fl[(size_t)b * nch];
+                int cnt = 0;
+                for (int c = 0; c < nch; ++c) cnt += fa[c] & fb[c];
+                act += cnt;
+                tot += nch;
+            }
+        h->nz_fraction = tot > 0 ? act / tot : 1.0;
     }
     void chol_solve_dev(const double* rhs_dev, double* out_dev, int Ms) {
         HIPCHK(hipMemcpyAsync(h->d_vecM2, rhs_dev, Ms * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -240,7 +274,8 @@ struct Dev {
     static int pick_tile(int64_t Ms) { return Ms >= 3072 ? 4 : (Ms >= 768 ? 2 : 1); }
 
     void launch_syrk(int T, const double* A, int64_t ld, const int* idx, int64_t row0, int Ms, int K, const double* theta,
-                     const double* diag, double* S, int64_t ldS, int64_t srow0, int mode, int MsB = -1) {
+                     const double* diag, double* S, int64_t ldS, int64_t srow0, int mode, int MsB = -1,
+                     const unsigned char* nz = nullptr, int nzpitch = 0) {
         int TS = 32 * T;
         int64_t nt = (Ms + TS - 1) / TS;
         int ntj = 0;
@@ -254,17 +289,18 @@ struct Dev {
         if (blocks <= 0) return;
         // per-launch timing of the MFMA kernel itself (algorithmic flops: Ms*MsB*K over the stored triangle/rectangle)
         double fl = (MsB == Ms && ntj == 0) ? (double)Ms * (Ms + 1) * K : 2.0 * ((double)Ms * MsB - 0.5 * (double)MsB * MsB) * K;
+        if (nz) fl *= h->nz_fraction;
         int kid = h->use_graphs ? -1 : begin(ASM_K_SYRK_KERNEL, fl, 8.0 * ((double)(Ms + MsB) * K + (double)Ms * MsB));
         struct EndGuard { Dev* d; int id; ~EndGuard() { d->end(id); } } guard_{this, kid};
         if (T == 4)
             hipLaunchKernelGGL((k_syrk<4, 8>), dim3((unsigned)blocks), dim3(512), 0, h->stream, A, ld, idx, row0, Ms, K, theta, diag, S,
-                               ldS, srow0, mode, MsB, ntj);
+                               ldS, srow0, mode, MsB, ntj, nz, nzpitch);
         else if (T == 2)
             hipLaunchKernelGGL((k_syrk<2, 4>), dim3((unsigned)blocks), dim3(256), 0, h->stream, A, ld, idx, row0, Ms, K, theta, diag, S,
-                               ldS, srow0, mode, MsB, ntj);
+                               ldS, srow0, mode, MsB, ntj, nz, nzpitch);
         else
             hipLaunchKernelGGL((k_syrk<1, 4>), dim3((unsigned)blocks), dim3(256), 0, h->stream, A, ld, idx, row0, Ms, K, theta, diag, S,
-                               ldS, srow0, mode, MsB, ntj);
+                               ldS, srow0, mode, MsB, ntj, nz, nzpitch);
     }
 
     // S[0:Ms,0:Ms] (lower) = Ah[idx,:] diag(theta) Ah[idx,:]' + diag     idx == nullptr -> identity
@@ -914,7 +950,8 @@ void free_device(asm_handle* h) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(h->d_perm); F(h->d_ustart); F(h->d_uoff); F(h->d_adjoff);
     F(h->d_dE); F(h->d_J); F(h->d_Ah); F(h->d_S); F(h->d_c); F(h->d_rho); F(h->d_theta); F(h->d_diag); F(h->d_diag0);
-    F(h->d_vecN); F(h->d_vecM); F(h->d_vecM2); F(h->d_part); F(h->d_partial); F(h->d_idx); F(h->d_Linv); F(h->d_tpart); F(h->d_ipm); F(h->d_ipm_i);
+    F(h->d_vecN); F(h->d_vecM); F(h->d_vecM2); F(h->d_part); F(h->d_partial); F(h->d_idx); F(h->d_Linv); F(h->d_tpart); F(h->d_ipm); F(h->d_ipm_i); F(h->d_nz);
+    h->d_nz = nullptr; h->nz_valid = false;
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     h->d_ipm = nullptr; h->d_ipm_i = nullptr; h->h_scal = nullptr;
     if (h->h_pin) (void)hipHostFree(h->h_pin);
@@ -1009,6 +1046,7 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     dmalloc(&h->d_Linv, (h->Mp / ASM_NB + 1) * ASM_NB * ASM_NB);
     h->tpart_len = (h->Mp / ASM_TRSV_ROWS + 2) * ASM_NB;
     dmalloc(&h->d_tpart, 2 * h->tpart_len);
+    dmalloc(&h->d_nz, (h->Mp / 32 + 1) * (h->ldn / ASM_KC + 1));
     h->nsp = round_up(std::max<int64_t>(h->ns, 1), 16);
     {
         int64_t nd = 24 * h->ldn + 22 * h->Mp + 16 * h->nsp + 64;
@@ -1081,6 +1119,7 @@ void do_solve(asm_handle* h, double delta, int feasibility, double* p_out, doubl
     }
     vec rho(M);
     sv.dev.scale(c.data(), rho.data());
+    sv.dev.tile_flags();
 
     // feasibility-restoration shift (subproblem.jl:287-295) and slack lower bounds (:298-381)
     vec b(h->E), viol(m, 0.0), slo_un;

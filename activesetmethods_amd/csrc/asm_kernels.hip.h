@@ -22,6 +22,7 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 #define ASM_NB 64          // Cholesky panel width
 #define ASM_KC 32          // k-chunk staged through LDS by k_syrk
+#define ASM_MAXCHUNKS 1024  // k-chunk list of k_syrk (sparse Schur build); n <= 32768, else the dense sweep is used
 #define ASM_PITCH 34       // LDS row pitch in doubles: KC + 2  (pitch = 2 mod 32 -> conflict-free ds_read_b64 fragments)
 
 // ---------------------------------------------------------------------------------------------------
@@ -149,7 +150,8 @@ __global__ __launch_bounds__(256) void k_gemv_t_stage2(const double* __restrict_
 template <int T, int NW>
 __global__ __launch_bounds__(64 * NW) void k_syrk(const double* __restrict__ A, int64_t ld, const int* __restrict__ idx, int64_t row0,
                                               int Ms, int K, const double* __restrict__ theta, const double* __restrict__ diag,
-                                              double* __restrict__ S, int64_t ldS, int64_t srow0, int mode, int MsB, int ntj) {
+                                              double* __restrict__ S, int64_t ldS, int64_t srow0, int mode, int MsB, int ntj,
+                                              const unsigned char* __restrict__ nzflags, int nzpitch) {
     constexpr int TS = 32 * T;
     // two LDS stages: the global loads of chunk c+1 are issued before the MFMAs of chunk c and written to the
     // other stage afterwards, so HBM/L2 latency hides under 16*T*T/4 matrix instructions; one barrier per chunk.
@@ -216,13 +218,38 @@ __global__ __launch_bounds__(64 * NW) void k_syrk(const double* __restrict__ A, 
             *reinterpret_cast<double2*>(&Bs[st][r * ASM_PITCH + lk]) = rb[ps];
         }
     };
-    gload(0);
-    lstore(0);
+    // k-chunks to visit: all of them, or (Schur build of a sparse Jacobian) only those where both operand tiles
+    // hold a non-zero - the skipped products are exact zeros, and the list keeps increasing k order, so the
+    // result is bitwise the one of the dense sweep.
+    __shared__ int s_list[ASM_MAXCHUNKS];
+    __shared__ int s_cnt;
+    int nchunks = K / ASM_KC;
+    if (nzflags) {
+        if (w == 0) {
+            const unsigned char* fa = nzflags + (int64_t)bi * nzpitch;
+            const unsigned char* fb = nzflags + (int64_t)bj * nzpitch;
+            int cnt = 0;
+            for (int base = 0; base < nchunks; base += 64) {
+                int c = base + lane;
+                bool f = c < nchunks && (fa[c] & fb[c]);
+                unsigned long long m = __ballot(f);
+                if (f) s_list[cnt + __popcll(m & ((1ull << lane) - 1ull))] = c;
+                cnt += __popcll(m);
+            }
+            if (lane == 0) s_cnt = cnt;
+        }
+        __syncthreads();
+        nchunks = s_cnt;
+    }
+    auto chunk_k0 = [&](int i) { return (nzflags ? s_list[i] : i) * ASM_KC; };
+    if (nchunks > 0) {
+        gload(chunk_k0(0));
+        lstore(0);
+    }
     __syncthreads();
-    const int nchunks = K / ASM_KC;
     for (int c = 0; c < nchunks; ++c) {
         const int st = c & 1;
-        if (c + 1 < nchunks) gload((c + 1) * ASM_KC);
+        if (c + 1 < nchunks) gload(chunk_k0(c + 1));
 #pragma unroll
         for (int kk = 0; kk < ASM_KC; kk += 4) {
             double af[TI], bf[TJ];
@@ -562,4 +589,28 @@ __global__ __launch_bounds__(256) void k_mfma_f64_peak(double* __restrict__ out,
 #pragma unroll
     for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     if (s == 12345.678) out[0] = s;      // keep the accumulators alive
+}
+
+// nz[t][c] = 1 iff the 32T-row tile t of A has a non-zero in k-chunk c (32 columns).  One workgroup per (tile, group of
+// 8 chunks); feeds the chunk skipping of the Schur build for sparse Jacobians (ACOPF: ~3 non-zeros per row).
+__global__ __launch_bounds__(256) void k_tile_nzflags(const double* __restrict__ A, int64_t ld, int64_t M, int tile_rows, int nchunks,
+                                                      unsigned char* __restrict__ nz, int nzpitch) {
+    const int t = blockIdx.x, c0 = blockIdx.y * 8;
+    __shared__ int any[8];
+    if (threadIdx.x < 8) any[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t r0 = (int64_t)t * tile_rows;
+    // 256 threads = 8 chunks x 32 columns; loop over the rows of the tile
+    const int col = c0 * ASM_KC + threadIdx.x;
+    const int cc = threadIdx.x >> 5;
+    bool f = false;
+    if (c0 + cc < nchunks)
+        for (int r = 0; r < tile_rows; ++r) {
+            int64_t i = r0 + r;
+            if (i >= M) break;
+            f = f || (A[i * ld + col] != 0.0);
+        }
+    if (f) any[cc] = 1;
+    __syncthreads();
+    if (threadIdx.x < 8 && c0 + threadIdx.x < nchunks) nz[(int64_t)t * nzpitch + c0 + threadIdx.x] = (unsigned char)any[threadIdx.x];
 }
