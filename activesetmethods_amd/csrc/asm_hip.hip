@@ -349,7 +349,7 @@ struct Dev {
     void chol_launches(int Ms, double thr) {
         // two-level right-looking blocking: 64-wide steps inside a 512-wide outer panel touch only the panel's
         // own columns; the large trailing matrix is read-modify-written once per outer panel (K = 512).
-        const int NBO = 8 * ASM_NB;
+        const int NBO = 16 * ASM_NB;
         for (int K0 = 0; K0 < Ms; K0 += NBO) {
             int K1 = std::min(K0 + NBO, Ms);
             for (int k0 = K0; k0 < K1; k0 += ASM_NB) {
