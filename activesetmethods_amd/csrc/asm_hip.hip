@@ -92,7 +92,7 @@ struct asm_handle {
     double *d_dE = nullptr, *d_J = nullptr, *d_Ah = nullptr, *d_S = nullptr;
     double *d_c = nullptr, *d_rho = nullptr, *d_theta = nullptr, *d_diag = nullptr, *d_diag0 = nullptr;
     double *d_vecN = nullptr, *d_vecM = nullptr, *d_vecM2 = nullptr, *d_part = nullptr, *d_partial = nullptr;
-    double *d_Linv = nullptr, *d_tpart = nullptr;
+    double *d_Linv = nullptr, *d_tpart = nullptr, *d_Binv = nullptr, *d_wpart = nullptr;
     int64_t tpart_len = 0;
     unsigned char* d_nz = nullptr;  // (row tile, k-chunk) non-zero flags of Ah
     bool nz_valid = false;
@@ -342,7 +342,11 @@ struct Dev {
 
     void chol(int Ms, double thr = 1e-14) {
         int id = begin(ASM_K_CHOL, (double)Ms * Ms * Ms / 3.0, 8.0 * 1.5 * Ms * (double)Ms);
-        run_sequence(thr == 1e-14 ? 1 : 2, Ms, Ms == (int)h->M, [&] { chol_launches(Ms, thr); });
+        run_sequence(thr == 1e-14 ? 1 : 2, Ms, Ms == (int)h->M, [&] {
+            chol_launches(Ms, thr);
+            hipLaunchKernelGGL(k_trtri512, dim3((unsigned)((Ms + ASM_WB - 1) / ASM_WB), ASM_WSUB), dim3(256), 0, h->stream, h->d_S, h->Mp,
+                               h->d_Linv, Ms, h->d_Binv);
+        });
         end(id);
         h->stats.nfact += 1;
     }
@@ -382,24 +386,23 @@ struct Dev {
         // forward: w = copy of rhs (d_vecM2, updated in place), z -> d_vecM ; backward: x -> d_vecM2 (w is dead by then)
         double* w = h->d_vecM2;
         double* z = h->d_vecM;
-        for (int k0 = 0; k0 < Ms; k0 += ASM_NB) {
-            int nb = std::min(ASM_NB, Ms - k0);
-            int rem = Ms - (k0 + nb);
-            unsigned g = (unsigned)std::max(1, (rem + ASM_TRSV_ROWS - 1) / ASM_TRSV_ROWS);
-            hipLaunchKernelGGL(k_trsv_fwd_step, dim3(g), dim3(256), 0, h->stream, h->d_S, h->Mp, h->d_Linv, k0, nb, Ms, w, z);
+        const int nB = (Ms + ASM_WB - 1) / ASM_WB;
+        for (int B = 0; B < nB; ++B) {
+            int b1 = std::min((B + 1) * ASM_WB, Ms);
+            hipLaunchKernelGGL(k_wtrsv_fwd_diag, dim3(ASM_WB / 4), dim3(256), 0, h->stream, h->d_Binv, B, Ms, w, z);
+            int rem = Ms - b1;
+            if (rem > 0)
+                hipLaunchKernelGGL(k_wtrsv_fwd_panel, dim3((unsigned)((rem + 31) / 32)), dim3(256), 0, h->stream, h->d_S, h->Mp, B, Ms, z, w);
         }
-        int last = ((Ms - 1) / ASM_NB) * ASM_NB;
-        int n_in = 0;
-        int flip = 0;
-        for (int k0 = last; k0 >= 0; k0 -= ASM_NB) {
-            int nb = std::min(ASM_NB, Ms - k0);
-            unsigned g = (unsigned)std::max(1, (Ms - k0 + ASM_TRSV_BROWS - 1) / ASM_TRSV_BROWS);
-            double* pin = h->d_tpart + (int64_t)flip * h->tpart_len;
-            double* pout = h->d_tpart + (int64_t)(1 - flip) * h->tpart_len;
-            hipLaunchKernelGGL(k_trsv_bwd_step, dim3(g), dim3(256), 0, h->stream, h->d_S, h->Mp, h->d_Linv, k0, nb, Ms, z, w, pin, n_in,
-                               pout);
-            n_in = (int)g;
-            flip = 1 - flip;
+        for (int B = nB - 1; B >= 0; --B) {
+            int b1 = std::min((B + 1) * ASM_WB, Ms);
+            int rem = Ms - b1;
+            int np = 0;
+            if (rem > 0) {
+                np = (rem + ASM_WBROWS - 1) / ASM_WBROWS;
+                hipLaunchKernelGGL(k_wtrsv_bwd_panel, dim3((unsigned)np), dim3(256), 0, h->stream, h->d_S, h->Mp, B, Ms, w, h->d_wpart);
+            }
+            hipLaunchKernelGGL(k_wtrsv_bwd_diag, dim3(ASM_WSUB), dim3(256), 0, h->stream, h->d_Binv, B, Ms, z, h->d_wpart, np, w);
         }
     }
 
@@ -950,7 +953,8 @@ void free_device(asm_handle* h) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(h->d_perm); F(h->d_ustart); F(h->d_uoff); F(h->d_adjoff);
     F(h->d_dE); F(h->d_J); F(h->d_Ah); F(h->d_S); F(h->d_c); F(h->d_rho); F(h->d_theta); F(h->d_diag); F(h->d_diag0);
-    F(h->d_vecN); F(h->d_vecM); F(h->d_vecM2); F(h->d_part); F(h->d_partial); F(h->d_idx); F(h->d_Linv); F(h->d_tpart); F(h->d_ipm); F(h->d_ipm_i); F(h->d_nz);
+    F(h->d_vecN); F(h->d_vecM); F(h->d_vecM2); F(h->d_part); F(h->d_partial); F(h->d_idx); F(h->d_Linv); F(h->d_tpart); F(h->d_Binv); F(h->d_wpart);
+    h->d_Binv = h->d_wpart = nullptr; F(h->d_ipm); F(h->d_ipm_i); F(h->d_nz);
     h->d_nz = nullptr; h->nz_valid = false;
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     h->d_ipm = nullptr; h->d_ipm_i = nullptr; h->h_scal = nullptr;
@@ -1044,6 +1048,8 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     dmalloc(&h->d_partial, (int64_t)ASM_TMAXCHUNKS * h->ldn);
     dmalloc(&h->d_idx, h->Mp);
     dmalloc(&h->d_Linv, (h->Mp / ASM_NB + 1) * ASM_NB * ASM_NB);
+    dmalloc(&h->d_Binv, (h->Mp / ASM_WB + 1) * (int64_t)ASM_WB * ASM_WB);
+    dmalloc(&h->d_wpart, (h->Mp / 128 + 2) * (int64_t)ASM_WB);
     h->tpart_len = (h->Mp / ASM_TRSV_ROWS + 2) * ASM_NB;
     dmalloc(&h->d_tpart, 2 * h->tpart_len);
     dmalloc(&h->d_nz, (h->Mp / 32 + 1) * (h->ldn / ASM_KC + 1));

@@ -614,3 +614,216 @@ __global__ __launch_bounds__(256) void k_tile_nzflags(const double* __restrict__
     __syncthreads();
     if (threadIdx.x < 8 && c0 + threadIdx.x < nchunks) nz[(int64_t)t * nzpitch + c0 + threadIdx.x] = (unsigned char)any[threadIdx.x];
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Wide-block triangular solves.  After the factorisation the 512 x 512 diagonal blocks of L are inverted explicitly
+// (k_trtri512, from the 64 x 64 block inverses of k_potrf_diag), so a solve needs 2 launches per 512-wide block and
+// direction instead of one per 64-wide block: 148 launches instead of 582 at M = 18637.
+//   block inverse X = L_BB^-1 by block columns:  X_jj = Linv_j ;  X_ij = -Linv_i * sum_{k=j}^{i-1} L_ik X_kj   (i > j)
+#define ASM_WB 512
+#define ASM_WSUB (ASM_WB / ASM_NB)
+__global__ __launch_bounds__(256) void k_trtri512(const double* __restrict__ L, int64_t ld, const double* __restrict__ Linv, int Ms,
+                                                  double* __restrict__ Binv) {
+    __shared__ double Ta[ASM_NB * ASM_DP];
+    __shared__ double Tb[ASM_NB * ASM_DP];
+    const int B = blockIdx.x, j = blockIdx.y;
+    const int tid = threadIdx.x, r = tid & 63, g = tid >> 6;
+    const int b0 = B * ASM_WB;                                  // first row/col of the wide block
+    double* X = Binv + (int64_t)B * ASM_WB * ASM_WB;            // row-major 512 x 512
+    const int nsub = min(ASM_WSUB, (Ms - b0 + ASM_NB - 1) / ASM_NB);
+    // zero the blocks above the diagonal of this block column and pad missing sub-blocks with the identity
+    for (int i = 0; i < ASM_WSUB; ++i) {
+        if (i >= j && i < nsub && j < nsub) continue;
+        for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
+            int rr = e >> 6, c = e & 63;
+            X[(int64_t)(i * ASM_NB + rr) * ASM_WB + j * ASM_NB + c] = (i == j && rr == c) ? 1.0 : 0.0;
+        }
+    }
+    if (j >= nsub) return;
+    // X_jj = Linv_j
+    {
+        const double* src = Linv + (int64_t)((b0 / ASM_NB) + j) * ASM_NB * ASM_NB;
+        for (int e = tid; e < ASM_NB * ASM_NB; e += 256)
+            X[(int64_t)(j * ASM_NB + (e >> 6)) * ASM_WB + j * ASM_NB + (e & 63)] = src[e];
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int i = j + 1; i < nsub; ++i) {
+        double acc[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc[u] = 0.0;
+        for (int k = j; k < i; ++k) {
+            // Ta = L_ik (rows b0+64i.., cols b0+64k..), Tb = X_kj
+            for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
+                int rr = e >> 6, c = e & 63;
+                int gi = b0 + i * ASM_NB + rr;
+                Ta[rr * ASM_DP + c] = gi < Ms ? L[(int64_t)gi * ld + b0 + k * ASM_NB + c] : 0.0;
+                Tb[rr * ASM_DP + c] = X[(int64_t)(k * ASM_NB + rr) * ASM_WB + j * ASM_NB + c];
+            }
+            __syncthreads();
+            for (int q = 0; q < ASM_NB; ++q) {
+                double a = Ta[r * ASM_DP + q];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc[u] = fma(a, Tb[q * ASM_DP + g * 16 + u], acc[u]);
+            }
+            __syncthreads();
+        }
+        // Tb = acc ; Ta = Linv_i ; X_ij = -Ta * Tb
+#pragma unroll
+        for (int u = 0; u < 16; ++u) Tb[r * ASM_DP + g * 16 + u] = acc[u];
+        {
+            const double* src = Linv + (int64_t)((b0 / ASM_NB) + i) * ASM_NB * ASM_NB;
+            for (int e = tid; e < ASM_NB * ASM_NB; e += 256) Ta[(e >> 6) * ASM_DP + (e & 63)] = src[e];
+        }
+        __syncthreads();
+        double out[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) out[u] = 0.0;
+        for (int q = 0; q <= r; ++q) {                 // Linv_i is lower triangular
+            double a = Ta[r * ASM_DP + q];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) out[u] = fma(a, Tb[q * ASM_DP + g * 16 + u], out[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) X[(int64_t)(i * ASM_NB + r) * ASM_WB + j * ASM_NB + g * 16 + u] = -out[u];
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// forward, wide block B:  z_B = X_B w_B   (one wavefront per row: 128 workgroups of 4 rows; all loads of a row in flight)
+__global__ __launch_bounds__(256) void k_wtrsv_fwd_diag(const double* __restrict__ Binv, int B, int Ms, const double* __restrict__ w,
+                                                        double* __restrict__ z) {
+    const int b0 = B * ASM_WB;
+    const double* X = Binv + (int64_t)B * ASM_WB * ASM_WB;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wv;
+    if (b0 + row >= Ms) return;
+    double v[ASM_WB / 64];
+#pragma unroll
+    for (int u = 0; u < ASM_WB / 64; ++u) {
+        int c = u * 64 + lane;
+        v[u] = (c <= row) ? X[(int64_t)row * ASM_WB + c] * w[b0 + c] : 0.0;
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < ASM_WB / 64; ++u) acc += v[u];
+    acc = wave_sum(acc);
+    if (lane == 0) z[b0 + row] = acc;
+}
+// forward panel update:  w[i] -= L[i, b0:b1] . z[b0:b1]   for i >= b1.  A wavefront owns 8 rows: their 64 loads are issued
+// together, the 8 sums are reduced, and lanes 0..7 apply the 8 read-modify-writes in parallel.
+__global__ __launch_bounds__(256) void k_wtrsv_fwd_panel(const double* __restrict__ L, int64_t ld, int B, int Ms, const double* __restrict__ z,
+                                                         double* __restrict__ w) {
+    __shared__ double zs[ASM_WB];
+    const int b0 = B * ASM_WB, b1 = min(b0 + ASM_WB, Ms), wdt = b1 - b0;
+    for (int c = threadIdx.x; c < ASM_WB; c += 256) zs[c] = c < wdt ? z[b0 + c] : 0.0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i0 = b1 + blockIdx.x * 32 + wv * 8;
+    double wold = 0.0;
+    if (lane < 8 && i0 + lane < Ms) wold = w[i0 + lane];
+    double acc[8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        int i = i0 + rr;
+        double a = 0.0;
+        if (i < Ms) {
+            const double* row = L + (int64_t)i * ld + b0;
+#pragma unroll
+            for (int u = 0; u < ASM_WB / 64; ++u) {
+                int c = u * 64 + lane;
+                a = fma(c < wdt ? row[c] : 0.0, zs[c], a);
+            }
+        }
+        acc[rr] = a;
+    }
+    double mine = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        double t = wave_sum(acc[rr]);
+        if (lane == rr) mine = t;
+    }
+    if (lane < 8 && i0 + lane < Ms) w[i0 + lane] = wold - mine;
+}
+// backward partial sums for wide block B over a chunk of 512 rows i >= b1:  part[g][c] = sum_i L[i, b0+c] x[i]
+#define ASM_WBROWS 512
+__global__ __launch_bounds__(256) void k_wtrsv_bwd_panel(const double* __restrict__ L, int64_t ld, int B, int Ms, const double* __restrict__ x,
+                                                         double* __restrict__ part) {
+    __shared__ double red[4][ASM_WB];
+    const int b0 = B * ASM_WB, b1 = min(b0 + ASM_WB, Ms), wdt = b1 - b0;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double acc[ASM_WB / 64];
+#pragma unroll
+    for (int u = 0; u < ASM_WB / 64; ++u) acc[u] = 0.0;
+    const int base = b1 + blockIdx.x * ASM_WBROWS;
+    for (int r0 = wv; r0 < ASM_WBROWS; r0 += 16) {            // 4 rows per batch and wavefront: 32 loads in flight
+        double xi[4];
+        const double* rowp[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int i = base + r0 + 4 * q;
+            bool ok = i < Ms;
+            xi[q] = ok ? x[i] : 0.0;
+            rowp[q] = L + (int64_t)(ok ? i : b1) * ld + b0;
+        }
+        double v[4][ASM_WB / 64];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int u = 0; u < ASM_WB / 64; ++u) {
+                int c = u * 64 + lane;
+                v[q][u] = c < wdt ? rowp[q][c] : 0.0;
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int u = 0; u < ASM_WB / 64; ++u) acc[u] = fma(v[q][u], xi[q], acc[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < ASM_WB / 64; ++u) red[wv][u * 64 + lane] = acc[u];
+    __syncthreads();
+    for (int c = threadIdx.x; c < ASM_WB; c += 256)
+        part[(int64_t)blockIdx.x * ASM_WB + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+// backward diagonal:  t = z_B - sum_g part[g] ;  x_B = X_B' t   (thread per column, rows split over 4 wavefronts, 8 loads in flight)
+__global__ __launch_bounds__(256) void k_wtrsv_bwd_diag(const double* __restrict__ Binv, int B, int Ms, const double* __restrict__ z,
+                                                        const double* __restrict__ part, int n_part, double* __restrict__ x) {
+    __shared__ double ts[ASM_WB];
+    __shared__ double red[4][64];
+    const int b0 = B * ASM_WB, b1 = min(b0 + ASM_WB, Ms), wdt = b1 - b0;
+    const double* X = Binv + (int64_t)B * ASM_WB * ASM_WB;
+    for (int c = threadIdx.x; c < ASM_WB; c += 256) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        if (c < wdt) {
+            int g = 0;
+            for (; g + 3 < n_part; g += 4) {
+                s0 += part[(int64_t)g * ASM_WB + c];
+                s1 += part[(int64_t)(g + 1) * ASM_WB + c];
+                s2 += part[(int64_t)(g + 2) * ASM_WB + c];
+                s3 += part[(int64_t)(g + 3) * ASM_WB + c];
+            }
+            for (; g < n_part; ++g) s0 += part[(int64_t)g * ASM_WB + c];
+            s0 = z[b0 + c] - ((s0 + s1) + (s2 + s3));
+        }
+        ts[c] = c < wdt ? s0 : 0.0;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;                      // column of the inverse = unknown index within the block
+    double acc = 0.0;
+    // rows r = c + wv, c + wv + 4, ... ; batches of 8 independent loads (the padded inverse is zero/identity outside the block)
+    for (int r0 = blockIdx.x * 64 + wv; r0 < ASM_WB; r0 += 32) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            int r = r0 + 4 * q;
+            v[q] = (r < ASM_WB && r >= c) ? X[(int64_t)r * ASM_WB + c] * ts[r] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += v[q];
+    }
+    red[wv][lane] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64 && c < wdt) x[b0 + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
