@@ -358,7 +358,7 @@ struct Dev {
             int K1 = std::min(K0 + NBO, Ms);
             for (int k0 = K0; k0 < K1; k0 += ASM_NB) {
                 int nb = std::min(ASM_NB, Ms - k0);
-                hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(64), 0, h->stream, h->d_S, h->Mp, k0, nb, h->d_diag0, thr, h->d_Linv);
+                hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, h->stream, h->d_S, h->Mp, k0, nb, h->d_diag0, thr, h->d_Linv);
                 int k1 = k0 + nb;
                 if (k1 < Ms) {
                     int rem = Ms - k1;

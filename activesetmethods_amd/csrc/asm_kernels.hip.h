@@ -318,68 +318,145 @@ __global__ __launch_bounds__(1024) void k_diag_prepare(double* __restrict__ S, i
 // ---------------------------------------------------------------------------------------------------
 // Cholesky of one NB x NB diagonal block, staged in LDS.  Pivot guard: d <= 1e-14*diag0 -> d := 1e256.
 #define ASM_DP (ASM_NB + 1)
-// One wavefront factors the 64x64 diagonal block: lane r keeps row r in registers (fully unrolled, compile-time
-// register indices).  Values needed by every lane (the pivot, the scaled column, the rows of L during the inversion)
-// are broadcast with v_readlane (constant lane index -> scalar registers): no LDS traffic and no barrier in the
-// 64-step chain.  The explicit inverse of L11 (lane c owns column c) is stored for the panel and triangular solves.
+// Cholesky of one 64x64 diagonal block + explicit inverse of the factor, on the critical path of every panel step.
+// 256 threads, everything in LDS, blocked by 16: (1) one wavefront factors the 16x16 sub-block in registers (row per
+// lane, wave shuffles), (2) substitution for the rows below, (3) rank-16 update of the remaining triangle; then the
+// inverse by 16x16 blocks: diagonal blocks by substitution (one wavefront each), off-diagonal blocks level by level
+// W_ij = -W_ii * sum_k L_ik W_kj.  Static pivot guard: d <= thr*diag0 -> 1e256 (row dropped, see asm_hip.hip).
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
     return __hiloint2double(hi, lo);
 }
-__global__ __launch_bounds__(64) void k_potrf_diag(double* __restrict__ S, int64_t ldS, int k0, int nb,
-                                                   const double* __restrict__ diag0, double thr, double* __restrict__ Linv) {
+__global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int64_t ldS, int k0, int nb,
+                                                    const double* __restrict__ diag0, double thr, double* __restrict__ Linv) {
     __shared__ double D[ASM_NB * ASM_DP];
-    const int r = threadIdx.x;
-    double a[ASM_NB];
-    // coalesced load through LDS, then row r -> registers (rows/cols >= nb are padded with the identity)
-    for (int rr = 0; rr < ASM_NB; ++rr)
-        D[rr * ASM_DP + r] = (rr < nb && r <= rr) ? S[(int64_t)(k0 + rr) * ldS + k0 + r] : (rr == r ? 1.0 : 0.0);
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < ASM_NB; ++c) a[c] = D[r * ASM_DP + c];
-    const double d0r = r < nb ? diag0[k0 + r] : 1.0;
-    double my_inv = 1.0;
-#pragma unroll
-    for (int j = 0; j < ASM_NB; ++j) {
-        double d = readlane_f64(a[j], j);
-        double g0 = readlane_f64(d0r, j);
-        if (!(d > thr * g0)) d = 1e256;
-        double ljj = sqrt(d);
-        double inv = 1.0 / ljj;
-        double l = a[j] * inv;
-        if (r == j) { l = ljj; my_inv = inv; }
-        a[j] = l;
-        // lanes r < c update entries of the (unused) upper triangle with harmless garbage: no predicate needed
-#pragma unroll
-        for (int c = j + 1; c < ASM_NB; ++c) a[c] = fma(-l, readlane_f64(l, c), a[c]);
+    __shared__ double W[ASM_NB * ASM_DP];
+    __shared__ double T[4][16 * 17];
+    __shared__ double d0[ASM_NB], dinv[ASM_NB];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
+        int rr = e >> 6, c = e & 63;
+        D[rr * ASM_DP + c] = (rr < nb && c <= rr) ? S[(int64_t)(k0 + rr) * ldS + k0 + c] : (rr == c ? 1.0 : 0.0);
+        W[rr * ASM_DP + c] = 0.0;
     }
-    // write back through LDS (coalesced)
+    if (tid < ASM_NB) d0[tid] = tid < nb ? diag0[k0 + tid] : 1.0;
     __syncthreads();
+    for (int sb = 0; sb < 4; ++sb) {
+        const int c0 = sb * 16;
+        if (wv == 0) {                                   // (1) 16x16 diagonal sub-block, lane t < 16 owns row c0+t
+            const int t = lane & 15;
+            double a[16];
 #pragma unroll
-    for (int c = 0; c < ASM_NB; ++c) D[r * ASM_DP + c] = (c <= r) ? a[c] : 0.0;
-    __syncthreads();
-    for (int rr = 0; rr < nb; ++rr)
-        if (r <= rr && r < nb) S[(int64_t)(k0 + rr) * ldS + k0 + r] = D[rr * ASM_DP + r];
-    // inverse: lane c solves L x = e_c ; L[rr][q] is register a[q] of lane rr -> scalar broadcast
-    double x[ASM_NB];
+            for (int c = 0; c < 16; ++c) a[c] = D[(c0 + t) * ASM_DP + c0 + c];
+            double my_inv = 1.0;
 #pragma unroll
-    for (int rr = 0; rr < ASM_NB; ++rr) {
-        double s0 = 0.0, s1 = 0.0;
+            for (int j = 0; j < 16; ++j) {
+                double d = readlane_f64(a[j], j);
+                if (!(d > thr * d0[c0 + j])) d = 1e256;
+                double ljj = sqrt(d);
+                double inv = 1.0 / ljj;
+                double l = a[j] * inv;
+                if (t == j) { l = ljj; my_inv = inv; }
+                a[j] = l;
 #pragma unroll
-        for (int q = 0; q < rr; q += 2) {
-            s0 = fma(readlane_f64(a[q], rr), x[q], s0);
-            if (q + 1 < rr) s1 = fma(readlane_f64(a[q + 1], rr), x[q + 1], s1);
+                for (int c = j + 1; c < 16; ++c) a[c] = fma(-l, readlane_f64(l, c), a[c]);
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) D[(c0 + t) * ASM_DP + c0 + c] = (c <= t) ? a[c] : 0.0;
+                dinv[c0 + t] = my_inv;
+            }
         }
-        double rhs = (rr == r) ? 1.0 : 0.0;
-        x[rr] = (rr < r) ? 0.0 : (rhs - (s0 + s1)) * readlane_f64(my_inv, rr);
+        __syncthreads();
+        const int rows_below = ASM_NB - (c0 + 16);
+        if (tid < rows_below) {                          // (2) rows below: x L11' = d  (substitution, L11 broadcast from LDS)
+            const int r = c0 + 16 + tid;
+            double x[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                double v = D[r * ASM_DP + c0 + c];
+#pragma unroll
+                for (int q = 0; q < c; ++q) v = fma(-x[q], D[(c0 + c) * ASM_DP + c0 + q], v);
+                x[c] = v * dinv[c0 + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) D[r * ASM_DP + c0 + c] = x[c];
+        }
+        __syncthreads();
+        {                                                // (3) rank-16 update of the remaining lower triangle
+            const int r = c0 + 16 + lane;
+            if (r < ASM_NB) {
+                double pr[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) pr[q] = D[r * ASM_DP + c0 + q];
+                for (int c = c0 + 16 + wv; c <= r; c += 4) {
+                    double acc = D[r * ASM_DP + c];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc = fma(-pr[q], D[c * ASM_DP + c0 + q], acc);
+                    D[r * ASM_DP + c] = acc;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < nb * ASM_NB; e += 256) {
+        int rr = e >> 6, c = e & 63;
+        if (c <= rr && c < nb) S[(int64_t)(k0 + rr) * ldS + k0 + c] = D[rr * ASM_DP + c];
+    }
+    // ---- inverse W = L^-1 by 16x16 blocks
+    {   // diagonal blocks: wavefront wv inverts block wv; lane t < 16 owns column t of the block inverse
+        const int c0 = wv * 16, t = lane & 15;
+        double x[16];
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            double sum = 0.0;
+#pragma unroll
+            for (int q = 0; q < rr; ++q) sum = fma(D[(c0 + rr) * ASM_DP + c0 + q], x[q], sum);
+            double rhs = (rr == t) ? 1.0 : 0.0;
+            x[rr] = (rr < t) ? 0.0 : (rhs - sum) * dinv[c0 + rr];
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) W[(c0 + rr) * ASM_DP + c0 + t] = x[rr];
+        }
     }
     __syncthreads();
+    for (int dlev = 1; dlev < 4; ++dlev) {               // off-diagonal blocks (i, j = i - dlev), one wavefront per block
+        const int i = wv + dlev, j = wv;
+        if (i < 4) {
+            // T = sum_{k=j}^{i-1} L_ik W_kj : entry (rr, cc), 4 entries per lane
+            double tv[4];
 #pragma unroll
-    for (int rr = 0; rr < ASM_NB; ++rr) D[rr * ASM_DP + r] = x[rr];
-    __syncthreads();
+            for (int u = 0; u < 4; ++u) {
+                int e = u * 64 + lane, rr = e >> 4, cc = e & 15;
+                double acc = 0.0;
+                for (int k = j; k < i; ++k)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc = fma(D[(i * 16 + rr) * ASM_DP + k * 16 + q], W[(k * 16 + q) * ASM_DP + j * 16 + cc], acc);
+                tv[u] = acc;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int e = u * 64 + lane;
+                T[wv][(e >> 4) * 17 + (e & 15)] = tv[u];
+            }
+        }
+        __syncthreads();
+        if (i < 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int e = u * 64 + lane, rr = e >> 4, cc = e & 15;
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc = fma(W[(i * 16 + rr) * ASM_DP + i * 16 + q], T[wv][q * 17 + cc], acc);
+                W[(i * 16 + rr) * ASM_DP + j * 16 + cc] = -acc;
+            }
+        }
+        __syncthreads();
+    }
     double* out = Linv + (int64_t)(k0 / ASM_NB) * ASM_NB * ASM_NB;
-    for (int rr = 0; rr < ASM_NB; ++rr) out[rr * ASM_NB + r] = D[rr * ASM_DP + r];
+    for (int e = tid; e < ASM_NB * ASM_NB; e += 256) out[e] = W[(e >> 6) * ASM_DP + (e & 63)];
 }
 
 // Panel solve through the explicit inverse:  S[i, k0:k1] <- S[i, k0:k1] * Linv11'  for the 64 rows of this tile.
