@@ -92,7 +92,7 @@ struct asm_handle {
     double *d_dE = nullptr, *d_J = nullptr, *d_Ah = nullptr, *d_S = nullptr;
     double *d_c = nullptr, *d_rho = nullptr, *d_theta = nullptr, *d_diag = nullptr, *d_diag0 = nullptr;
     double *d_vecN = nullptr, *d_vecM = nullptr, *d_vecM2 = nullptr, *d_part = nullptr, *d_partial = nullptr;
-    double *d_Linv = nullptr, *d_tpart = nullptr, *d_Binv = nullptr, *d_wpart = nullptr;
+    double *d_Linv = nullptr, *d_tpart = nullptr, *d_Binv = nullptr, *d_BinvT = nullptr, *d_wpart = nullptr, *d_wt = nullptr;
     int64_t tpart_len = 0;
     unsigned char* d_nz = nullptr;  // (row tile, k-chunk) non-zero flags of Ah
     bool nz_valid = false;
@@ -346,6 +346,7 @@ struct Dev {
             chol_launches(Ms, thr);
             hipLaunchKernelGGL(k_trtri512, dim3((unsigned)((Ms + ASM_WB - 1) / ASM_WB), ASM_WSUB), dim3(256), 0, h->stream, h->d_S, h->Mp,
                                h->d_Linv, Ms, h->d_Binv);
+            hipLaunchKernelGGL(k_transpose512, dim3((unsigned)((Ms + ASM_WB - 1) / ASM_WB), 64), dim3(256), 0, h->stream, h->d_Binv, h->d_BinvT);
         });
         end(id);
         h->stats.nfact += 1;
@@ -402,7 +403,8 @@ struct Dev {
                 np = (rem + ASM_WBROWS - 1) / ASM_WBROWS;
                 hipLaunchKernelGGL(k_wtrsv_bwd_panel, dim3((unsigned)np), dim3(256), 0, h->stream, h->d_S, h->Mp, B, Ms, w, h->d_wpart);
             }
-            hipLaunchKernelGGL(k_wtrsv_bwd_diag, dim3(ASM_WSUB), dim3(256), 0, h->stream, h->d_Binv, B, Ms, z, h->d_wpart, np, w);
+            hipLaunchKernelGGL(k_wtrsv_bwd_reduce, dim3(ASM_WSUB), dim3(256), 0, h->stream, B, Ms, z, h->d_wpart, np, h->d_wt);
+            hipLaunchKernelGGL(k_wtrsv_bwd_diag, dim3(ASM_WB / 4), dim3(256), 0, h->stream, h->d_BinvT, B, Ms, h->d_wt, w);
         }
     }
 
@@ -953,8 +955,8 @@ void free_device(asm_handle* h) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(h->d_perm); F(h->d_ustart); F(h->d_uoff); F(h->d_adjoff);
     F(h->d_dE); F(h->d_J); F(h->d_Ah); F(h->d_S); F(h->d_c); F(h->d_rho); F(h->d_theta); F(h->d_diag); F(h->d_diag0);
-    F(h->d_vecN); F(h->d_vecM); F(h->d_vecM2); F(h->d_part); F(h->d_partial); F(h->d_idx); F(h->d_Linv); F(h->d_tpart); F(h->d_Binv); F(h->d_wpart);
-    h->d_Binv = h->d_wpart = nullptr; F(h->d_ipm); F(h->d_ipm_i); F(h->d_nz);
+    F(h->d_vecN); F(h->d_vecM); F(h->d_vecM2); F(h->d_part); F(h->d_partial); F(h->d_idx); F(h->d_Linv); F(h->d_tpart); F(h->d_Binv); F(h->d_wpart); F(h->d_BinvT); F(h->d_wt);
+    h->d_Binv = h->d_wpart = h->d_BinvT = h->d_wt = nullptr; F(h->d_ipm); F(h->d_ipm_i); F(h->d_nz);
     h->d_nz = nullptr; h->nz_valid = false;
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     h->d_ipm = nullptr; h->d_ipm_i = nullptr; h->h_scal = nullptr;
@@ -1049,7 +1051,9 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     dmalloc(&h->d_idx, h->Mp);
     dmalloc(&h->d_Linv, (h->Mp / ASM_NB + 1) * ASM_NB * ASM_NB);
     dmalloc(&h->d_Binv, (h->Mp / ASM_WB + 1) * (int64_t)ASM_WB * ASM_WB);
-    dmalloc(&h->d_wpart, (h->Mp / 128 + 2) * (int64_t)ASM_WB);
+    dmalloc(&h->d_BinvT, (h->Mp / ASM_WB + 1) * (int64_t)ASM_WB * ASM_WB);
+    dmalloc(&h->d_wpart, (h->Mp / ASM_WBROWS + 2) * (int64_t)ASM_WB);
+    dmalloc(&h->d_wt, ASM_WB);
     h->tpart_len = (h->Mp / ASM_TRSV_ROWS + 2) * ASM_NB;
     dmalloc(&h->d_tpart, 2 * h->tpart_len);
     dmalloc(&h->d_nz, (h->Mp / 32 + 1) * (h->ldn / ASM_KC + 1));

@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256) void k_trtri512(const double* __restrict__ L, 
     __shared__ double Ta[ASM_NB * ASM_DP];
     __shared__ double Tb[ASM_NB * ASM_DP];
     const int B = blockIdx.x, j = blockIdx.y;
-    const int tid = threadIdx.x, r = tid & 63, g = tid >> 6;
+    const int tid = threadIdx.x;
     const int b0 = B * ASM_WB;                                  // first row/col of the wide block
     double* X = Binv + (int64_t)B * ASM_WB * ASM_WB;            // row-major 512 x 512
     const int nsub = min(ASM_WSUB, (Ms - b0 + ASM_NB - 1) / ASM_NB);
@@ -725,10 +725,14 @@ __global__ __launch_bounds__(256) void k_trtri512(const double* __restrict__ L, 
     }
     __threadfence_block();
     __syncthreads();
+    // 64x64x64 products with a 4x4 register block per thread (8 LDS reads per 16 fma)
+    const int ty = tid >> 4, tx = tid & 15;
     for (int i = j + 1; i < nsub; ++i) {
-        double acc[16];
+        double acc[4][4];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc[u] = 0.0;
+        for (int a_ = 0; a_ < 4; ++a_)
+#pragma unroll
+            for (int b_ = 0; b_ < 4; ++b_) acc[a_][b_] = 0.0;
         for (int k = j; k < i; ++k) {
             // Ta = L_ik (rows b0+64i.., cols b0+64k..), Tb = X_kj
             for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
@@ -738,31 +742,51 @@ __global__ __launch_bounds__(256) void k_trtri512(const double* __restrict__ L, 
                 Tb[rr * ASM_DP + c] = X[(int64_t)(k * ASM_NB + rr) * ASM_WB + j * ASM_NB + c];
             }
             __syncthreads();
+#pragma unroll 4
             for (int q = 0; q < ASM_NB; ++q) {
-                double a = Ta[r * ASM_DP + q];
+                double av[4], bv[4];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) acc[u] = fma(a, Tb[q * ASM_DP + g * 16 + u], acc[u]);
+                for (int a_ = 0; a_ < 4; ++a_) av[a_] = Ta[(ty * 4 + a_) * ASM_DP + q];
+#pragma unroll
+                for (int b_ = 0; b_ < 4; ++b_) bv[b_] = Tb[q * ASM_DP + tx * 4 + b_];
+#pragma unroll
+                for (int a_ = 0; a_ < 4; ++a_)
+#pragma unroll
+                    for (int b_ = 0; b_ < 4; ++b_) acc[a_][b_] = fma(av[a_], bv[b_], acc[a_][b_]);
             }
             __syncthreads();
         }
         // Tb = acc ; Ta = Linv_i ; X_ij = -Ta * Tb
 #pragma unroll
-        for (int u = 0; u < 16; ++u) Tb[r * ASM_DP + g * 16 + u] = acc[u];
+        for (int a_ = 0; a_ < 4; ++a_)
+#pragma unroll
+            for (int b_ = 0; b_ < 4; ++b_) Tb[(ty * 4 + a_) * ASM_DP + tx * 4 + b_] = acc[a_][b_];
         {
             const double* src = Linv + (int64_t)((b0 / ASM_NB) + i) * ASM_NB * ASM_NB;
             for (int e = tid; e < ASM_NB * ASM_NB; e += 256) Ta[(e >> 6) * ASM_DP + (e & 63)] = src[e];
         }
         __syncthreads();
-        double out[16];
+        double out[4][4];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) out[u] = 0.0;
-        for (int q = 0; q <= r; ++q) {                 // Linv_i is lower triangular
-            double a = Ta[r * ASM_DP + q];
+        for (int a_ = 0; a_ < 4; ++a_)
 #pragma unroll
-            for (int u = 0; u < 16; ++u) out[u] = fma(a, Tb[q * ASM_DP + g * 16 + u], out[u]);
+            for (int b_ = 0; b_ < 4; ++b_) out[a_][b_] = 0.0;
+        for (int q = 0; q <= ty * 4 + 3; ++q) {          // Linv_i is lower triangular (entries above the diagonal are 0)
+            double av[4], bv[4];
+#pragma unroll
+            for (int a_ = 0; a_ < 4; ++a_) av[a_] = Ta[(ty * 4 + a_) * ASM_DP + q];
+#pragma unroll
+            for (int b_ = 0; b_ < 4; ++b_) bv[b_] = Tb[q * ASM_DP + tx * 4 + b_];
+#pragma unroll
+            for (int a_ = 0; a_ < 4; ++a_)
+#pragma unroll
+                for (int b_ = 0; b_ < 4; ++b_) out[a_][b_] = fma(av[a_], bv[b_], out[a_][b_]);
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) X[(int64_t)(i * ASM_NB + r) * ASM_WB + j * ASM_NB + g * 16 + u] = -out[u];
+        for (int a_ = 0; a_ < 4; ++a_)
+#pragma unroll
+            for (int b_ = 0; b_ < 4; ++b_)
+                X[(int64_t)(i * ASM_NB + ty * 4 + a_) * ASM_WB + j * ASM_NB + tx * 4 + b_] = -out[a_][b_];
         __threadfence_block();
         __syncthreads();
     }
@@ -823,8 +847,8 @@ __global__ __launch_bounds__(256) void k_wtrsv_fwd_panel(const double* __restric
     }
     if (lane < 8 && i0 + lane < Ms) w[i0 + lane] = wold - mine;
 }
-// backward partial sums for wide block B over a chunk of 512 rows i >= b1:  part[g][c] = sum_i L[i, b0+c] x[i]
-#define ASM_WBROWS 512
+// backward partial sums for wide block B over chunks of 64 rows i >= b1:  part[g][c] = sum_i L[i, b0+c] x[i]
+#define ASM_WBROWS 64
 __global__ __launch_bounds__(256) void k_wtrsv_bwd_panel(const double* __restrict__ L, int64_t ld, int B, int Ms, const double* __restrict__ x,
                                                          double* __restrict__ part) {
     __shared__ double red[4][ASM_WB];
@@ -863,44 +887,61 @@ __global__ __launch_bounds__(256) void k_wtrsv_bwd_panel(const double* __restric
     for (int c = threadIdx.x; c < ASM_WB; c += 256)
         part[(int64_t)blockIdx.x * ASM_WB + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
-// backward diagonal:  t = z_B - sum_g part[g] ;  x_B = X_B' t   (thread per column, rows split over 4 wavefronts, 8 loads in flight)
-__global__ __launch_bounds__(256) void k_wtrsv_bwd_diag(const double* __restrict__ Binv, int B, int Ms, const double* __restrict__ z,
-                                                        const double* __restrict__ part, int n_part, double* __restrict__ x) {
-    __shared__ double ts[ASM_WB];
+// t = z_B - sum_g part[g]   (8 workgroups of 64 columns; partials split over the 4 wavefronts in a fixed order)
+__global__ __launch_bounds__(256) void k_wtrsv_bwd_reduce(int B, int Ms, const double* __restrict__ z, const double* __restrict__ part,
+                                                          int n_part, double* __restrict__ t) {
     __shared__ double red[4][64];
     const int b0 = B * ASM_WB, b1 = min(b0 + ASM_WB, Ms), wdt = b1 - b0;
-    const double* X = Binv + (int64_t)B * ASM_WB * ASM_WB;
-    for (int c = threadIdx.x; c < ASM_WB; c += 256) {
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        if (c < wdt) {
-            int g = 0;
-            for (; g + 3 < n_part; g += 4) {
-                s0 += part[(int64_t)g * ASM_WB + c];
-                s1 += part[(int64_t)(g + 1) * ASM_WB + c];
-                s2 += part[(int64_t)(g + 2) * ASM_WB + c];
-                s3 += part[(int64_t)(g + 3) * ASM_WB + c];
-            }
-            for (; g < n_part; ++g) s0 += part[(int64_t)g * ASM_WB + c];
-            s0 = z[b0 + c] - ((s0 + s1) + (s2 + s3));
-        }
-        ts[c] = c < wdt ? s0 : 0.0;
-    }
-    __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;                      // column of the inverse = unknown index within the block
+    const int c = blockIdx.x * 64 + lane;
     double acc = 0.0;
-    // rows r = c + wv, c + wv + 4, ... ; batches of 8 independent loads (the padded inverse is zero/identity outside the block)
-    for (int r0 = blockIdx.x * 64 + wv; r0 < ASM_WB; r0 += 32) {
+    for (int g0 = wv; g0 < n_part; g0 += 32) {
         double v[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            int r = r0 + 4 * q;
-            v[q] = (r < ASM_WB && r >= c) ? X[(int64_t)r * ASM_WB + c] * ts[r] : 0.0;
+            int g = g0 + 4 * q;
+            v[q] = g < n_part ? part[(int64_t)g * ASM_WB + c] : 0.0;
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc += v[q];
     }
     red[wv][lane] = acc;
     __syncthreads();
-    if (threadIdx.x < 64 && c < wdt) x[b0 + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (threadIdx.x < 64) t[c] = c < wdt ? z[b0 + c] - ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) : 0.0;
+}
+// x_B = X_B' t  through the transposed block inverse (row c of XT = column c of X): one wavefront per unknown
+__global__ __launch_bounds__(256) void k_wtrsv_bwd_diag(const double* __restrict__ BinvT, int B, int Ms, const double* __restrict__ t,
+                                                        double* __restrict__ x) {
+    const int b0 = B * ASM_WB;
+    const double* XT = BinvT + (int64_t)B * ASM_WB * ASM_WB;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wv;
+    if (b0 + row >= Ms) return;
+    double v[ASM_WB / 64];
+#pragma unroll
+    for (int u = 0; u < ASM_WB / 64; ++u) {
+        int c = u * 64 + lane;
+        v[u] = (c >= row) ? XT[(int64_t)row * ASM_WB + c] * t[c] : 0.0;
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < ASM_WB / 64; ++u) acc += v[u];
+    acc = wave_sum(acc);
+    if (lane == 0) x[b0 + row] = acc;
+}
+// XT_B = X_B'  (LDS-tiled transpose of every 512 x 512 block inverse)
+__global__ __launch_bounds__(256) void k_transpose512(const double* __restrict__ Binv, double* __restrict__ BinvT) {
+    __shared__ double tile[64 * 65];
+    const int B = blockIdx.x, ti = blockIdx.y >> 3, tj = blockIdx.y & 7;
+    const double* X = Binv + (int64_t)B * ASM_WB * ASM_WB;
+    double* XT = BinvT + (int64_t)B * ASM_WB * ASM_WB;
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        int r = e >> 6, c = e & 63;
+        tile[r * 65 + c] = X[(int64_t)(ti * 64 + r) * ASM_WB + tj * 64 + c];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        int r = e >> 6, c = e & 63;
+        XT[(int64_t)(tj * 64 + r) * ASM_WB + ti * 64 + c] = tile[c * 65 + r];
+    }
 }
