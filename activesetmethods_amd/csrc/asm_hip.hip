@@ -69,6 +69,8 @@ struct TimedRegion {
 struct asm_handle {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // look-ahead stream of the Cholesky (next panel's block chain runs beside the trailing update)
+    std::vector<hipEvent_t> la_events;
     std::string err;
     bool setup_done = false, inputs_ready = false;
 
@@ -132,7 +134,8 @@ namespace {
 // =====================================================================================================
 struct Dev {
     asm_handle* h;
-    explicit Dev(asm_handle* hh) : h(hh) {}
+    hipStream_t cur;                 // stream the factorisation kernels are launched on (h->stream, or the look-ahead stream)
+    explicit Dev(asm_handle* hh) : h(hh), cur(hh->stream) {}
 
     hipEvent_t get_event() {
         if (!h->event_pool.empty()) {
@@ -290,16 +293,16 @@ struct Dev {
         // per-launch timing of the MFMA kernel itself (algorithmic flops: Ms*MsB*K over the stored triangle/rectangle)
         double fl = (MsB == Ms && ntj == 0) ? (double)Ms * (Ms + 1) * K : 2.0 * ((double)Ms * MsB - 0.5 * (double)MsB * MsB) * K;
         if (nz) fl *= h->nz_fraction;
-        int kid = h->use_graphs ? -1 : begin(ASM_K_SYRK_KERNEL, fl, 8.0 * ((double)(Ms + MsB) * K + (double)Ms * MsB));
+        int kid = (h->use_graphs || cur != h->stream) ? -1 : begin(ASM_K_SYRK_KERNEL, fl, 8.0 * ((double)(Ms + MsB) * K + (double)Ms * MsB));
         struct EndGuard { Dev* d; int id; ~EndGuard() { d->end(id); } } guard_{this, kid};
         if (T == 4)
-            hipLaunchKernelGGL((k_syrk<4, 8>), dim3((unsigned)blocks), dim3(512), 0, h->stream, A, ld, idx, row0, Ms, K, theta, diag, S,
+            hipLaunchKernelGGL((k_syrk<4, 8>), dim3((unsigned)blocks), dim3(512), 0, cur, A, ld, idx, row0, Ms, K, theta, diag, S,
                                ldS, srow0, mode, MsB, ntj, nz, nzpitch);
         else if (T == 2)
-            hipLaunchKernelGGL((k_syrk<2, 4>), dim3((unsigned)blocks), dim3(256), 0, h->stream, A, ld, idx, row0, Ms, K, theta, diag, S,
+            hipLaunchKernelGGL((k_syrk<2, 4>), dim3((unsigned)blocks), dim3(256), 0, cur, A, ld, idx, row0, Ms, K, theta, diag, S,
                                ldS, srow0, mode, MsB, ntj, nz, nzpitch);
         else
-            hipLaunchKernelGGL((k_syrk<1, 4>), dim3((unsigned)blocks), dim3(256), 0, h->stream, A, ld, idx, row0, Ms, K, theta, diag, S,
+            hipLaunchKernelGGL((k_syrk<1, 4>), dim3((unsigned)blocks), dim3(256), 0, cur, A, ld, idx, row0, Ms, K, theta, diag, S,
                                ldS, srow0, mode, MsB, ntj, nz, nzpitch);
     }
 
@@ -351,29 +354,59 @@ struct Dev {
         end(id);
         h->stats.nfact += 1;
     }
-    void chol_launches(int Ms, double thr) {
-        // two-level right-looking blocking: 64-wide steps inside a 512-wide outer panel touch only the panel's
-        // own columns; the large trailing matrix is read-modify-written once per outer panel (K = 512).
-        const int NBO = 16 * ASM_NB;
-        for (int K0 = 0; K0 < Ms; K0 += NBO) {
-            int K1 = std::min(K0 + NBO, Ms);
-            for (int k0 = K0; k0 < K1; k0 += ASM_NB) {
-                int nb = std::min(ASM_NB, Ms - k0);
-                hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, h->stream, h->d_S, h->Mp, k0, nb, h->d_diag0, thr, h->d_Linv);
-                int k1 = k0 + nb;
-                if (k1 < Ms) {
-                    int rem = Ms - k1;
-                    hipLaunchKernelGGL(k_trsm_panel, dim3((unsigned)((rem + 63) / 64)), dim3(256), 0, h->stream, h->d_S, h->Mp, k0, nb, Ms,
-                                       h->d_Linv);
-                    if (k1 < K1)   // update the remaining columns of this outer panel only
-                        launch_syrk(pick_tile(rem), h->d_S + k0, h->Mp, nullptr, k1, rem, nb, nullptr, nullptr, h->d_S, h->Mp, k1, 1, K1 - k1);
-                }
-            }
-            if (K1 < Ms) {
-                int rem = Ms - K1;
-                launch_syrk(pick_tile(rem), h->d_S + K0, h->Mp, nullptr, K1, rem, K1 - K0, nullptr, nullptr, h->d_S, h->Mp, K1, 1);
+    // block chain of one outer panel [K0, K1): 64-wide potrf / panel solve / in-panel update steps
+    void chol_chain(int Ms, double thr, int K0, int K1) {
+        for (int k0 = K0; k0 < K1; k0 += ASM_NB) {
+            int nb = std::min(ASM_NB, Ms - k0);
+            hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, cur, h->d_S, h->Mp, k0, nb, h->d_diag0, thr, h->d_Linv);
+            int k1 = k0 + nb;
+            if (k1 < Ms) {
+                int rem = Ms - k1;
+                hipLaunchKernelGGL(k_trsm_panel, dim3((unsigned)((rem + 63) / 64)), dim3(256), 0, cur, h->d_S, h->Mp, k0, nb, Ms, h->d_Linv);
+                if (k1 < K1)   // update the remaining columns of this outer panel only
+                    launch_syrk(pick_tile(rem), h->d_S + k0, h->Mp, nullptr, k1, rem, nb, nullptr, nullptr, h->d_S, h->Mp, k1, 1, K1 - k1);
             }
         }
+    }
+    void chol_launches(int Ms, double thr) {
+        // Two-level right-looking blocking with look-ahead.  64-wide steps inside a 1024-wide outer panel touch only the
+        // panel's own columns; the trailing matrix is read-modify-written once per outer panel (K = 1024), in two parts:
+        // (a) the columns of the NEXT outer panel, (b) the rest.  The next panel's serial block chain then runs on a second
+        // stream beside (b), so the latency-bound chain hides under the MFMA-bound update.
+        const int NBO = 16 * ASM_NB;
+        const int nP = (Ms + NBO - 1) / NBO;
+        const bool la = nP > 2 && !h->use_graphs;
+        while ((int)h->la_events.size() < 2 * nP + 2) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            h->la_events.push_back(e);
+        }
+        cur = h->stream;
+        chol_chain(Ms, thr, 0, std::min(NBO, Ms));
+        for (int p = 0; p < nP; ++p) {
+            const int K0 = p * NBO, K1 = std::min(K0 + NBO, Ms);
+            if (K1 >= Ms) break;
+            const int rem = Ms - K1, wa = std::min(NBO, rem);            // next panel = first `wa` trailing columns
+            hipEvent_t e_a = h->la_events[2 * p], e_c = h->la_events[2 * p + 1];
+            cur = h->stream;
+            // (a) rows >= K1, columns of the next outer panel
+            launch_syrk(pick_tile(rem), h->d_S + K0, h->Mp, nullptr, K1, rem, K1 - K0, nullptr, nullptr, h->d_S, h->Mp, K1, 1, wa);
+            if (la) {
+                HIPCHK(hipEventRecord(e_a, h->stream));
+                HIPCHK(hipStreamWaitEvent(h->stream2, e_a, 0));
+                cur = h->stream2;
+                chol_chain(Ms, thr, K1, std::min(K1 + NBO, Ms));           // next panel's chain beside (b)
+                HIPCHK(hipEventRecord(e_c, h->stream2));
+                cur = h->stream;
+            }
+            // (b) the rest of the trailing matrix
+            const int rem2 = rem - wa;
+            if (rem2 > 0)
+                launch_syrk(pick_tile(rem2), h->d_S + K0, h->Mp, nullptr, K1 + wa, rem2, K1 - K0, nullptr, nullptr, h->d_S, h->Mp, K1 + wa, 1);
+            if (la) HIPCHK(hipStreamWaitEvent(h->stream, e_c, 0));
+            else chol_chain(Ms, thr, K1, std::min(K1 + NBO, Ms));
+        }
+        cur = h->stream;
     }
     // out = (L L')^-1 rhs   (compact vectors of length Ms)
     void chol_solve(const double* rhs, double* out, int Ms) {
@@ -1256,7 +1289,8 @@ int asm_create(int device, asm_handle** out) {
     asm_handle* h = new (std::nothrow) asm_handle();
     if (!h) return ASM_ERR_ARG;
     h->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess ||
+        hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, -1) != hipSuccess) {   // look-ahead chain: high priority
         delete h;
         return ASM_ERR_HIP;
     }
@@ -1279,6 +1313,8 @@ int asm_destroy(asm_handle* h) {
     for (auto& r : h->regions) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : h->event_pool) (void)hipEventDestroy(e);
     free_device(h);
+    for (auto e : h->la_events) (void)hipEventDestroy(e);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return ASM_OK;
