@@ -26,6 +26,7 @@ y_i >= 0 on GE rows, <= 0 on LE rows; z_j >= 0 at lower bound, <= 0 at upper bou
 """
 import numpy as np
 from scipy.linalg import solve_triangular
+from scipy.linalg.blas import dsyrk
 
 OPTIMAL, INFEASIBLE, DUAL_INFEASIBLE, OTHER = 1, 2, 3, 4   # values mirrored in include/asm_hip.h
 
@@ -92,6 +93,17 @@ def scale_lp(lp):
 
 # ----------------------------------------------------------------------------- Cholesky
 def chol_guard(S, diag0, thr=1e-14):
+    """LAPACK first: when no pivot comes near the guard the plain factor is the answer; otherwise the guarded loop."""
+    try:
+        Lf = np.linalg.cholesky(np.tril(S) + np.tril(S, -1).T)
+        if np.all(np.diag(Lf) ** 2 > 1e3 * thr * diag0):
+            return Lf
+    except np.linalg.LinAlgError:
+        pass
+    return _chol_guard_loop(S, diag0, thr)
+
+
+def _chol_guard_loop(S, diag0, thr=1e-14):
     """Lower Cholesky factor of SPD S (blocked, right-looking).  A pivot <= thr*diag0[j] is replaced
     by PIV_BIG**2 (row j is then effectively dropped from the solve: its unknown comes out as 0) -
     a static rule in elimination (index) order.  thr = 1e-14 inside the IPM (S is regularised there);
@@ -227,7 +239,7 @@ class IPM:
             dS = np.where(ineq, g / np.where(ineq, pi, 1.0), 0.0)
             if ns:
                 np.add.at(dS, lp.srow, ths_inv)
-            S = (A * thp_inv) @ A.T
+            S = dsyrk(1.0, A * np.sqrt(thp_inv), lower=True)          # lower triangle of A diag(thp_inv) A'
             idx = np.arange(M)
             S[idx, idx] += dS
             diag0 = S[idx, idx].copy()
