@@ -28,6 +28,10 @@ namespace {
 const double INF = std::numeric_limits<double>::infinity();
 const double TOL_P = 1e-9, TOL_D = 1e-6;
 const int IPM_MAXIT = 60;
+const int IPM_MCC = 2;           // Gondzio centrality correctors per iteration (oracle/lp_solver.py)
+const double MCC_DELTA = 0.3, MCC_BMIN = 0.1, MCC_BMAX = 10.0, MCC_GAMMA = 0.1;
+const int PCG_MAXIT = 20;       // conjugate-gradient steps per Newton solve (preconditioner = the Cholesky factor)
+const double PCG_KAPPA = 1e-3;  // Newton-system residual tolerance relative to the current primal residual
 const double IPM_RHO_P = 1e-8;   // primal proximal regularisation of the Newton system
 
 struct HipError : std::runtime_error {
@@ -57,6 +61,12 @@ typedef std::vector<int8_t> ivec;
 struct ActiveSet {
     ivec rowst, bst, sst;
     bool valid = false;
+};
+
+// adaptive decisions carried from one LP of a phase to the next (oracle/lp_solver.py: solve_scaled `hint`)
+struct SolveHint {
+    int warm_fail = 0, warm_skip = 0;
+    bool prefer_ref = false;
 };
 
 struct TimedRegion {
@@ -114,6 +124,8 @@ struct asm_handle {
 
     // ---- warm start (retained active set per phase; GLPK keeps its basis, slp.jl:38-40) ----
     ActiveSet warm[2];
+    SolveHint hint[2];
+    int64_t stats_pcg = 0;          // conjugate-gradient steps since creation (verbose diagnostics)
     ActiveSet last;
     asm_solve_stats stats;
 
@@ -521,13 +533,13 @@ struct Solver {
         bool stalled = false;
         int iters = 0;
         int status = ASM_OTHER;
-        double mu = 0, pinf = 0, dinf = 0, gap = 0, ymax = 0;
+        double mu = 0, pinf = 0, dinf = 0, gap = 0, ymax = 0, rpmax = 0;
     } ip;
 
     // ---- device-resident IPM state (asm_ipm_kernels.hip.h) ---------------------------------------------------
     IpmPtrs P;
     IpmDir dirA, dirC;
-    double *d_sres = nullptr, *d_corr = nullptr, *d_tN = nullptr;
+    double *d_sres = nullptr, *d_corr = nullptr, *d_tN = nullptr, *d_pcg = nullptr;
 
     void ipm_bind() {
         double* a = h->d_ipm;
@@ -545,7 +557,7 @@ struct Solver {
         P.r = r;
         P.g = Mv(); P.y = Mv(); P.pi = Mv(); P.act = Mv(); P.rp = Mv(); P.dS = Mv(); P.t1 = Mv(); P.rhs = Mv(); P.res = Mv(); P.rcg = Mv();
         dirA.dg = Mv(); dirA.dy = Mv(); dirA.dpi = Mv(); dirC.dg = Mv(); dirC.dy = Mv(); dirC.dpi = Mv();
-        d_sres = Mv(); d_corr = Mv();
+        d_sres = Mv(); d_corr = Mv(); d_pcg = Mv();
         double *w = Sv(), *slo = Sv(), *scoef = Sv();
         P.w = w; P.slo = slo; P.scoef = scoef;
         P.s = Sv(); P.ts = Sv(); P.mus = Sv(); P.rds = Sv(); P.ths_inv = Sv(); P.hs = Sv(); P.rcs = Sv();
@@ -601,6 +613,7 @@ struct Solver {
         ip.mu = h->h_scal[SC_MU];
         ip.gap = ip.mu / lp.scale_q;
         ip.ymax = h->h_scal[SC_YMAX];
+        ip.rpmax = h->h_scal[SC_RPMAX];
     }
 
     // pull the iterate back to the host (identification, certificates, unpolished fallback)
@@ -634,23 +647,40 @@ struct Solver {
         return ynr - lhs;
     }
 
-    // one Newton solve with the current factor (oracle: IPM.run.solve); mode 0 affine, 1 corrector
-    void ipm_solve(int mode, IpmDir& D) {
+    // one Newton solve with the current factor (oracle: IPM.run.solve); mode 0 affine, 1 Mehrotra corrector built on
+    // `base`, 2 Gondzio centrality corrector for `base` at the trial steps (tp, td)
+    void ipm_solve(int mode, const IpmDir& base, IpmDir& D, double tp = 0.0, double td = 0.0) {
         const unsigned g = grid_all();
         const int M = (int)lp.M;
-        hipLaunchKernelGGL(k_ipm_rhs1, dim3(g), dim3(256), 0, h->stream, P, dirA, mode);
+        hipLaunchKernelGGL(k_ipm_rhs1, dim3(g), dim3(256), 0, h->stream, P, base, mode, tp, td, MCC_BMIN, MCC_BMAX);
         dev.gemv_n_dev(h->d_Ah, P.tmpn, P.t1);
-        hipLaunchKernelGGL(k_ipm_rhs2, dim3(g), dim3(256), 0, h->stream, P);
+        hipLaunchKernelGGL(k_ipm_rhs2, dim3(g), dim3(256), 0, h->stream, P, mode == 2 ? 0.0 : 1.0);
         dev.chol_solve_dev(P.rhs, D.dy, M);
-        for (int it = 0; it < 2; ++it) {      // adaptive iterative refinement on the unregularised Schur system
-            dev.gemv_t_dev(h->d_Ah, D.dy, d_tN);
-            hipLaunchKernelGGL(k_vec_mul, dim3((unsigned)((lp.n + 255) / 256)), dim3(256), 0, h->stream, d_tN, P.thp_inv, lp.n);
-            dev.gemv_n_dev(h->d_Ah, d_tN, d_sres);
+        {
+            // preconditioned CG on the unregularised Schur system, the Cholesky factor as preconditioner (oracle: IPM.run.solve).
+            // The residual of this system is exactly the primal residual the step leaves behind, hence the tolerance.
+            auto applyS = [&](const double* v) {          // d_sres = Ah Th^-1 Ah' v
+                dev.gemv_t_dev(h->d_Ah, v, d_tN);
+                hipLaunchKernelGGL(k_vec_mul, dim3((unsigned)((lp.n + 255) / 256)), dim3(256), 0, h->stream, d_tN, P.thp_inv, lp.n);
+                dev.gemv_n_dev(h->d_Ah, d_tN, d_sres);
+            };
+            applyS(D.dy);
             hipLaunchKernelGGL(k_ipm_res, dim3(1), dim3(1024), 0, h->stream, P, d_sres, D.dy);
             read_scal();
-            if (h->h_scal[SC_EMAX] <= 1e-10 * h->h_scal[SC_RMAX]) break;
-            dev.chol_solve_dev(P.res, d_corr, M);
-            hipLaunchKernelGGL(k_vec_add, dim3((unsigned)((lp.M + 255) / 256)), dim3(256), 0, h->stream, D.dy, d_corr, lp.M);
+            const double tol = std::max(1e-10 * h->h_scal[SC_RMAX], PCG_KAPPA * ip.rpmax);
+            if (h->h_scal[SC_EMAX] > tol) {
+                dev.chol_solve_dev(P.res, d_corr, M);
+                hipLaunchKernelGGL(k_pcg_start, dim3(1), dim3(1024), 0, h->stream, P, d_corr, d_pcg);
+                for (int it = 0; it < PCG_MAXIT; ++it) {
+                    applyS(d_pcg);
+                    hipLaunchKernelGGL(k_pcg_step1, dim3(1), dim3(1024), 0, h->stream, P, d_sres, d_pcg, D.dy);
+                    read_scal();
+                    h->stats_pcg += 1;
+                    if (h->h_scal[SC_STOP] != 0.0 || h->h_scal[SC_EMAX] <= tol) break;
+                    dev.chol_solve_dev(P.res, d_corr, M);
+                    hipLaunchKernelGGL(k_pcg_step2, dim3(1), dim3(1024), 0, h->stream, P, d_corr, d_pcg);
+                }
+            }
         }
         dev.gemv_t_dev(h->d_Ah, D.dy, d_tN);
         hipLaunchKernelGGL(k_ipm_dir, dim3(g), dim3(256), 0, h->stream, P, D, d_tN);
@@ -681,12 +711,29 @@ struct Solver {
             dev.chol(M);
             ip.iters += 1;
             done += 1;
-            ipm_solve(0, dirA);
-            hipLaunchKernelGGL(k_ipm_steps, dim3(1), dim3(1024), 0, h->stream, P, dirA, 0);
+            ipm_solve(0, dirA, dirA);
+            hipLaunchKernelGGL(k_ipm_steps, dim3(1), dim3(1024), 0, h->stream, P, dirA);
             hipLaunchKernelGGL(k_ipm_muaff, dim3(1), dim3(1024), 0, h->stream, P, dirA);
-            ipm_solve(1, dirC);
-            hipLaunchKernelGGL(k_ipm_steps, dim3(1), dim3(1024), 0, h->stream, P, dirC, 1);
-            hipLaunchKernelGGL(k_ipm_update, dim3(grid_all()), dim3(256), 0, h->stream, P, dirC);
+            ipm_solve(1, dirA, dirC);
+            hipLaunchKernelGGL(k_ipm_steps, dim3(1), dim3(1024), 0, h->stream, P, dirC);
+            read_scal();
+            double ap = h->h_scal[SC_AP], ad = h->h_scal[SC_AD];
+            // Gondzio multiple centrality correctors (oracle: IPM.run): dirA is free again and receives the candidate
+            for (int kc = 0; kc < IPM_MCC; ++kc) {
+                    if (std::min(ap, ad) >= 0.9) break;
+                const double tp = std::min(1.0, ap + MCC_DELTA), td = std::min(1.0, ad + MCC_DELTA);
+                ipm_solve(2, dirC, dirA, tp, td);
+                hipLaunchKernelGGL(k_ipm_diradd, dim3(grid_all()), dim3(256), 0, h->stream, P, dirA, dirC);
+                hipLaunchKernelGGL(k_ipm_steps, dim3(1), dim3(1024), 0, h->stream, P, dirA);
+                read_scal();
+                const double ap2 = h->h_scal[SC_AP], ad2 = h->h_scal[SC_AD];
+                if (!(ap2 >= ap && ad2 >= ad && ap2 + ad2 >= ap + ad + MCC_GAMMA * MCC_DELTA)) break;
+                std::swap(dirA, dirC);
+                ap = ap2; ad = ad2;
+            }
+            if (h->verbose) std::fprintf(stderr, "[asm]     ap %.3e ad %.3e  cg steps so far %lld\n", ap, ad, (long long)h->stats_pcg);
+            const double eta = ip.mu >= 1.0 ? 0.995 : std::min(std::max(0.995, 1.0 - ip.mu / lp.scale_q), 0.999999);
+            hipLaunchKernelGGL(k_ipm_update, dim3(grid_all()), dim3(256), 0, h->stream, P, dirC, std::min(1.0, eta * ap), std::min(1.0, eta * ad));
         }
     }
 
@@ -901,23 +948,30 @@ struct Solver {
     // oracle: solve_scaled
     double t_warm = 0, t_ipm = 0, t_polish = 0;
     static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-    int solve_scaled(const ActiveSet* warm, EqpOut& o, ActiveSet& out_as) {
-        int st = solve_scaled_impl(warm, o, out_as);
+    int solve_scaled(const ActiveSet* warm, SolveHint& hint, EqpOut& o, ActiveSet& out_as) {
+        int st = solve_scaled_impl(warm, hint, o, out_as);
         if (h->verbose) std::fprintf(stderr, "[asm] phases: warm %.2f ms, ipm %.2f ms (%d its), polish %.2f ms\n", t_warm, t_ipm, ip.iters, t_polish);
         return st;
     }
-    int solve_scaled_impl(const ActiveSet* warm, EqpOut& o, ActiveSet& out_as) {
+    int solve_scaled_impl(const ActiveSet* warm, SolveHint& hint, EqpOut& o, ActiveSet& out_as) {
         const int64_t n = lp.n, M = lp.M, ns = lp.ns;
         vec zero_p(n), zero_y(M, 0.0);
         for (int64_t j = 0; j < n; ++j) zero_p[j] = std::min(std::max(0.0, lp.lb[j]), lp.ub[j]);
         h->stats.path = -1;
         h->stats.polished = 1;
         if (warm && warm->valid && (int64_t)warm->rowst.size() == M && (int64_t)warm->bst.size() == n && (int64_t)warm->sst.size() == ns) {
-            double t0 = now_ms();
-            bool okw = eqp_loop(*warm, zero_p, zero_y, 1, o, out_as);
-            t_warm += now_ms() - t0;
-            if (okw) { h->stats.path = 0; return ASM_OPTIMAL; }
+            if (hint.warm_skip > 0) {
+                hint.warm_skip -= 1;
+            } else {
+                double t0 = now_ms();
+                bool okw = eqp_loop(*warm, zero_p, zero_y, 1, o, out_as);
+                t_warm += now_ms() - t0;
+                if (okw) { hint.warm_fail = 0; h->stats.path = 0; return ASM_OPTIMAL; }
+                hint.warm_fail = std::min(hint.warm_fail + 1, 3);
+                hint.warm_skip = hint.warm_fail;
+            }
         }
+        const bool prefer_ref = hint.prefer_ref;
         ipm_init();
         const double tols[3] = {1e-8, 1e-10, 1e-12};
         const int more[3] = {IPM_MAXIT, 6, 6};
@@ -942,18 +996,27 @@ struct Solver {
                 if (lp.ns == 0 && phase1_infeasible()) { h->stats.path = 7; return ASM_INFEASIBLE; }
                 break;
             }
+            if (prefer_ref && stage + 1 < 3) continue;      // straight on to the last stage
             double t1 = now_ms();
             ipm_download();
             identify(sets0);
             have_sets = true;
+            if (prefer_ref) break;
             bool okp = eqp_loop(sets0, zero_p, zero_y, 2, o, out_as);
             t_polish += now_ms() - t1;
             if (okp) { h->stats.path = 1 + stage; return ASM_OPTIMAL; }
         }
         if (have_sets) {
+            double t1 = now_ms();
             vec pc(n);
             for (int64_t j = 0; j < n; ++j) pc[j] = std::min(std::max(ip.p[j], lp.lb[j]), lp.ub[j]);
-            if (eqp_loop(sets0, pc, ip.y, 2, o, out_as)) { h->stats.path = 4; return ASM_OPTIMAL; }
+            bool okr = eqp_loop(sets0, pc, ip.y, 2, o, out_as);
+            t_polish += now_ms() - t1;
+            if (okr) { hint.prefer_ref = true; h->stats.path = 4; return ASM_OPTIMAL; }
+            hint.prefer_ref = false;
+            if (prefer_ref) {                               // the least-norm polish has not been tried on this LP yet
+                if (eqp_loop(sets0, zero_p, zero_y, 2, o, out_as)) { h->stats.path = 3; return ASM_OPTIMAL; }
+            }
         }
         h->stats.path = 5;
         h->stats.polished = 0;
@@ -1092,7 +1155,7 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     dmalloc(&h->d_nz, (h->Mp / 32 + 1) * (h->ldn / ASM_KC + 1));
     h->nsp = round_up(std::max<int64_t>(h->ns, 1), 16);
     {
-        int64_t nd = 24 * h->ldn + 22 * h->Mp + 16 * h->nsp + 64;
+        int64_t nd = 24 * h->ldn + 23 * h->Mp + 16 * h->nsp + 64;
         dmalloc(&h->d_ipm, nd);
         HIPCHK(hipMemsetAsync(h->d_ipm, 0, nd * sizeof(double), h->stream));
         dmalloc(&h->d_ipm_i, 3 * h->Mp + h->nsp);
@@ -1121,6 +1184,7 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     h->warm[0] = ActiveSet(); h->warm[1] = ActiveSet(); h->last = ActiveSet();
+    h->hint[0] = SolveHint(); h->hint[1] = SolveHint();
     std::memset(&h->stats, 0, sizeof(h->stats));
     h->setup_done = true;
 }
@@ -1205,7 +1269,7 @@ void do_solve(asm_handle* h, double delta, int feasibility, double* p_out, doubl
 
     Solver::EqpOut o;
     ActiveSet as;
-    int st = sv.solve_scaled(&h->warm[fr ? 1 : 0], o, as);
+    int st = sv.solve_scaled(&h->warm[fr ? 1 : 0], h->hint[fr ? 1 : 0], o, as);
     *status = st;
 
     for (int64_t j = 0; j < n; ++j) { p_out[j] = 0.0; mult_x_U[j] = 0.0; mult_x_L[j] = 0.0; }
@@ -1372,6 +1436,8 @@ int asm_sublp_reset_warm(asm_handle* h) {
     if (!h) return ASM_ERR_ARG;
     h->warm[0] = ActiveSet();
     h->warm[1] = ActiveSet();
+    h->hint[0] = SolveHint();
+    h->hint[1] = SolveHint();
     return ASM_OK;
 }
 

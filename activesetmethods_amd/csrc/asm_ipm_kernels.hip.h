@@ -21,7 +21,7 @@ struct IpmPtrs {
 struct IpmDir {
     double *dp, *ds, *dg, *dy, *dmuL, *dmuU, *dmus, *dpi;
 };
-enum { SC_PINF = 0, SC_DINF, SC_MU, SC_YMAX, SC_AP, SC_AD, SC_SM, SC_ALPHA, SC_EMAX, SC_RMAX, SC_COUNT };
+enum { SC_PINF = 0, SC_DINF, SC_MU, SC_YMAX, SC_AP, SC_AD, SC_SM, SC_ALPHA, SC_EMAX, SC_RMAX, SC_RZ, SC_RPMAX, SC_RZ0, SC_STOP, SC_COUNT };
 
 __device__ __forceinline__ double blk_reduce_max(double v, double* sh) {
     v = wave_max(v);
@@ -79,7 +79,7 @@ __device__ __forceinline__ double slack_sum(const IpmPtrs& P, int64_t i, const d
 // residuals + convergence measures; act = Ah p and aty = Ah' y were produced by the gemv kernels
 __global__ __launch_bounds__(1024) void k_ipm_measures(IpmPtrs P) {
     __shared__ double sh[16];
-    double pinf = 0.0, dinf = 0.0, mu = 0.0, ymax = 0.0;
+    double pinf = 0.0, dinf = 0.0, mu = 0.0, ymax = 0.0, rpmax = 0.0;
     for (int64_t i = threadIdx.x; i < P.M; i += 1024) {
         bool ineq = P.rtype[i] != 0;
         double sg = (double)P.rtype[i];
@@ -87,6 +87,7 @@ __global__ __launch_bounds__(1024) void k_ipm_measures(IpmPtrs P) {
         double rp = a - (P.r[i] + sg * (ineq ? P.g[i] : 0.0));
         P.rp[i] = rp;
         pinf = fmax(pinf, fabs(rp) / (1.0 + fabs(P.r[i])));
+        rpmax = fmax(rpmax, fabs(rp));
         if (ineq) mu += P.g[i] * P.pi[i];
         ymax = fmax(ymax, fabs(P.y[i]));
     }
@@ -106,12 +107,14 @@ __global__ __launch_bounds__(1024) void k_ipm_measures(IpmPtrs P) {
     pinf = blk_reduce_max(pinf, sh);
     dinf = blk_reduce_max(dinf, sh);
     ymax = blk_reduce_max(ymax, sh);
+    rpmax = blk_reduce_max(rpmax, sh);
     mu = blk_reduce_sum(mu, sh);
     if (threadIdx.x == 0) {
         P.scal[SC_PINF] = pinf;
         P.scal[SC_DINF] = dinf / P.scale_q;
         P.scal[SC_MU] = mu / (double)P.ncomp;
         P.scal[SC_YMAX] = ymax;
+        P.scal[SC_RPMAX] = rpmax;
     }
 }
 
@@ -133,42 +136,66 @@ __global__ __launch_bounds__(256) void k_ipm_theta(IpmPtrs P, double rho_p) {
     }
 }
 
-// complementarity right-hand sides (mode 0: affine, mode 1: corrector with the affine direction A) and hp, hs, theta*hp
-__global__ __launch_bounds__(256) void k_ipm_rhs1(IpmPtrs P, IpmDir A, int mode) {
+// complementarity right-hand sides and hp, hs, theta*hp.
+//   mode 0: affine (predictor);  mode 1: Mehrotra corrector with the affine direction A;
+//   mode 2: Gondzio centrality corrector for the direction A at the trial step (tp, td): the products of the trial
+//           point are projected onto [lo, hi], the residual terms rp / rdp / rds are dropped (oracle: IPM.run, corr()).
+__device__ __forceinline__ double mcc_term(double x, double dx, double z, double dz, double lo, double hi) {
+    double v = (x + dx) * (z + dz);
+    return fmax(fmin(fmax(v, lo), hi) - v, -hi);
+}
+__global__ __launch_bounds__(256) void k_ipm_rhs1(IpmPtrs P, IpmDir A, int mode, double tp, double td, double bmin, double bmax) {
     int64_t t = blockIdx.x * 256 + threadIdx.x;
     const double sm = mode ? P.scal[SC_SM] : 0.0;
+    const double lo = bmin * sm, hi = bmax * sm;
+    const double res = mode == 2 ? 0.0 : 1.0;
     if (t < P.n) {
         bool fr = P.ub[t] > P.lb[t];
-        double rcL = sm - P.tL[t] * P.muL[t], rcU = sm - P.tU[t] * P.muU[t];
-        if (mode) {
-            rcL -= A.dp[t] * A.dmuL[t];
-            rcU += A.dp[t] * A.dmuU[t];
+        double rcL, rcU;
+        if (mode == 2) {
+            rcL = fr ? mcc_term(P.tL[t], tp * A.dp[t], P.muL[t], td * A.dmuL[t], lo, hi) : 0.0;
+            rcU = fr ? mcc_term(P.tU[t], tp * -A.dp[t], P.muU[t], td * A.dmuU[t], lo, hi) : 0.0;
+        } else {
+            rcL = sm - P.tL[t] * P.muL[t];
+            rcU = sm - P.tU[t] * P.muU[t];
+            if (mode) {
+                rcL -= A.dp[t] * A.dmuL[t];
+                rcU += A.dp[t] * A.dmuU[t];
+            }
         }
         P.rcL[t] = rcL;
         P.rcU[t] = rcU;
-        double hp = fr ? -P.rdp[t] + rcL / P.tL[t] - rcU / P.tU[t] : 0.0;
+        double hp = fr ? -res * P.rdp[t] + rcL / P.tL[t] - rcU / P.tU[t] : 0.0;
         P.hp[t] = hp;
         P.tmpn[t] = P.thp_inv[t] * hp;
     }
     if (t < P.ns) {
-        double rcs = sm - P.ts[t] * P.mus[t];
-        if (mode) rcs -= A.ds[t] * A.dmus[t];
+        double rcs;
+        if (mode == 2) rcs = mcc_term(P.ts[t], tp * A.ds[t], P.mus[t], td * A.dmus[t], lo, hi);
+        else {
+            rcs = sm - P.ts[t] * P.mus[t];
+            if (mode) rcs -= A.ds[t] * A.dmus[t];
+        }
         P.rcs[t] = rcs;
-        P.hs[t] = -P.rds[t] + rcs / P.ts[t];
+        P.hs[t] = -res * P.rds[t] + rcs / P.ts[t];
     }
     if (t < P.M) {
-        double rcg = sm - P.g[t] * P.pi[t];
-        if (mode) rcg -= A.dg[t] * A.dpi[t];
+        double rcg;
+        if (mode == 2) rcg = P.rtype[t] != 0 ? mcc_term(P.g[t], tp * A.dg[t], P.pi[t], td * A.dpi[t], lo, hi) : 0.0;
+        else {
+            rcg = sm - P.g[t] * P.pi[t];
+            if (mode) rcg -= A.dg[t] * A.dpi[t];
+        }
         P.rcg[t] = rcg;
     }
 }
 
 // rhs = -rp - Ah(theta hp) + sg rcg/pi - E(ths hs)
-__global__ __launch_bounds__(256) void k_ipm_rhs2(IpmPtrs P) {
+__global__ __launch_bounds__(256) void k_ipm_rhs2(IpmPtrs P, double res) {
     int64_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P.M) return;
     bool ineq = P.rtype[i] != 0;
-    double v = -P.rp[i] - P.t1[i] + (ineq ? (double)P.rtype[i] * P.rcg[i] / P.pi[i] : 0.0);
+    double v = -res * P.rp[i] - P.t1[i] + (ineq ? (double)P.rtype[i] * P.rcg[i] / P.pi[i] : 0.0);
     if (P.ns) {
         int k0 = P.rs0[i], k1 = P.rs1[i];
         if (k0 >= 0) v -= P.scoef[k0] * P.ths_inv[k0] * P.hs[k0];
@@ -204,6 +231,59 @@ __global__ __launch_bounds__(1024) void k_ipm_res(IpmPtrs P, const double* __res
     }
 }
 
+// ---- preconditioned conjugate gradients on  S dy = rhs,  S = Ah Th^-1 Ah' + dS,  preconditioner = the Cholesky factor.
+// p = z ; rz = r'z
+__global__ __launch_bounds__(1024) void k_pcg_start(IpmPtrs P, const double* __restrict__ z, double* __restrict__ p) {
+    __shared__ double sh[16];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < P.M; i += 1024) {
+        double zi = z[i];
+        p[i] = zi;
+        acc += P.res[i] * zi;
+    }
+    acc = blk_reduce_sum(acc, sh);
+    if (threadIdx.x == 0) {
+        P.scal[SC_RZ] = acc;
+        P.scal[SC_RZ0] = acc;
+        P.scal[SC_STOP] = 0.0;
+    }
+}
+// Sp = sres + dS p ; alpha = rz / p'Sp ; x += alpha p ; r -= alpha Sp ; scal[EMAX] = max|r|
+__global__ __launch_bounds__(1024) void k_pcg_step1(IpmPtrs P, const double* __restrict__ sres, const double* __restrict__ p,
+                                                    double* __restrict__ x) {
+    __shared__ double sh[16];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < P.M; i += 1024) acc += p[i] * (sres[i] + P.dS[i] * p[i]);
+    acc = blk_reduce_sum(acc, sh);
+    const double rz = P.scal[SC_RZ];
+    if (!(acc > 0.0 && rz > 1e-30 * P.scal[SC_RZ0] && rz < 1e12 * acc)) {   // breakdown: the rest of the residual is outside range(S)
+        if (threadIdx.x == 0) P.scal[SC_STOP] = 1.0;
+        return;
+    }
+    const double alpha = rz / acc;
+    double emax = 0.0;
+    for (int64_t i = threadIdx.x; i < P.M; i += 1024) {
+        double pi = p[i];
+        x[i] += alpha * pi;
+        double r = P.res[i] - alpha * (sres[i] + P.dS[i] * pi);
+        P.res[i] = r;
+        emax = fmax(emax, fabs(r));
+    }
+    emax = blk_reduce_max(emax, sh);
+    if (threadIdx.x == 0) P.scal[SC_EMAX] = emax;
+}
+// beta = r'z / rz_old ; p = z + beta p ; rz = r'z
+__global__ __launch_bounds__(1024) void k_pcg_step2(IpmPtrs P, const double* __restrict__ z, double* __restrict__ p) {
+    __shared__ double sh[16];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < P.M; i += 1024) acc += P.res[i] * z[i];
+    acc = blk_reduce_sum(acc, sh);
+    const double beta = acc / P.scal[SC_RZ];
+    for (int64_t i = threadIdx.x; i < P.M; i += 1024) p[i] = z[i] + beta * p[i];
+    __syncthreads();
+    if (threadIdx.x == 0) P.scal[SC_RZ] = acc;
+}
+
 // Newton direction from dy and aty2 = Ah' dy (in P.aty is NOT touched; tN holds Ah' dy)
 __global__ __launch_bounds__(256) void k_ipm_dir(IpmPtrs P, IpmDir D, const double* __restrict__ tN) {
     int64_t t = blockIdx.x * 256 + threadIdx.x;
@@ -229,8 +309,8 @@ __global__ __launch_bounds__(256) void k_ipm_dir(IpmPtrs P, IpmDir D, const doub
 
 __device__ __forceinline__ double ratio(double x, double dx) { return dx < 0.0 ? -x / dx : 1e300; }
 
-// step lengths to the boundary (ap primal, ad dual); mode 1 additionally: alpha = min(1, eta min(ap, ad))
-__global__ __launch_bounds__(1024) void k_ipm_steps(IpmPtrs P, IpmDir D, int mode) {
+// step lengths to the boundary (ap primal, ad dual), each capped at 1
+__global__ __launch_bounds__(1024) void k_ipm_steps(IpmPtrs P, IpmDir D) {
     __shared__ double sh[16];
     double ap = 1e300, ad = 1e300;
     for (int64_t j = threadIdx.x; j < P.n; j += 1024) {
@@ -252,11 +332,6 @@ __global__ __launch_bounds__(1024) void k_ipm_steps(IpmPtrs P, IpmDir D, int mod
     if (threadIdx.x == 0) {
         P.scal[SC_AP] = ap;
         P.scal[SC_AD] = ad;
-        if (mode) {
-            double mu = P.scal[SC_MU];
-            double eta = mu >= 1.0 ? 0.995 : fmin(fmax(0.995, 1.0 - mu / P.scale_q), 0.999999);
-            P.scal[SC_ALPHA] = fmin(1.0, eta * fmin(ap, ad));
-        }
     }
 }
 
@@ -281,28 +356,47 @@ __global__ __launch_bounds__(1024) void k_ipm_muaff(IpmPtrs P, IpmDir A) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_ipm_update(IpmPtrs P, IpmDir C) {
+// D += E (candidate direction of a centrality corrector)
+__global__ __launch_bounds__(256) void k_ipm_diradd(IpmPtrs P, IpmDir D, IpmDir E) {
     int64_t t = blockIdx.x * 256 + threadIdx.x;
-    const double al = P.scal[SC_ALPHA];
+    if (t < P.n) {
+        D.dp[t] += E.dp[t];
+        D.dmuL[t] += E.dmuL[t];
+        D.dmuU[t] += E.dmuU[t];
+    }
+    if (t < P.ns) {
+        D.ds[t] += E.ds[t];
+        D.dmus[t] += E.dmus[t];
+    }
+    if (t < P.M) {
+        D.dg[t] += E.dg[t];
+        D.dy[t] += E.dy[t];
+        D.dpi[t] += E.dpi[t];
+    }
+}
+
+// iterate += (al primal, be dual) * direction
+__global__ __launch_bounds__(256) void k_ipm_update(IpmPtrs P, IpmDir C, double al, double be) {
+    int64_t t = blockIdx.x * 256 + threadIdx.x;
     if (t < P.n) {
         bool fr = P.ub[t] > P.lb[t];
         P.p[t] += al * C.dp[t];
         P.tL[t] = fr ? P.tL[t] + al * C.dp[t] : 1.0;
         P.tU[t] = fr ? P.tU[t] - al * C.dp[t] : 1.0;
-        P.muL[t] += al * C.dmuL[t];
-        P.muU[t] += al * C.dmuU[t];
+        P.muL[t] += be * C.dmuL[t];
+        P.muU[t] += be * C.dmuU[t];
     }
     if (t < P.ns) {
         P.s[t] += al * C.ds[t];
         P.ts[t] += al * C.ds[t];
-        P.mus[t] += al * C.dmus[t];
+        P.mus[t] += be * C.dmus[t];
     }
     if (t < P.M) {
         bool ineq = P.rtype[t] != 0;
         P.g[t] = ineq ? P.g[t] + al * C.dg[t] : 1.0;
-        double pi = P.pi[t] + al * C.dpi[t];
+        double pi = P.pi[t] + be * C.dpi[t];
         P.pi[t] = pi;
-        P.y[t] = ineq ? (double)P.rtype[t] * pi : P.y[t] + al * C.dy[t];
+        P.y[t] = ineq ? (double)P.rtype[t] * pi : P.y[t] + be * C.dy[t];
     }
 }
 

@@ -15,9 +15,9 @@ Algorithm (all decisions deterministic, no randomisation):
   0. power-of-two row/column/objective scaling (exact in binary floating point);
   1. warm path: re-use the previous call's active set, solve the equality-constrained problem on it
      (active-set Schur complement  S = A_HF A_HF' , Cholesky/LDLt, two solves) and accept if it
-     passes the LP optimality check;
-  2. otherwise a Mehrotra predictor-corrector interior-point method in row (Schur) form
-     S = A Th^-1 A' + D, to 1e-8, which identifies the optimal partition;
+     passes the LP optimality check (skipped for a few solves after repeated failures);
+  2. otherwise a Mehrotra predictor-corrector interior-point method with Gondzio's multiple centrality
+     correctors in row (Schur) form S = A Th^-1 A' + D, to 1e-8, which identifies the optimal partition;
   3. active-set polish: the same Schur solve on the identified set gives the vertex and its
      multipliers to ~1e-13; a short correction loop (drop wrong-sign multipliers, add violated
      constraints) repairs near-degenerate mis-identifications.
@@ -34,7 +34,10 @@ TOL_P = 1e-9      # primal feasibility of the accepted vertex (scaled units)
 TOL_D = 1e-6      # dual feasibility of the accepted vertex (scaled units)
 IPM_TOL = 1e-8
 IPM_MAXIT = 60
-IPM_REFINE = 2
+PCG_MAXIT = 20       # conjugate-gradient steps per Newton solve
+PCG_KAPPA = 1e-3     # Newton-system residual tolerance relative to the current primal residual
+IPM_MCC = 2          # Gondzio multiple centrality correctors per iteration (a solve costs ~1/50 of a factorisation)
+MCC_DELTA, MCC_BMIN, MCC_BMAX, MCC_GAMMA = 0.3, 0.1, 10.0, 0.1
 IPM_RHO_P = 1e-8     # primal proximal regularisation of the Newton system (bounds Theta^-1 for effectively free variables)
 CHOL_NB = 64
 PIV_BIG = 1e128
@@ -162,7 +165,8 @@ def farkas_margin(lp, y):
 
 
 class IPM:
-    """Mehrotra predictor-corrector, single primal/dual step length, Schur (row) form.
+    """Mehrotra predictor-corrector + Gondzio multiple centrality correctors, separate primal / dual step
+    lengths, Schur (row) form.
     Resumable: `run(tol, max_more)` continues from the current iterate."""
 
     def __init__(self, lp):
@@ -234,6 +238,7 @@ class IPM:
                 return self.status
             tL, tU, ts, g, pi, muL, muU, mus = self.tL, self.tU, self.ts, self.g, self.pi, self.muL, self.muU, self.mus
             rp, rdp, rds, mu = self.rp, self.rdp, self.rds, self.mu
+            rpmax = float(np.abs(rp).max(initial=0.0))
             thp_inv = np.where(free, 1.0 / np.where(free, muL / tL + muU / tU + IPM_RHO_P, 1.0), 0.0)
             ths_inv = ts / mus
             dS = np.where(ineq, g / np.where(ineq, pi, 1.0), 0.0)
@@ -248,20 +253,38 @@ class IPM:
             self.iters += 1
             done += 1
 
-            def solve(rcL, rcU, rcs, rcg):
-                hp = np.where(free, -rdp + rcL / tL - rcU / tU, 0.0)
-                hs = -rds + rcs / ts
-                rhs = -rp - A @ (thp_inv * hp) + np.where(ineq, sg * rcg / np.where(ineq, pi, 1.0), 0.0)
+            def solve(rcL, rcU, rcs, rcg, res=1.0):
+                hp = np.where(free, -res * rdp + rcL / tL - rcU / tU, 0.0)
+                hs = -res * rds + rcs / ts
+                rhs = -res * rp - A @ (thp_inv * hp) + np.where(ineq, sg * rcg / np.where(ineq, pi, 1.0), 0.0)
                 if ns:
                     tmp = np.zeros(M)
                     np.add.at(tmp, lp.srow, lp.scoef * ths_inv * hs)
                     rhs -= tmp
                 dy = chol_solve(L, rhs)
-                for _ in range(IPM_REFINE):              # adaptive iterative refinement on the unregularised S
-                    res = rhs - (A @ (thp_inv * (A.T @ dy)) + dS * dy)
-                    if np.abs(res).max(initial=0.0) <= 1e-10 * max(1.0, np.abs(rhs).max(initial=0.0)):
-                        break
-                    dy = dy + chol_solve(L, res)
+                # preconditioned CG on the unregularised S (preconditioner = the Cholesky factor).  The residual of this
+                # system is exactly the primal residual the step leaves behind, hence the tolerance.
+                res = rhs - (A @ (thp_inv * (A.T @ dy)) + dS * dy)
+                tol = max(1e-10 * max(1.0, np.abs(rhs).max(initial=0.0)), PCG_KAPPA * rpmax)
+                if np.abs(res).max(initial=0.0) > tol:
+                    z = chol_solve(L, res)
+                    pv = z.copy()
+                    rz = rz0 = float(res @ z)
+                    for _ in range(PCG_MAXIT):
+                        Sp = A @ (thp_inv * (A.T @ pv)) + dS * pv
+                        pSp = float(pv @ Sp)
+                        if not (pSp > 0.0 and rz > 1e-30 * rz0 and rz < 1e12 * pSp):
+                            break                         # breakdown: the rest of the residual is outside range(S)
+                        alpha = rz / pSp
+                        dy = dy + alpha * pv
+                        res = res - alpha * Sp
+                        if np.abs(res).max(initial=0.0) <= tol:
+                            break
+                        z = chol_solve(L, res)
+                        rzn = float(res @ z)
+                        beta = rzn / rz
+                        pv = z + beta * pv
+                        rz = rzn
                 dp = thp_inv * (hp + A.T @ dy)
                 ds = ths_inv * (hs + lp.scoef * dy[lp.srow])
                 dmuL = np.where(free, (rcL - muL * dp) / tL, 0.0)
@@ -288,18 +311,38 @@ class IPM:
                                                           sm - ts * mus - ds * dmus, sm - g * pi - dg * dpi)
             eta = 0.995 if mu >= 1.0 else min(max(0.995, 1.0 - mu / self.scale_q), 0.999999)
             ap, ad = steps(dp, ds, dg, dmuL, dmuU, dmus, dpi)
-            a = min(1.0, eta * min(ap, ad))
+            for _kc in range(IPM_MCC):                    # Gondzio multiple centrality correctors
+                if min(ap, ad) >= 0.9:
+                    break
+                tp, td = min(1.0, ap + MCC_DELTA), min(1.0, ad + MCC_DELTA)
+                lo, hi = MCC_BMIN * sm, MCC_BMAX * sm
+
+                def corr(x, dx, z, dz):
+                    v = (x + tp * dx) * (z + td * dz)
+                    return np.maximum(np.minimum(np.maximum(v, lo), hi) - v, -hi)
+                cL = np.where(free, corr(tL, dp, muL, dmuL), 0.0)
+                cU = np.where(free, corr(tU, -dp, muU, dmuU), 0.0)
+                cs = corr(ts, ds, mus, dmus)
+                cg = np.where(ineq, corr(g, dg, pi, dpi), 0.0)
+                e = solve(cL, cU, cs, cg, 0.0)
+                cand = [u + v for u, v in zip((dp, ds, dg, dy, dmuL, dmuU, dmus, dpi), e)]
+                ap2, ad2 = steps(cand[0], cand[1], cand[2], cand[4], cand[5], cand[6], cand[7])
+                if not (ap2 >= ap and ad2 >= ad and ap2 + ad2 >= ap + ad + MCC_GAMMA * MCC_DELTA):
+                    break
+                dp, ds, dg, dy, dmuL, dmuU, dmus, dpi = cand
+                ap, ad = ap2, ad2
+            a, b = min(1.0, eta * ap), min(1.0, eta * ad)      # separate primal / dual step lengths
             self.p = self.p + a * dp
             self.s = self.s + a * ds
             self.g = np.where(ineq, g + a * dg, 1.0)
             self.tL = np.where(free, tL + a * dp, 1.0)
             self.tU = np.where(free, tU - a * dp, 1.0)
             self.ts = ts + a * ds
-            self.muL = muL + a * dmuL
-            self.muU = muU + a * dmuU
-            self.mus = mus + a * dmus
-            self.pi = pi + a * dpi
-            self.y = np.where(ineq, sg * self.pi, self.y + a * dy)
+            self.muL = muL + b * dmuL
+            self.muU = muU + b * dmuU
+            self.mus = mus + b * dmus
+            self.pi = pi + b * dpi
+            self.y = np.where(ineq, sg * self.pi, self.y + b * dy)
 
 
 # ----------------------------------------------------------------------------- active-set machinery
@@ -481,17 +524,31 @@ def phase1_infeasible(lp, stats):
     return farkas_margin(lp, ip.y) > 1e-9
 
 
-def solve_scaled(lp, warm=None, stats=None):
+def solve_scaled(lp, warm=None, stats=None, hint=None):
+    """`hint` (dict, updated in place) carries two adaptive decisions from one LP of a phase to the next:
+      warm_fail / warm_skip : after k consecutive failed warm attempts the next min(k,3) solves skip the attempt;
+      prefer_ref            : the last LP was only polishable from the interior-point iterate (non-unique
+                              optimum, typical of the restoration LPs) -> run the IPM straight to the last stage and
+                              try that polish first."""
     if stats is None:
         stats = {}
+    if hint is None:
+        hint = {}
     stats.update(nfact=0, eqp=0, ipm_iters=0, path='', polished=1)
     zero_p = np.clip(np.zeros(lp.n), lp.lb, lp.ub)
     zero_y = np.zeros(lp.M)
     if warm is not None and len(warm[0]) == lp.M and len(warm[1]) == lp.n and len(warm[2]) == lp.ns:
-        ok, p, s, y, sets = eqp_loop(lp, warm, zero_p, zero_y, 1, stats)
-        if ok:
-            stats['path'] = 'warm'
-            return OPTIMAL, p, s, y, sets
+        if hint.get('warm_skip', 0) > 0:
+            hint['warm_skip'] -= 1
+        else:
+            ok, p, s, y, sets = eqp_loop(lp, warm, zero_p, zero_y, 1, stats)
+            if ok:
+                hint['warm_fail'] = 0
+                stats['path'] = 'warm'
+                return OPTIMAL, p, s, y, sets
+            hint['warm_fail'] = min(hint.get('warm_fail', 0) + 1, 3)
+            hint['warm_skip'] = hint['warm_fail']
+    prefer_ref = bool(hint.get('prefer_ref', False))
     ip = IPM(lp)
     sets0 = None
     for stage, (tol, more) in enumerate(IPM_STAGES):
@@ -515,7 +572,11 @@ def solve_scaled(lp, warm=None, stats=None):
                 stats['path'] = 'phase1-infeasible'
                 return INFEASIBLE, None, None, None, None
             break                                   # never reached 1e-8: no identification attempt
+        if prefer_ref and stage + 1 < len(IPM_STAGES):
+            continue                                # straight on to the last stage
         sets0 = identify(lp, ip)
+        if prefer_ref:
+            break
         ok, p, s, y, sets = eqp_loop(lp, sets0, zero_p, zero_y, 2, stats)
         if ok:
             stats['path'] = 'ipm%d+ln' % stage
@@ -523,8 +584,15 @@ def solve_scaled(lp, warm=None, stats=None):
     if sets0 is not None:
         ok, p, s, y, sets = eqp_loop(lp, sets0, np.clip(ip.p, lp.lb, lp.ub), ip.y, 2, stats)
         if ok:
+            hint['prefer_ref'] = True
             stats['path'] = 'ipm+ref'
             return OPTIMAL, p, s, y, sets
+        hint['prefer_ref'] = False
+        if prefer_ref:                              # the least-norm polish has not been tried on this LP yet
+            ok, p, s, y, sets = eqp_loop(lp, sets0, zero_p, zero_y, 2, stats)
+            if ok:
+                stats['path'] = 'ipm%d+ln' % (len(IPM_STAGES) - 1)
+                return OPTIMAL, p, s, y, sets
     stats['path'] = 'ipm-unpolished'
     stats['polished'] = 0
     if sets0 is None:
@@ -534,12 +602,12 @@ def solve_scaled(lp, warm=None, stats=None):
     return st, np.clip(ip.p, lp.lb, lp.ub), np.maximum(ip.s, lp.slo), ip.y, sets0
 
 
-def solve_lp(lp, warm=None):
+def solve_lp(lp, warm=None, hint=None):
     """Solve `lp`.  Returns dict(status, p, s, y, z, sets, stats); z = q - A'y (reduced costs), all in
     the caller's (unscaled) units; bound-active p_j are exactly lb_j / ub_j."""
     stats = {}
     slp, c, rho, kap = scale_lp(lp)
-    st, p, s, y, sets = solve_scaled(slp, warm, stats)
+    st, p, s, y, sets = solve_scaled(slp, warm, stats, hint)
     if st not in (OPTIMAL, OTHER) or p is None:
         return dict(status=st, p=None, s=None, y=None, z=None, sets=None, stats=stats)
     p = p * c

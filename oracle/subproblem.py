@@ -101,6 +101,7 @@ class QpModel:
         # entries currently stored in A[val,:]); create_model! starts them with slack terms only.
         self.A_adj = np.zeros((len(self.adj), n))
         self.warm = {False: None, True: None}     # last accepted active set per phase
+        self.hint = {False: {}, True: {}}         # adaptive solver decisions per phase (lp_solver.solve_scaled)
 
     # ------------------------------------------------------------------ sub_optimize!
     def build_lp(self, x_k, Delta, feasibility):
@@ -147,7 +148,7 @@ class QpModel:
         assert len(d.c) == n and len(d.c_lb) == m and len(d.c_ub) == m
         assert len(d.v_lb) == n and len(d.v_ub) == n and len(x_k) == n
         lp = self.build_lp(x_k, Delta, feasibility)
-        out = L.solve_lp(lp, self.warm[bool(feasibility)])
+        out = L.solve_lp(lp, self.warm[bool(feasibility)], self.hint[bool(feasibility)])
         status = out['status']
         Xsol = np.zeros(n); lam = np.zeros(m); mult_x_U = np.zeros(n); mult_x_L = np.zeros(n)
         p_slack = {}
