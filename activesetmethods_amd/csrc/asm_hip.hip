@@ -107,6 +107,12 @@ struct asm_handle {
     double *d_Linv = nullptr, *d_tpart = nullptr, *d_Binv = nullptr, *d_BinvT = nullptr, *d_wpart = nullptr, *d_wt = nullptr;
     int64_t tpart_len = 0;
     unsigned char* d_nz = nullptr;  // (row tile, k-chunk) non-zero flags of Ah
+    // sparse copy of the fixed Jacobian pattern for the matrix-vector products (sparse patterns only)
+    bool sp_ok = false, spv_Ah_valid = false, spv_J_valid = false;
+    int64_t sp_nnz = 0;
+    int *d_sp_ptr = nullptr, *d_sp_col = nullptr, *d_sc_ptr = nullptr, *d_sc_row = nullptr, *d_sc_pos = nullptr;
+    int64_t* d_sp_off = nullptr;
+    double *d_spv_Ah = nullptr, *d_spv_J = nullptr;
     bool nz_valid = false;
     int nz_T = 0, nz_pitch = 0;
     double nz_fraction = 1.0;       // executed share of the (tile pair, k-chunk) products of the Schur build
@@ -204,36 +210,39 @@ struct Dev {
     }
 
     // out[M] = A x   (A = Ah or J, M rows)
-    void gemv_n(const double* A, const double* x, double* out) {
-        h2d(h->d_vecN, x, h->n, h->ldn);
-        int id = begin(ASM_K_GEMV, 2.0 * h->M * h->n, 8.0 * h->M * h->ldn);
-        hipLaunchKernelGGL(k_gemv_n, dim3((unsigned)((h->M + 3) / 4)), dim3(256), 0, h->stream, A, h->ldn, h->d_vecN,
-                           h->d_vecM, h->M, h->ldn);
-        end(id);
-        d2h(out, h->d_vecM, h->M);
+    // gathered pattern values of A (d_Ah or d_J) for the sparse products, nullptr when the pattern is dense
+    const double* sparse_vals(const double* A) {
+        if (!h->sp_ok) return nullptr;
+        double* v = nullptr;
+        bool* valid = nullptr;
+        if (A == h->d_Ah) { v = h->d_spv_Ah; valid = &h->spv_Ah_valid; }
+        else if (A == h->d_J) { v = h->d_spv_J; valid = &h->spv_J_valid; }
+        else return nullptr;
+        if (!*valid) {
+            hipLaunchKernelGGL(k_sp_gather, dim3((unsigned)((h->sp_nnz + 255) / 256)), dim3(256), 0, h->stream, A, h->d_sp_off, v, h->sp_nnz);
+            *valid = true;
+        }
+        return v;
     }
-    // out[n] = A' y
-    void gemv_t(const double* A, const double* y, double* out) {
-        h2d(h->d_vecM, y, h->M, h->Mp);
-        int64_t R = std::min<int64_t>((h->M + 31) / 32, ASM_TMAXCHUNKS);
-        int64_t chunk = (h->M + R - 1) / R;
-        R = (h->M + chunk - 1) / chunk;
-        int id = begin(ASM_K_GEMV, 2.0 * h->M * h->n, 8.0 * h->M * h->ldn);
-        hipLaunchKernelGGL(k_gemv_t_stage1, dim3((unsigned)((h->ldn + 255) / 256), (unsigned)R), dim3(256), 0, h->stream, A,
-                           h->ldn, h->d_vecM, h->d_partial, h->M, h->ldn, chunk);
-        hipLaunchKernelGGL(k_gemv_t_stage2, dim3((unsigned)((h->ldn + 255) / 256)), dim3(256), 0, h->stream, h->d_partial,
-                           h->d_vecN, R, h->ldn);
-        end(id);
-        d2h(out, h->d_vecN, h->n);
-    }
-
-    // device-pointer variants (the IPM keeps its vectors in HBM)
-    void gemv_n_dev(const double* A, const double* x, double* out) {
+    void launch_gemv_n(const double* A, const double* x, double* out) {
+        if (const double* v = sparse_vals(A)) {
+            int id = begin(ASM_K_GEMV, 2.0 * h->sp_nnz, 20.0 * h->sp_nnz + 12.0 * h->M);
+            hipLaunchKernelGGL(k_spmv_n, dim3((unsigned)((h->M + 255) / 256)), dim3(256), 0, h->stream, h->d_sp_ptr, h->d_sp_col, v, x, out, h->M);
+            end(id);
+            return;
+        }
         int id = begin(ASM_K_GEMV, 2.0 * h->M * h->n, 8.0 * h->M * h->ldn);
         hipLaunchKernelGGL(k_gemv_n, dim3((unsigned)((h->M + 3) / 4)), dim3(256), 0, h->stream, A, h->ldn, x, out, h->M, h->ldn);
         end(id);
     }
-    void gemv_t_dev(const double* A, const double* y, double* out) {
+    void launch_gemv_t(const double* A, const double* y, double* out) {
+        if (const double* v = sparse_vals(A)) {
+            int id = begin(ASM_K_GEMV, 2.0 * h->sp_nnz, 24.0 * h->sp_nnz + 12.0 * h->n);
+            hipLaunchKernelGGL(k_spmv_t, dim3((unsigned)((h->ldn + 255) / 256)), dim3(256), 0, h->stream, h->d_sc_ptr, h->d_sc_row, h->d_sc_pos, v,
+                               y, out, h->n, h->ldn);
+            end(id);
+            return;
+        }
         int64_t R = std::min<int64_t>((h->M + 31) / 32, ASM_TMAXCHUNKS);
         int64_t chunk = (h->M + R - 1) / R;
         R = (h->M + chunk - 1) / chunk;
@@ -243,6 +252,22 @@ struct Dev {
         hipLaunchKernelGGL(k_gemv_t_stage2, dim3((unsigned)((h->ldn + 255) / 256)), dim3(256), 0, h->stream, h->d_partial, out, R, h->ldn);
         end(id);
     }
+    // out[M] = A x   (host vectors)
+    void gemv_n(const double* A, const double* x, double* out) {
+        h2d(h->d_vecN, x, h->n, h->ldn);
+        launch_gemv_n(A, h->d_vecN, h->d_vecM);
+        d2h(out, h->d_vecM, h->M);
+    }
+    // out[n] = A' y
+    void gemv_t(const double* A, const double* y, double* out) {
+        h2d(h->d_vecM, y, h->M, h->Mp);
+        launch_gemv_t(A, h->d_vecM, h->d_vecN);
+        d2h(out, h->d_vecN, h->n);
+    }
+
+    // device-pointer variants (the IPM keeps its vectors in HBM)
+    void gemv_n_dev(const double* A, const double* x, double* out) { launch_gemv_n(A, x, out); }
+    void gemv_t_dev(const double* A, const double* y, double* out) { launch_gemv_t(A, y, out); }
     void syrk_dev(const int* idx_dev, int Ms, const double* theta_dev, const double* diag_dev) {
         const bool skip = h->nz_valid && idx_dev == nullptr && Ms == (int)h->M && pick_tile(Ms) == h->nz_T;
         int id = begin(ASM_K_SYRK, (skip ? h->nz_fraction : 1.0) * (double)Ms * (Ms + 1) * h->ldn,
@@ -455,6 +480,7 @@ struct Dev {
 
     // COO values (device resident) -> dense J incl. the extra range rows (common.jl:12-20, subproblem.jl:438-457)
     void assemble() {
+        h->spv_J_valid = false;
         int id = begin(ASM_K_ASSEMBLE, 0.0, 8.0 * h->nnz + 8.0 * h->nu + (h->dense_fast ? 0.0 : 24.0 * h->nu + 8.0 * h->nnz));
         if (h->dense_fast) {
             int64_t total = h->m * h->n;
@@ -483,6 +509,7 @@ struct Dev {
     }
     // Ah = diag(1/rho) J diag(c);  rho (host, M)
     void scale(const double* c, double* rho) {
+        h->spv_Ah_valid = false;
         h2d(h->d_c, c, h->n, h->ldn);
         int id = begin(ASM_K_SCALE, 0.0, 8.0 * 3.0 * h->M * h->ldn);
         hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)h->M), dim3(256), 0, h->stream, h->d_J, h->d_c, h->d_Ah, h->d_rho, h->n,
@@ -1054,6 +1081,10 @@ void free_device(asm_handle* h) {
     F(h->d_vecN); F(h->d_vecM); F(h->d_vecM2); F(h->d_part); F(h->d_partial); F(h->d_idx); F(h->d_Linv); F(h->d_tpart); F(h->d_Binv); F(h->d_wpart); F(h->d_BinvT); F(h->d_wt);
     h->d_Binv = h->d_wpart = h->d_BinvT = h->d_wt = nullptr; F(h->d_ipm); F(h->d_ipm_i); F(h->d_nz);
     h->d_nz = nullptr; h->nz_valid = false;
+    F(h->d_sp_ptr); F(h->d_sp_col); F(h->d_sc_ptr); F(h->d_sc_row); F(h->d_sc_pos); F(h->d_sp_off); F(h->d_spv_Ah); F(h->d_spv_J);
+    h->d_sp_ptr = h->d_sp_col = h->d_sc_ptr = h->d_sc_row = h->d_sc_pos = nullptr;
+    h->d_sp_off = nullptr; h->d_spv_Ah = h->d_spv_J = nullptr;
+    h->sp_ok = h->spv_Ah_valid = h->spv_J_valid = false; h->sp_nnz = 0;
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     h->d_ipm = nullptr; h->d_ipm_i = nullptr; h->h_scal = nullptr;
     if (h->h_pin) (void)hipHostFree(h->h_pin);
@@ -1135,6 +1166,38 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
         ustart.push_back(nnz);
     }
     h->nu = dense ? nnz : (int64_t)uoff.size();
+    // sparse pattern (CSR + CSC) of the LP matrix rows [0, M): the unique Jacobian entries plus the copies of the range
+    // rows; used by the matrix-vector products when the fill is below 1/16
+    std::vector<int> sp_ptr, sp_col, sc_ptr, sc_row, sc_pos;
+    std::vector<int64_t> sp_off;
+    {
+        int64_t nadjent = 0;
+        for (int64_t v : adjoff) nadjent += v >= 0;
+        const int64_t nnzS = (int64_t)uoff.size() + nadjent;
+        if (!dense && nnzS > 0 && nnzS * 16 <= h->M * n && nnzS < (int64_t)1 << 30) {
+            sp_off.reserve(nnzS);
+            for (int64_t v : uoff) sp_off.push_back(v);                 // sorted by (row, col), rows < m
+            for (int64_t v : adjoff) if (v >= 0) sp_off.push_back(v);   // rows m.., same order
+            sp_ptr.assign(h->M + 1, 0);
+            sp_col.resize(nnzS);
+            for (int64_t k = 0; k < nnzS; ++k) {
+                sp_ptr[sp_off[k] / h->ldn + 1] += 1;
+                sp_col[k] = (int)(sp_off[k] % h->ldn);
+            }
+            for (int64_t i = 0; i < h->M; ++i) sp_ptr[i + 1] += sp_ptr[i];
+            sc_ptr.assign(n + 1, 0);
+            for (int64_t k = 0; k < nnzS; ++k) sc_ptr[sp_col[k] + 1] += 1;
+            for (int64_t j = 0; j < n; ++j) sc_ptr[j + 1] += sc_ptr[j];
+            std::vector<int> fill(sc_ptr.begin(), sc_ptr.end() - 1);
+            sc_row.resize(nnzS); sc_pos.resize(nnzS);
+            for (int64_t k = 0; k < nnzS; ++k) {                          // stable: rows ascending inside a column
+                int q = fill[sp_col[k]]++;
+                sc_row[q] = (int)(sp_off[k] / h->ldn);
+                sc_pos[q] = (int)k;
+            }
+            h->sp_nnz = nnzS;
+        }
+    }
 
     dmalloc(&h->d_dE, nnz);
     dmalloc(&h->d_J, h->Mp * h->ldn);
@@ -1153,6 +1216,18 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     h->tpart_len = (h->Mp / ASM_TRSV_ROWS + 2) * ASM_NB;
     dmalloc(&h->d_tpart, 2 * h->tpart_len);
     dmalloc(&h->d_nz, (h->Mp / 32 + 1) * (h->ldn / ASM_KC + 1));
+    if (h->sp_nnz > 0) {
+        dmalloc(&h->d_sp_ptr, h->M + 1); dmalloc(&h->d_sp_col, h->sp_nnz); dmalloc(&h->d_sp_off, h->sp_nnz);
+        dmalloc(&h->d_sc_ptr, n + 1); dmalloc(&h->d_sc_row, h->sp_nnz); dmalloc(&h->d_sc_pos, h->sp_nnz);
+        dmalloc(&h->d_spv_Ah, h->sp_nnz); dmalloc(&h->d_spv_J, h->sp_nnz);
+        HIPCHK(hipMemcpy(h->d_sp_ptr, sp_ptr.data(), sp_ptr.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_sp_col, sp_col.data(), sp_col.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_sp_off, sp_off.data(), sp_off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_sc_ptr, sc_ptr.data(), sc_ptr.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_sc_row, sc_row.data(), sc_row.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_sc_pos, sc_pos.data(), sc_pos.size() * sizeof(int), hipMemcpyHostToDevice));
+        h->sp_ok = true;
+    }
     h->nsp = round_up(std::max<int64_t>(h->ns, 1), 16);
     {
         int64_t nd = 24 * h->ldn + 23 * h->Mp + 16 * h->nsp + 64;
@@ -1508,6 +1583,7 @@ static void test_alloc(asm_handle* h, int64_t M, int64_t K) {
     std::vector<int64_t> jr(1, 1), jc(1, 1);
     vec lo(M, 0.0), hi(M, 0.0), vl(K, -1.0), vu(K, 1.0);
     do_setup(h, K, M, 1, jr.data(), jc.data(), lo.data(), hi.data(), vl.data(), vu.data());
+    h->sp_ok = false;     // the hooks write arbitrary matrices into the buffers
 }
 
 int asm_test_syrk(asm_handle* h, const double* A, int64_t M, int64_t K, const int32_t* idx, int64_t Ms, const double* theta,

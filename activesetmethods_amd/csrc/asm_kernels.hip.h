@@ -945,3 +945,31 @@ __global__ __launch_bounds__(256) void k_transpose512(const double* __restrict__
         XT[(int64_t)(tj * 64 + r) * ASM_WB + ti * 64 + c] = tile[c * 65 + r];
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Sparse matrix-vector products on the fixed Jacobian pattern (ACOPF: 0.03 % fill).  The dense row-major matrix stays
+// the operand of the MFMA kernels; these read a gathered copy of its pattern entries (CSR values, CSC via positions).
+// One thread per row / column, fixed summation order -> deterministic.
+__global__ __launch_bounds__(256) void k_sp_gather(const double* __restrict__ A, const int64_t* __restrict__ off,
+                                                   double* __restrict__ vals, int64_t nnz) {
+    int64_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k < nnz) vals[k] = A[off[k]];
+}
+__global__ __launch_bounds__(256) void k_spmv_n(const int* __restrict__ ptr, const int* __restrict__ col, const double* __restrict__ vals,
+                                                const double* __restrict__ x, double* __restrict__ out, int64_t M) {
+    int64_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    double acc = 0.0;
+    for (int k = ptr[i]; k < ptr[i + 1]; ++k) acc += vals[k] * x[col[k]];
+    out[i] = acc;
+}
+__global__ __launch_bounds__(256) void k_spmv_t(const int* __restrict__ cptr, const int* __restrict__ row, const int* __restrict__ pos,
+                                                const double* __restrict__ vals, const double* __restrict__ y, double* __restrict__ out,
+                                                int64_t n, int64_t ldn) {
+    int64_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= ldn) return;
+    double acc = 0.0;
+    if (j < n)
+        for (int k = cptr[j]; k < cptr[j + 1]; ++k) acc += vals[pos[k]] * y[row[k]];
+    out[j] = acc;
+}

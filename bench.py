@@ -153,6 +153,25 @@ def _cores():
         return HOST_THREADS
 
 
+def highs_baseline(lp):
+    """Independent third-party CPU LP code on the identical first sub-LP: SciPy's HiGHS dual simplex on
+    the sparse form, cold start, one thread.  Not the reference's GLPK (absent here) - an orientation figure only."""
+    try:
+        import numpy as np, scipy.sparse as sp
+        from scipy.optimize import linprog
+        A = sp.csr_matrix(lp.A)
+        eq, ge, le = lp.rtype == 0, lp.rtype == 1, lp.rtype == -1
+        A_ub = sp.vstack([-A[ge], A[le]]).tocsr()
+        b_ub = np.concatenate([-lp.r[ge], lp.r[le]])
+        t0 = time.perf_counter()
+        res = linprog(lp.q, A_ub=A_ub, b_ub=b_ub, A_eq=A[eq], b_eq=lp.r[eq], bounds=np.c_[lp.lb, lp.ub], method="highs-ds")
+        dt = time.perf_counter() - t0
+        return dict(lp_solves_per_s=1.0 / dt, seconds=dt, status=int(res.status), simplex_iterations=int(res.nit),
+                    note="scipy.optimize.linprog(method='highs-ds') on the first normal-phase sub-LP of the workload (sparse, cold start, 1 thread)")
+    except Exception as e:                                   # SciPy missing or HiGHS failure: report, do not fail the bench
+        return dict(error=repr(e))
+
+
 def cpu_baseline(pr, algorithm, budget_s, fact_per_step):
     """Oracle (NumPy restatement of the same path) on a bounded sample of the same workload.
     Small NLPs: whole SLP iterations from x0.  Large NLPs (one LP would take minutes on the host): the first
@@ -176,8 +195,13 @@ def cpu_baseline(pr, algorithm, budget_s, fact_per_step):
             if dt >= 0.5 * budget_s or k >= 64:
                 break
             k = max(k + 1, int(k * min(4.0, 0.8 * budget_s / max(dt, 1e-3))))
+        x = pr.x0.copy()
+        A, st = compute_jacobian_matrix(pr.m, pr.n, pr.j_row - 1, pr.j_col - 1, pr.eval_jac_g(x, np.zeros(pr.nnz)))
+        qp = QpModel(QpData(pr.eval_grad_f(x, np.zeros(pr.n)), pr.eval_f(x), A, pr.eval_g(x, np.zeros(pr.m)), pr.g_L, pr.g_U, pr.x_L, pr.x_U, st),
+                     pr.j_row, pr.j_col)
         return dict(value=steps / t_total, unit="iter/s", cores=cores, kind="port",
-                    sample="oracle SLP (%s) from x0, first %d SLP iterations of the same NLP, %.1f s" % (algorithm, steps, t_total))
+                    sample="oracle SLP (%s) from x0, first %d SLP iterations of the same NLP, %.1f s" % (algorithm, steps, t_total),
+                    highs=highs_baseline(qp.build_lp(x, 1000.0 if algorithm == "Line Search" else 0.4, False)))
     x = pr.x0.copy()
     t0 = time.perf_counter()
     dE = pr.eval_jac_g(x, np.zeros(pr.nnz))
@@ -199,7 +223,8 @@ def cpu_baseline(pr, algorithm, budget_s, fact_per_step):
     return dict(value=1.0 / step_s, unit="iter/s", cores=cores, kind="port",
                 sample="oracle: assembly+formulation+scaling of the first sub-LP (%.1f s) and %d interior-point iterations of it "
                        "(%.1f s each: Schur build + Cholesky + solves), scaled by the %.1f factorisations per SLP step measured on the GPU run"
-                       % (t_setup, its, per_fact, fact_per_step))
+                       % (t_setup, its, per_fact, fact_per_step),
+                highs=highs_baseline(lp))
 
 
 def main():
