@@ -106,7 +106,8 @@ struct asm_handle {
     double *d_vecN = nullptr, *d_vecM = nullptr, *d_vecM2 = nullptr, *d_part = nullptr, *d_partial = nullptr;
     double *d_Linv = nullptr, *d_tpart = nullptr, *d_Binv = nullptr, *d_BinvT = nullptr, *d_wpart = nullptr, *d_wt = nullptr;
     int64_t tpart_len = 0;
-    unsigned char* d_nz = nullptr;  // (row tile, k-chunk) non-zero flags of Ah
+    unsigned char* d_nz = nullptr;  // (row tile, k-chunk) non-zero flags of Ah; second half: flags of a gathered row set
+    int64_t nz_half = 0;
     // sparse copy of the fixed Jacobian pattern for the matrix-vector products (sparse patterns only)
     bool sp_ok = false, spv_Ah_valid = false, spv_J_valid = false;
     int64_t sp_nnz = 0;
@@ -286,11 +287,14 @@ struct Dev {
         const int nt = (int)((h->M + TS - 1) / TS);
         h->nz_pitch = nch;
         hipLaunchKernelGGL(k_tile_nzflags, dim3((unsigned)nt, (unsigned)((nch + 7) / 8)), dim3(256), 0, h->stream, h->d_Ah, h->ldn, h->M, TS,
-                           nch, h->d_nz, h->nz_pitch);
+                           nch, h->d_nz, h->nz_pitch, (const int*)nullptr);
         h->nz_valid = true;
-        // fraction of (tile pair, chunk) products actually executed: keeps the flop accounting of the roofline honest
+        h->nz_fraction = executed_fraction(h->d_nz, nt, nch);
+    }
+    // fraction of (tile pair, chunk) products actually executed: keeps the flop accounting of the roofline honest
+    double executed_fraction(const unsigned char* d_flags, int nt, int nch) {
         std::vector<unsigned char> fl((size_t)nt * nch);
-        HIPCHK(hipMemcpyAsync(fl.data(), h->d_nz, fl.size(), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(fl.data(), d_flags, fl.size(), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         double act = 0.0, tot = 0.0;
         for (int a = 0; a < nt; ++a)
@@ -301,7 +305,7 @@ struct Dev {
                 act += cnt;
                 tot += nch;
             }
-        h->nz_fraction = tot > 0 ? act / tot : 1.0;
+        return tot > 0 ? act / tot : 1.0;
     }
     void chol_solve_dev(const double* rhs_dev, double* out_dev, int Ms) {
         HIPCHK(hipMemcpyAsync(h->d_vecM2, rhs_dev, Ms * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -315,7 +319,7 @@ struct Dev {
 
     void launch_syrk(int T, const double* A, int64_t ld, const int* idx, int64_t row0, int Ms, int K, const double* theta,
                      const double* diag, double* S, int64_t ldS, int64_t srow0, int mode, int MsB = -1,
-                     const unsigned char* nz = nullptr, int nzpitch = 0) {
+                     const unsigned char* nz = nullptr, int nzpitch = 0, double nzfrac = -1.0) {
         int TS = 32 * T;
         int64_t nt = (Ms + TS - 1) / TS;
         int ntj = 0;
@@ -329,7 +333,7 @@ struct Dev {
         if (blocks <= 0) return;
         // per-launch timing of the MFMA kernel itself (algorithmic flops: Ms*MsB*K over the stored triangle/rectangle)
         double fl = (MsB == Ms && ntj == 0) ? (double)Ms * (Ms + 1) * K : 2.0 * ((double)Ms * MsB - 0.5 * (double)MsB * MsB) * K;
-        if (nz) fl *= h->nz_fraction;
+        if (nz) fl *= nzfrac >= 0.0 ? nzfrac : h->nz_fraction;
         int kid = (h->use_graphs || cur != h->stream) ? -1 : begin(ASM_K_SYRK_KERNEL, fl, 8.0 * ((double)(Ms + MsB) * K + (double)Ms * MsB));
         struct EndGuard { Dev* d; int id; ~EndGuard() { d->end(id); } } guard_{this, kid};
         if (T == 4)
@@ -351,9 +355,19 @@ struct Dev {
             HIPCHK(hipMemcpyAsync(h->d_idx, idx_host, Ms * sizeof(int), hipMemcpyHostToDevice, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
         }
-        int id = begin(ASM_K_SYRK, (double)Ms * (Ms + 1) * h->ldn, 8.0 * (Ms * (double)h->ldn + 0.5 * Ms * (double)Ms));
-        launch_syrk(pick_tile(Ms), h->d_Ah, h->ldn, idx_host ? h->d_idx : nullptr, 0, Ms, (int)h->ldn, h->d_theta,
-                    diag ? h->d_diag : nullptr, h->d_S, h->Mp, 0, 0);
+        // sparse Jacobians: chunk flags of the gathered row set (second half of the flag buffer), as in the full Schur build
+        const int nch = (int)(h->ldn / ASM_KC);
+        const int T = pick_tile(Ms), TS = 32 * T;
+        const int nt = (Ms + TS - 1) / TS;
+        const bool skip = h->nz_valid && idx_host != nullptr && nt > 0;
+        unsigned char* nz2 = h->d_nz + h->nz_half;
+        if (skip)
+            hipLaunchKernelGGL(k_tile_nzflags, dim3((unsigned)nt, (unsigned)((nch + 7) / 8)), dim3(256), 0, h->stream, h->d_Ah, h->ldn, (int64_t)Ms, TS,
+                               nch, nz2, nch, (const int*)h->d_idx);
+        const double frac = skip ? executed_fraction(nz2, nt, nch) : 1.0;
+        int id = begin(ASM_K_SYRK, frac * (double)Ms * (Ms + 1) * h->ldn, 8.0 * (Ms * (double)h->ldn + 0.5 * Ms * (double)Ms));
+        launch_syrk(T, h->d_Ah, h->ldn, idx_host ? h->d_idx : nullptr, 0, Ms, (int)h->ldn, h->d_theta,
+                    diag ? h->d_diag : nullptr, h->d_S, h->Mp, 0, 0, -1, skip ? nz2 : nullptr, nch, frac);
         end(id);
     }
     void diag_prepare(int Ms, int mode, double rel, double absv) {
@@ -1215,7 +1229,8 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     dmalloc(&h->d_wt, ASM_WB);
     h->tpart_len = (h->Mp / ASM_TRSV_ROWS + 2) * ASM_NB;
     dmalloc(&h->d_tpart, 2 * h->tpart_len);
-    dmalloc(&h->d_nz, (h->Mp / 32 + 1) * (h->ldn / ASM_KC + 1));
+    h->nz_half = (h->Mp / 32 + 1) * (h->ldn / ASM_KC + 1);
+    dmalloc(&h->d_nz, 2 * h->nz_half);
     if (h->sp_nnz > 0) {
         dmalloc(&h->d_sp_ptr, h->M + 1); dmalloc(&h->d_sp_col, h->sp_nnz); dmalloc(&h->d_sp_off, h->sp_nnz);
         dmalloc(&h->d_sc_ptr, n + 1); dmalloc(&h->d_sc_row, h->sp_nnz); dmalloc(&h->d_sc_pos, h->sp_nnz);

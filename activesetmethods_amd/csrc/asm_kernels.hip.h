@@ -671,7 +671,7 @@ __global__ __launch_bounds__(256) void k_mfma_f64_peak(double* __restrict__ out,
 // nz[t][c] = 1 iff the 32T-row tile t of A has a non-zero in k-chunk c (32 columns).  One workgroup per (tile, group of
 // 8 chunks); feeds the chunk skipping of the Schur build for sparse Jacobians (ACOPF: ~3 non-zeros per row).
 __global__ __launch_bounds__(256) void k_tile_nzflags(const double* __restrict__ A, int64_t ld, int64_t M, int tile_rows, int nchunks,
-                                                      unsigned char* __restrict__ nz, int nzpitch) {
+                                                      unsigned char* __restrict__ nz, int nzpitch, const int* __restrict__ idx) {
     const int t = blockIdx.x, c0 = blockIdx.y * 8;
     __shared__ int any[8];
     if (threadIdx.x < 8) any[threadIdx.x] = 0;
@@ -685,7 +685,8 @@ __global__ __launch_bounds__(256) void k_tile_nzflags(const double* __restrict__
         for (int r = 0; r < tile_rows; ++r) {
             int64_t i = r0 + r;
             if (i >= M) break;
-            f = f || (A[i * ld + col] != 0.0);
+            const int64_t ri = idx ? idx[i] : i;      // gathered row set of an active-set build
+            f = f || (A[ri * ld + col] != 0.0);
         }
     if (f) any[cc] = 1;
     __syncthreads();
