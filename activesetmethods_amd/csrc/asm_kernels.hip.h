@@ -178,11 +178,24 @@ __global__ __launch_bounds__(64 * NW) void k_syrk(const double* __restrict__ A, 
     constexpr int TI = TS / 32, TJ = TS / (16 * WCOLS);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w / WCOLS, wc = w % WCOLS;
+    // mode 1 (S -= A B'): the accumulators start from the S tile and the A operand is negated when staged, so the
+    // read of S overlaps the first operand loads instead of trailing the last MFMA
     v4f64 acc[TI][TJ];
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < TJ; ++j) {
+            acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+            if (mode != 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int row = bi * TS + wr * 16 * TI + i * 16 + (lane >> 4) + 4 * r;
+                    int col = bj * TS + wc * 16 * TJ + j * 16 + (lane & 15);
+                    if (row < Ms && col < MsB && col <= row) acc[i][j][r] = S[(srow0 + row) * ldS + (srow0 + col)];
+                }
+            }
+        }
+    const double asign = mode != 0 ? -1.0 : 1.0;
 
     // staging assignment: TS rows x KC doubles per operand; each thread moves 2 doubles (16 B) per pass
     constexpr int PER_ROW = ASM_KC / 2;                 // threads per row
@@ -205,7 +218,8 @@ __global__ __launch_bounds__(64 * NW) void k_syrk(const double* __restrict__ A, 
         double2 th = theta ? *reinterpret_cast<const double2*>(theta + k0 + lk) : make_double2(1.0, 1.0);
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
-            ra[ps] = arow[ps] ? *reinterpret_cast<const double2*>(arow[ps] + k0 + lk) : make_double2(0.0, 0.0);
+            double2 a = arow[ps] ? *reinterpret_cast<const double2*>(arow[ps] + k0 + lk) : make_double2(0.0, 0.0);
+            ra[ps] = make_double2(asign * a.x, asign * a.y);
             double2 b = brow[ps] ? *reinterpret_cast<const double2*>(brow[ps] + k0 + lk) : make_double2(0.0, 0.0);
             rb[ps] = make_double2(b.x * th.x, b.y * th.y);
         }
@@ -276,12 +290,8 @@ __global__ __launch_bounds__(64 * NW) void k_syrk(const double* __restrict__ A, 
                 if (row < Ms && col < MsB && col <= row) {
                     double* dst = S + (srow0 + row) * ldS + (srow0 + col);
                     double v = acc[i][j][r];
-                    if (mode == 0) {
-                        if (row == col && diag) v += diag[row];
-                        *dst = v;
-                    } else {
-                        *dst = *dst - v;
-                    }
+                    if (mode == 0 && row == col && diag) v += diag[row];
+                    *dst = v;
                 }
             }
 }
