@@ -30,6 +30,7 @@ const double TOL_P = 1e-9, TOL_D = 1e-6;
 const int IPM_MAXIT = 60;
 const int IPM_MCC = 2;           // Gondzio centrality correctors per iteration (oracle/lp_solver.py)
 const double MCC_DELTA = 0.3, MCC_BMIN = 0.1, MCC_BMAX = 10.0, MCC_GAMMA = 0.1;
+const int CHOL_NBI = 256, CHOL_NBO = 1024;   // inner / outer panel widths of the three-level Cholesky
 const int PCG_MAXIT = 20;       // conjugate-gradient steps per Newton solve (preconditioner = the Cholesky factor)
 const double PCG_KAPPA = 1e-3;  // Newton-system residual tolerance relative to the current primal residual
 const double IPM_RHO_P = 1e-8;   // primal proximal regularisation of the Newton system
@@ -405,17 +406,25 @@ struct Dev {
         end(id);
         h->stats.nfact += 1;
     }
-    // block chain of one outer panel [K0, K1): 64-wide potrf / panel solve / in-panel update steps
+    // block chain of one outer panel [K0, K1): 64-wide potrf / panel solve steps whose rank-64 updates stay inside a
+    // 256-wide inner panel; the rest of the outer panel is updated once per inner panel with K = 256
     void chol_chain(int Ms, double thr, int K0, int K1) {
-        for (int k0 = K0; k0 < K1; k0 += ASM_NB) {
-            int nb = std::min(ASM_NB, Ms - k0);
-            hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, cur, h->d_S, h->Mp, k0, nb, h->d_diag0, thr, h->d_Linv);
-            int k1 = k0 + nb;
-            if (k1 < Ms) {
-                int rem = Ms - k1;
-                hipLaunchKernelGGL(k_trsm_panel, dim3((unsigned)((rem + 63) / 64)), dim3(256), 0, cur, h->d_S, h->Mp, k0, nb, Ms, h->d_Linv);
-                if (k1 < K1)   // update the remaining columns of this outer panel only
-                    launch_syrk(pick_tile(rem), h->d_S + k0, h->Mp, nullptr, k1, rem, nb, nullptr, nullptr, h->d_S, h->Mp, k1, 1, K1 - k1);
+        for (int I0 = K0; I0 < K1; I0 += CHOL_NBI) {
+            const int I1 = std::min(I0 + CHOL_NBI, K1);
+            for (int k0 = I0; k0 < I1; k0 += ASM_NB) {
+                int nb = std::min(ASM_NB, Ms - k0);
+                hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, cur, h->d_S, h->Mp, k0, nb, h->d_diag0, thr, h->d_Linv);
+                int k1 = k0 + nb;
+                if (k1 < Ms) {
+                    int rem = Ms - k1;
+                    hipLaunchKernelGGL(k_trsm_panel, dim3((unsigned)((rem + 63) / 64)), dim3(256), 0, cur, h->d_S, h->Mp, k0, nb, Ms, h->d_Linv);
+                    if (k1 < I1)   // update the remaining columns of this inner panel only
+                        launch_syrk(pick_tile(rem), h->d_S + k0, h->Mp, nullptr, k1, rem, nb, nullptr, nullptr, h->d_S, h->Mp, k1, 1, I1 - k1);
+                }
+            }
+            if (I1 < K1 && I1 < Ms) {
+                int rem = Ms - I1;
+                launch_syrk(pick_tile(rem), h->d_S + I0, h->Mp, nullptr, I1, rem, I1 - I0, nullptr, nullptr, h->d_S, h->Mp, I1, 1, K1 - I1);
             }
         }
     }
@@ -424,7 +433,7 @@ struct Dev {
         // panel's own columns; the trailing matrix is read-modify-written once per outer panel (K = 1024), in two parts:
         // (a) the columns of the NEXT outer panel, (b) the rest.  The next panel's serial block chain then runs on a second
         // stream beside (b), so the latency-bound chain hides under the MFMA-bound update.
-        const int NBO = 16 * ASM_NB;
+        const int NBO = CHOL_NBO;
         const int nP = (Ms + NBO - 1) / NBO;
         const bool la = nP > 2 && !h->use_graphs;
         while ((int)h->la_events.size() < 2 * nP + 2) {
