@@ -60,20 +60,23 @@ def test_synthetic_dense_small_trace(alg, iters):
     assert all(r['stats']['polished'] == 1 for r in sh.trace)
 
 
-def test_reductions_on_resident_jacobian():
-    """KT_residuals / row norms computed from the HBM-resident Jacobian (common.jl:35-44)."""
-    from activesetmethods_amd import problems, QpData, HipSubOptimizer
+@pytest.mark.parametrize("kind", ["dense", "sparse"])
+def test_reductions_on_resident_jacobian(kind):
+    """KT_residuals / row norms computed from the HBM-resident Jacobian (common.jl:35-44); the sparse case runs the
+    products on the CSR/CSC copy of the pattern."""
+    from activesetmethods_amd import problems, acopf, QpData, HipSubOptimizer
     from oracle import slp as O
     from oracle.subproblem import compute_jacobian_matrix
-    pr = problems.synthetic_dense_nlp(90, 40)
+    pr = problems.synthetic_dense_nlp(90, 40) if kind == "dense" else acopf.acopf_problem(acopf.synthetic_case("case118", 3), "case118")
     rng = np.random.default_rng(0)
-    x = rng.uniform(-0.5, 0.5, pr.n)
+    x = rng.uniform(-0.5, 0.5, pr.n) if kind == "dense" else pr.x0 + 0.01 * rng.standard_normal(pr.n)
     df = pr.eval_grad_f(x, np.zeros(pr.n)); E = pr.eval_g(x, np.zeros(pr.m)); dE = pr.eval_jac_g(x, np.zeros(pr.nnz))
     opt = HipSubOptimizer(QpData(df, 0.0, dE, E, pr.g_L, pr.g_U, pr.x_L, pr.x_U), pr.j_row, pr.j_col)
     opt.upload(dE, df, 0.0, E, x)
     lam = rng.standard_normal(pr.m); mu = rng.standard_normal(pr.n) * 0.1; ml = rng.standard_normal(pr.n) * 0.1
     J, _ = compute_jacobian_matrix(pr.m, pr.n, pr.j_row - 1, pr.j_col - 1, dE)
-    assert abs(opt.kt_residuals(df, lam, mu, ml) - O.KT_residuals(df, lam, mu, ml, J)) < 1e-12
+    ref = O.KT_residuals(df, lam, mu, ml, J)
+    assert abs(opt.kt_residuals(df, lam, mu, ml) - ref) < 1e-12 * max(1.0, abs(ref))
     assert rel_err(opt.jac_row_norms(), np.linalg.norm(J, axis=1)) < 1e-13
     opt.close()
 
@@ -113,6 +116,36 @@ def test_acopf_case118_sized_lp_parity():
     rows, bnd, sl = opt.active_set()
     assert np.array_equal(rows, o_out[6]['sets'][0]) and np.array_equal(bnd, o_out[6]['sets'][1])
     assert rel_err(h_out[0], o_out[0]) < 1e-9 and rel_err(h_out[1], o_out[1]) < 1e-9
+    opt.close()
+
+
+def test_acopf_restoration_lp_with_non_unique_optimum():
+    """Trust-Region sub-LP of the case118-sized grid at x0: INFEASIBLE, then the restoration LP `min sum(slacks)`, whose
+    optimum is not unique (the least-norm polish fails at every stage, the polish from the interior-point iterate
+    succeeds: path 'ipm+ref').  The optimal point is then not pinned by the LP - the reference's simplex would return yet
+    another vertex - so the bars are: same path and iteration counts as the oracle, same optimal value (unique), the
+    step within 1e-6 (both follow the same central path), and the path decision carried to the next call."""
+    from activesetmethods_amd import acopf
+    from tests.util import oracle_solve, hip_solve
+    pr = acopf.acopf_problem(acopf.synthetic_case("case118", 1), "case118")
+    x = pr.x0.copy()
+    sp = dict(n=pr.n, m=pr.m, j_row=pr.j_row, j_col=pr.j_col, dE=pr.eval_jac_g(x, np.zeros(pr.nnz)), df=pr.eval_grad_f(x, np.zeros(pr.n)),
+              f=pr.eval_f(x), E=pr.eval_g(x, np.zeros(pr.m)), x_k=x, c_lb=pr.g_L, c_ub=pr.g_U, v_lb=pr.x_L, v_ub=pr.x_U, delta=0.4)
+    qp, o_out = oracle_solve(sp)
+    opt, h_out = hip_solve(sp)
+    assert o_out[5] == h_out[5] == 2                                       # subproblem.jl:532-536
+    for call in range(2):
+        qp, o_out = oracle_solve(sp, True, qp)
+        opt, h_out = hip_solve(sp, True, opt)
+        st, so = opt.last_stats(), o_out[6]['stats']
+        assert o_out[5] == h_out[5] == 1
+        assert so['path'] == 'ipm+ref' and st['path'] == 4
+        assert st['ipm_iters'] == so['ipm_iters'] and st['eqp'] == so['eqp']
+        obj_o = sum(sum(v) for v in o_out[4].values()); obj_h = sum(sum(v) for v in h_out[4].values())
+        assert abs(obj_h - obj_o) <= 1e-8 * max(1.0, abs(obj_o))
+        assert rel_err(h_out[0], o_out[0]) < 1e-6
+        assert qp.hint[True].get('prefer_ref') is True
+    assert so['eqp'] <= 4                                                  # second call went straight to that polish
     opt.close()
 
 

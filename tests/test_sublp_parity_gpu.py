@@ -72,6 +72,49 @@ def test_warm_sequence_matches():
     opt.close()
 
 
+PATH_NAMES = {0: 'warm', 1: 'ipm0+ln', 2: 'ipm1+ln', 3: 'ipm2+ln', 4: 'ipm+ref', 5: 'ipm-unpolished', 6: 'ipm-infeasible',
+              7: 'phase1-infeasible', 8: 'ipm~+ln'}
+
+
+@pytest.mark.parametrize("seed,n,m,density,dup,nrange", [(41, 600, 380, 0.012, 0.2, 5), (42, 900, 700, 0.006, 0.0, 8)])
+def test_sparse_pattern_parity(seed, n, m, density, dup, nrange):
+    """Fill below 1/16: the matrix-vector products run on the CSR/CSC copy of the pattern and the Schur builds skip
+    empty k-chunks; results must not differ from the oracle's dense arithmetic beyond the usual bar."""
+    sp = random_subproblem(seed, n, m, density, dup, nrange)
+    qp, o_out = oracle_solve(sp)
+    opt, h_out = hip_solve(sp)
+    _compare(o_out, h_out, opt, None)
+    assert PATH_NAMES[opt.last_stats()['path']] == o_out[6]['stats']['path']
+    opt.close()
+
+
+def test_restoration_sequence_path_decisions_match():
+    """A run of restoration-phase LPs on one handle: the per-phase hints (skipped warm attempts after failures, the
+    polish-from-the-interior-iterate preference for non-unique optima) are state carried from call to call; the
+    HIP solver must take the oracle's path at every call and return the same point."""
+    sp = random_subproblem(51, 120, 90, 0.15, 0.1, 4, infeasible=True)
+    qp, o_out = oracle_solve(sp)
+    opt, h_out = hip_solve(sp)
+    assert o_out[5] == 2 and h_out[5] == 2
+    rng = np.random.default_rng(9)
+    paths = []
+    for call in range(6):
+        sp2 = dict(sp)
+        sp2['dE'] = sp['dE'] * (1.0 + 2e-2 * rng.standard_normal(len(sp['dE'])))
+        sp2['E'] = sp['E'] + 1e-2 * rng.standard_normal(len(sp['E']))
+        sp2['x_k'] = np.clip(sp['x_k'] + 0.05 * rng.standard_normal(len(sp['x_k'])), -0.9, 0.9)
+        qp, o_out = oracle_solve(sp2, True, qp)
+        opt, h_out = hip_solve(sp2, True, opt)
+        assert o_out[5] == h_out[5]
+        st = opt.last_stats()
+        assert PATH_NAMES[st['path']] == o_out[6]['stats']['path'], (call, st, o_out[6]['stats'])
+        assert st['eqp'] == o_out[6]['stats']['eqp'] and st['ipm_iters'] == o_out[6]['stats']['ipm_iters']
+        if o_out[5] == 1 and o_out[6]['stats']['polished'] == 1:
+            _compare(o_out, h_out, opt, None)
+        paths.append(o_out[6]['stats']['path'])
+    opt.close()
+
+
 def test_c_abi_argument_errors(hip_lib):
     import ctypes as C
     from activesetmethods_amd.subproblem import QpData, HipSubOptimizer, AsmHipError
