@@ -2,7 +2,8 @@
 
 Independent NLP instances are the only data-parallel axis of the path: one SLP run is strictly
 sequential.  Scenarios are block-partitioned over ranks (one process per GPU), every rank solves its
-own block on its own handle / HIP stream with no data-path collective, and a single all-reduce of a
+own block - `concurrency` scenarios at a time, each on its own handle / HIP stream (stream pool) - with no
+data-path collective, and a single all-reduce of a
 <= 8-double vector (RCCL over xGMI on the GPU box, gloo in the CPU tests) merges the convergence
 statistics at the end: sum{#scenarios, #converged, SLP iterations, LP solves, restoration solves},
 max{final inf_pr, final inf_du, wall seconds}."""
@@ -51,13 +52,24 @@ def reduce_stats(stats, device=None):
     return out
 
 
-def solve_batch(make_model, n_scenarios, rank=0, world=1, run=None, reduce_device=None):
-    """Solve scenarios [lo, hi) of this rank one after another on this rank's GPU; `make_model(s)` returns
-    the Model of scenario s, `run(model)` the finished SLP object (default: activesetmethods_amd.optimize)."""
+def solve_batch(make_model, n_scenarios, rank=0, world=1, run=None, reduce_device=None, concurrency=1):
+    """Solve scenarios [lo, hi) of this rank on this rank's GPU; `make_model(s)` returns the Model of scenario s,
+    `run(model)` the finished SLP object (default: activesetmethods_amd.optimize).
+
+    `concurrency` > 1 runs that many scenarios at a time, each on its own handle = its own HIP stream, from a pool of
+    host threads (the C ABI is re-entrant per handle and releases the GIL): a single case300-sized SLP run is bound by
+    the latency of its serial kernel chain and leaves most of the GPU idle, so independent runs overlap almost freely.
+    Scenarios are handed to the next free worker in index order (dynamic assignment inside the rank); the results are
+    returned in index order and do not depend on the concurrency."""
     if run is None:
         from .slp import optimize as run
     lo, hi = partition(n_scenarios, world, rank)
     t0 = time.perf_counter()
-    slps = [run(make_model(s)) for s in range(lo, hi)]
+    if concurrency <= 1 or hi - lo <= 1:
+        slps = [run(make_model(s)) for s in range(lo, hi)]
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=int(concurrency)) as pool:
+            slps = list(pool.map(lambda s: run(make_model(s)), range(lo, hi)))
     st = local_stats(slps, time.perf_counter() - t0)
     return slps, reduce_stats(st, reduce_device)

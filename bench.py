@@ -33,6 +33,17 @@ def _host_cpu_quota():
     return os.cpu_count() or 1
 
 
+def _cpu_throttled_s():
+    """Seconds this cgroup has been frozen for exceeding its CPU quota so far (0 when unknown)."""
+    try:
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            if line.startswith("throttled_usec"):
+                return int(line.split()[1]) * 1e-6
+    except Exception:
+        pass
+    return 0.0
+
+
 HOST_THREADS = max(1, min(8, _host_cpu_quota() // 2))      # half the quota: BLAS workers spin-wait after every call
 for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
     os.environ.setdefault(_v, str(HOST_THREADS))
@@ -70,25 +81,28 @@ def run_batch(args, rank, world, local_rank, dist, torch):
     base = acopf.synthetic_case("case300", 1, 0.5)     # half the nominal synthetic load: Line-Search SLP converges in ~30 iterations
     per_gpu = args.steps
     total = per_gpu * world
-    shared = {}
-
-    def factory(d, r, c):
-        if "opt" in shared:                 # constraint bounds (the loads) differ per scenario: new LP skeleton
-            shared["opt"].close()
-        shared["opt"] = A.HipSubOptimizer(d, r, c, device=local_rank)
-        return shared["opt"]
+    def factory(d, r, c):                   # constraint bounds (the loads) differ per scenario: one LP skeleton = one handle each
+        return A.HipSubOptimizer(d, r, c, device=local_rank)
 
     def make_model(sidx):
         pr = acopf.acopf_problem(acopf.scenario_case(base, sidx), "case300-sized scenario %d" % sidx)
         return A.Model.from_problem(pr, A.Parameters(algorithm=args.algorithm, max_iter=args.max_iter, external_optimizer=factory))
 
+    def run(model, max_lp_solves=None):
+        slp = A.optimize(model, max_lp_solves)
+        if slp.optimizer is not None:
+            slp.optimizer.close()           # frees the handle's HBM; the statistics live on the SLP object
+        return slp
+
     if args.warmup:
-        A.optimize(make_model(10 ** 6 + rank), max_lp_solves=2)
+        run(make_model(10 ** 6 + rank), 2)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    thr0 = _cpu_throttled_s()
     t0 = time.perf_counter()
-    slps, stats = batch.solve_batch(make_model, total, rank, world, reduce_device="cuda" if dist is not None else None)
+    slps, stats = batch.solve_batch(make_model, total, rank, world, run=run, reduce_device="cuda" if dist is not None else None,
+                                    concurrency=args.concurrency)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -102,8 +116,10 @@ def run_batch(args, rank, world, local_rank, dist, torch):
                "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / per_gpu, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": WORKLOADS["c5"]["desc"], "algorithm": args.algorithm, "max_iter": args.max_iter,
-                          "scenarios_total": total, "parallelism": "scenarios block-partitioned, %d per GPU" % per_gpu},
-               "batch_stats": stats}
+                          "scenarios_total": total,
+                          "parallelism": "scenarios block-partitioned, %d per GPU, %d at a time per GPU (stream pool)" % (per_gpu, args.concurrency)},
+               "batch_stats": stats,
+               "host": {"cpu_quota": _host_cpu_quota(), "blas_threads": HOST_THREADS, "cgroup_throttled_s": round(_cpu_throttled_s() - thr0, 3)}}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
@@ -237,6 +253,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--scenarios-per-gpu", type=int, default=None, help="workload c5: scenarios per GPU (alias of --steps)")
     ap.add_argument("--max-iter", type=int, default=100, help="workload c5: SLP iteration cap per scenario")
+    ap.add_argument("--concurrency", type=int, default=3, help="workload c5: scenarios in flight per GPU (one handle / HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
@@ -247,6 +264,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.workload == "c5":
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # one hardware queue per concurrent scenario stream (ROCm default: 4)
     import torch
     dist = None
     if world > 1:

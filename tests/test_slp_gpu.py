@@ -178,3 +178,21 @@ def test_scenario_batch_on_one_gpu():
         pr = acopf.acopf_problem(acopf.scenario_case(base, sidx, 0.95, 1.05), "case3 scenario")
         mo, so = _oracle_run(pr, algorithm="Line Search", max_iter=100)
         assert abs(mo.obj_val - sh.problem.obj_val) < 1e-6 and so.lp_solves == sh.lp_solves
+    shared["opt"].close()
+
+    # stream pool: three scenarios in flight, one handle / HIP stream each, from host threads - same results, same order
+    def make_model_pool(sidx):
+        pr = acopf.acopf_problem(acopf.scenario_case(base, sidx, 0.95, 1.05), "case3 scenario")
+        return A.Model.from_problem(pr, A.Parameters(algorithm="Line Search", max_iter=100))
+
+    def run(model):
+        slp = A.optimize(model)
+        slp.optimizer.close()
+        return slp
+
+    slps2, stats2 = batch.solve_batch(make_model_pool, 4, rank=0, world=1, run=run, concurrency=3)
+    assert [s.lp_solves for s in slps2] == [s.lp_solves for s in slps]
+    assert all(s2.problem.obj_val == s1.problem.obj_val for s1, s2 in zip(slps, slps2))
+    assert np.array_equal(np.concatenate([s.x for s in slps2]), np.concatenate([s.x for s in slps]))
+    for k in ("scenarios", "converged", "iterations", "lp_solves", "restoration_solves", "inf_pr", "inf_du"):
+        assert stats2[k] == stats[k]
