@@ -227,6 +227,7 @@ struct Dev {
         return v;
     }
     void launch_gemv_n(const double* A, const double* x, double* out) {
+        if (h->M == 0) return;                         // LP without rows
         if (const double* v = sparse_vals(A)) {
             int id = begin(ASM_K_GEMV, 2.0 * h->sp_nnz, 20.0 * h->sp_nnz + 12.0 * h->M);
             hipLaunchKernelGGL(k_spmv_n, dim3((unsigned)((h->M + 255) / 256)), dim3(256), 0, h->stream, h->d_sp_ptr, h->d_sp_col, v, x, out, h->M);
@@ -238,6 +239,10 @@ struct Dev {
         end(id);
     }
     void launch_gemv_t(const double* A, const double* y, double* out) {
+        if (h->M == 0) {                               // LP without rows: A'y = 0
+            HIPCHK(hipMemsetAsync(out, 0, h->ldn * sizeof(double), h->stream));
+            return;
+        }
         if (const double* v = sparse_vals(A)) {
             int id = begin(ASM_K_GEMV, 2.0 * h->sp_nnz, 24.0 * h->sp_nnz + 12.0 * h->n);
             hipLaunchKernelGGL(k_spmv_t, dim3((unsigned)((h->ldn + 255) / 256)), dim3(256), 0, h->stream, h->d_sc_ptr, h->d_sc_row, h->d_sc_pos, v,
@@ -281,6 +286,7 @@ struct Dev {
     // per (row tile, k-chunk) non-zero flags of Ah for the chunk-skipping Schur build (sparse Jacobians only)
     void tile_flags() {
         h->nz_valid = false;
+        if (h->M == 0) return;
         const int nch = (int)(h->ldn / ASM_KC);
         if (h->dense_fast || nch > ASM_MAXCHUNKS || h->nnz * 8 > h->M * h->n) return;     // dense pattern: nothing to skip
         h->nz_T = pick_tile(h->M);
@@ -396,6 +402,7 @@ struct Dev {
     }
 
     void chol(int Ms, double thr = 1e-14) {
+        if (Ms <= 0) return;
         int id = begin(ASM_K_CHOL, (double)Ms * Ms * Ms / 3.0, 8.0 * 1.5 * Ms * (double)Ms);
         run_sequence(thr == 1e-14 ? 1 : 2, Ms, Ms == (int)h->M, [&] {
             chol_launches(Ms, thr);
@@ -518,6 +525,7 @@ struct Dev {
     }
     // rel[j] = max_i |J_ij| / max_k |J_ik|   (host, n) - matrix-based cap of the column scale
     void col_relmax(double* rel) {
+        if (h->M == 0) { std::fill(rel, rel + h->n, 0.0); return; }
         int64_t R = std::min<int64_t>((h->M + 31) / 32, ASM_TMAXCHUNKS);
         int64_t chunk = (h->M + R - 1) / R;
         R = (h->M + chunk - 1) / chunk;
@@ -533,6 +541,7 @@ struct Dev {
     // Ah = diag(1/rho) J diag(c);  rho (host, M)
     void scale(const double* c, double* rho) {
         h->spv_Ah_valid = false;
+        if (h->M == 0) return;
         h2d(h->d_c, c, h->n, h->ldn);
         int id = begin(ASM_K_SCALE, 0.0, 8.0 * 3.0 * h->M * h->ldn);
         hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)h->M), dim3(256), 0, h->stream, h->d_J, h->d_c, h->d_Ah, h->d_rho, h->n,
@@ -1570,6 +1579,7 @@ int asm_jac_row_norms(asm_handle* h, double* out_m) {
         HIPCHK(hipSetDevice(h->device));
         Dev d(h);
         d.assemble();
+        if (h->m == 0) return;
         hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((h->m + 3) / 4)), dim3(256), 0, h->stream, h->d_J, h->ldn, h->d_vecM, h->m, h->ldn);
         d.d2h(out_m, h->d_vecM, h->m);
     });
@@ -1586,8 +1596,10 @@ int asm_kt_residuals(asm_handle* h, const double* df, const double* lambda, cons
         vec lam(h->M, 0.0), jtl(n), rn(std::max<int64_t>(m, 1));
         for (int64_t i = 0; i < m; ++i) lam[i] = lambda[i];
         d.gemv_t(h->d_J, lam.data(), jtl.data());
-        hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, h->stream, h->d_J, h->ldn, h->d_vecM, m, h->ldn);
-        if (m > 0) d.d2h(rn.data(), h->d_vecM, m);
+        if (m > 0) {
+            hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, h->stream, h->d_J, h->ldn, h->d_vecM, m, h->ldn);
+            d.d2h(rn.data(), h->d_vecM, m);
+        }
         // common.jl:38-43
         double res = 0.0, ndf = 0.0;
         for (int64_t j = 0; j < n; ++j) {

@@ -244,7 +244,7 @@ class IPM:
             dS = np.where(ineq, g / np.where(ineq, pi, 1.0), 0.0)
             if ns:
                 np.add.at(dS, lp.srow, ths_inv)
-            S = dsyrk(1.0, A * np.sqrt(thp_inv), lower=True)          # lower triangle of A diag(thp_inv) A'
+            S = dsyrk(1.0, A * np.sqrt(thp_inv), lower=True) if M else np.zeros((0, 0))   # lower triangle of A diag(thp_inv) A'
             idx = np.arange(M)
             S[idx, idx] += dS
             diag0 = S[idx, idx].copy()

@@ -160,3 +160,13 @@ def test_acopf_case3_known_objective(alg):
     O.optimize(m)
     assert m.status == 0
     assert abs(m.obj_val - d["expected_objective"]) <= 1e-3 * d["expected_objective"]
+
+
+def test_edge_case_shapes_have_their_hand_worked_answers():
+    from tests.util import edge_case_subproblems, EDGE_CASE_ANSWERS, oracle_solve
+    for name, sp in edge_case_subproblems().items():
+        qp, out = oracle_solve(sp)
+        assert out[5] == 1, name
+        p_ref, lam_ref = EDGE_CASE_ANSWERS[name]
+        assert np.allclose(out[0], p_ref, atol=1e-12), name
+        assert np.allclose(out[1], lam_ref, atol=1e-12), name

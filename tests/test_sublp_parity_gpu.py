@@ -115,6 +115,20 @@ def test_restoration_sequence_path_decisions_match():
     opt.close()
 
 
+def test_edge_case_shapes():
+    """No rows, one variable, rows without entries, all variables fixed, zero radius, cancelling duplicates: the HIP path
+    must return the hand-worked answers (and the oracle's) without special-casing by the caller."""
+    from tests.util import edge_case_subproblems, EDGE_CASE_ANSWERS
+    for name, sp in edge_case_subproblems().items():
+        qp, o_out = oracle_solve(sp)
+        opt, h_out = hip_solve(sp)
+        assert h_out[5] == 1, name
+        p_ref, lam_ref = EDGE_CASE_ANSWERS[name]
+        assert np.allclose(h_out[0], p_ref, atol=1e-12) and np.allclose(h_out[1], lam_ref, atol=1e-12), name
+        _compare(o_out, h_out, opt, None)
+        opt.close()
+
+
 def test_c_abi_argument_errors(hip_lib):
     import ctypes as C
     from activesetmethods_amd.subproblem import QpData, HipSubOptimizer, AsmHipError

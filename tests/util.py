@@ -68,3 +68,37 @@ def hip_solve(sp, feasibility=False, opt=None, device=0):
 def rel_err(a, b):
     a = np.asarray(a, float); b = np.asarray(b, float)
     return float(np.abs(a - b).max(initial=0.0) / max(1.0, np.abs(b).max(initial=0.0)))
+
+
+def edge_case_subproblems():
+    """Degenerate shapes of the sub-LP boundary: no rows, one variable (the README problem at x = 0), rows without
+    Jacobian entries, all variables fixed, zero trust region, duplicates cancelling to a stored exact zero."""
+    e = np.zeros(0); I = np.zeros(0, np.int64)
+    one = lambda **kw: dict(f=0.0, **kw)
+    return {
+        "no_rows": one(n=3, m=0, j_row=I, j_col=I, dE=e, df=np.array([1.0, -2.0, 0.0]), E=e, x_k=np.zeros(3), c_lb=e, c_ub=e,
+                       v_lb=-np.ones(3), v_ub=np.ones(3), delta=0.4),
+        "one_var": one(n=1, m=1, j_row=np.array([1]), j_col=np.array([1]), dE=np.array([-1.0]), df=np.array([1.0]), E=np.array([0.0]),
+                       x_k=np.zeros(1), c_lb=np.array([2.0]), c_ub=np.array([2.0]), v_lb=np.array([-INF]), v_ub=np.array([INF]), delta=1000.0),
+        "no_entries": one(n=2, m=2, j_row=I, j_col=I, dE=e, df=np.array([1.0, 1.0]), E=np.array([0.5, -0.5]), x_k=np.zeros(2),
+                          c_lb=np.array([0.0, -INF]), c_ub=np.array([INF, 0.0]), v_lb=-np.ones(2), v_ub=np.ones(2), delta=0.4),
+        "all_fixed": one(n=2, m=1, j_row=np.array([1, 1]), j_col=np.array([1, 2]), dE=np.array([1.0, 1.0]), df=np.array([1.0, -1.0]),
+                         E=np.array([0.0]), x_k=np.array([0.3, 0.7]), c_lb=np.array([-1.0]), c_ub=np.array([1.0]),
+                         v_lb=np.array([0.3, 0.7]), v_ub=np.array([0.3, 0.7]), delta=0.4),
+        "zero_radius": one(n=2, m=1, j_row=np.array([1, 1]), j_col=np.array([1, 2]), dE=np.array([1.0, 1.0]), df=np.array([1.0, -1.0]),
+                           E=np.array([0.0]), x_k=np.array([0.3, 0.7]), c_lb=np.array([-1.0]), c_ub=np.array([1.0]),
+                           v_lb=-np.ones(2), v_ub=np.ones(2), delta=0.0),
+        "cancelling_duplicates": one(n=2, m=1, j_row=np.array([1, 1, 1]), j_col=np.array([1, 1, 2]), dE=np.array([1.0, -1.0, 2.0]),
+                                     df=np.array([1.0, 1.0]), E=np.array([0.1]), x_k=np.zeros(2), c_lb=np.array([0.0]), c_ub=np.array([0.0]),
+                                     v_lb=-np.ones(2), v_ub=np.ones(2), delta=0.4),
+    }
+
+
+EDGE_CASE_ANSWERS = {      # worked by hand from the LP each case poses
+    "no_rows": ([-0.4, 0.4, 0.0], []),
+    "one_var": ([-2.0], [-1.0]),                 # -p = 2 ; df - J'lambda = 1 - (-1)(-1) = 0
+    "no_entries": ([-0.4, -0.4], [0.0, 0.0]),
+    "all_fixed": ([0.0, 0.0], [0.0]),
+    "zero_radius": ([0.0, 0.0], [0.0]),
+    "cancelling_duplicates": ([-0.4, -0.05], [0.5]),   # 2 p2 = -0.1 ; 1 - 2 lambda = 0
+}
