@@ -343,14 +343,17 @@ struct Dev {
         if (nz) fl *= nzfrac >= 0.0 ? nzfrac : h->nz_fraction;
         int kid = (h->use_graphs || cur != h->stream) ? -1 : begin(ASM_K_SYRK_KERNEL, fl, 8.0 * ((double)(Ms + MsB) * K + (double)Ms * MsB));
         struct EndGuard { Dev* d; int id; ~EndGuard() { d->end(id); } } guard_{this, kid};
-        if (T == 4)
-            hipLaunchKernelGGL((k_syrk<4, 8>), dim3((unsigned)blocks), dim3(512), 0, cur, A, ld, idx, row0, Ms, K, theta, diag, S,
+        if (T == 4 && mode == 1 && !nz && K % 16 == 0)      // Cholesky updates: 16-wide k-chunks, two workgroups per CU
+            hipLaunchKernelGGL((k_syrk<4, 8, 16, 4>), dim3((unsigned)blocks), dim3(512), 0, cur, A, ld, idx, row0, Ms, K, theta, diag, S,
+                               ldS, srow0, mode, MsB, ntj, nz, nzpitch);
+        else if (T == 4)
+            hipLaunchKernelGGL((k_syrk<4, 8, 32, 2>), dim3((unsigned)blocks), dim3(512), 0, cur, A, ld, idx, row0, Ms, K, theta, diag, S,
                                ldS, srow0, mode, MsB, ntj, nz, nzpitch);
         else if (T == 2)
-            hipLaunchKernelGGL((k_syrk<2, 4>), dim3((unsigned)blocks), dim3(256), 0, cur, A, ld, idx, row0, Ms, K, theta, diag, S,
+            hipLaunchKernelGGL((k_syrk<2, 4, 32, 1>), dim3((unsigned)blocks), dim3(256), 0, cur, A, ld, idx, row0, Ms, K, theta, diag, S,
                                ldS, srow0, mode, MsB, ntj, nz, nzpitch);
         else
-            hipLaunchKernelGGL((k_syrk<1, 4>), dim3((unsigned)blocks), dim3(256), 0, cur, A, ld, idx, row0, Ms, K, theta, diag, S,
+            hipLaunchKernelGGL((k_syrk<1, 4, 32, 1>), dim3((unsigned)blocks), dim3(256), 0, cur, A, ld, idx, row0, Ms, K, theta, diag, S,
                                ldS, srow0, mode, MsB, ntj, nz, nzpitch);
     }
 

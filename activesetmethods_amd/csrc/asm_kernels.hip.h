@@ -147,16 +147,18 @@ __global__ __launch_bounds__(256) void k_gemv_t_stage2(const double* __restrict_
 // the four wavefronts form a 2x2 grid and each owns T x T MFMA tiles of 16x16.
 // v_mfma_f64_16x16x4_f64 operand maps (cdna_hip_programming.md:161): lane l holds A[i=l&15][k=l>>4] and
 // B[k=l>>4][j=l&15]; result register r of lane l is D[row=(l>>4)+4r][col=l&15].
-template <int T, int NW>
-__global__ __launch_bounds__(64 * NW) void k_syrk(const double* __restrict__ A, int64_t ld, const int* __restrict__ idx, int64_t row0,
+// KC = k-chunk staged through LDS (32: 139 KB of LDS, one workgroup per CU; 16: 74 KB and <= 128 VGPRs, two per CU -
+// used for the Cholesky updates so that the latency-bound panel kernels of the look-ahead stream can share the CUs).
+template <int T, int NW, int KC, int WPE>
+__global__ __launch_bounds__(64 * NW, WPE) void k_syrk(const double* __restrict__ A, int64_t ld, const int* __restrict__ idx, int64_t row0,
                                               int Ms, int K, const double* __restrict__ theta, const double* __restrict__ diag,
                                               double* __restrict__ S, int64_t ldS, int64_t srow0, int mode, int MsB, int ntj,
                                               const unsigned char* __restrict__ nzflags, int nzpitch) {
     constexpr int TS = 32 * T;
     // two LDS stages: the global loads of chunk c+1 are issued before the MFMAs of chunk c and written to the
     // other stage afterwards, so HBM/L2 latency hides under 16*T*T/4 matrix instructions; one barrier per chunk.
-    __shared__ __attribute__((aligned(16))) double As[2][TS * ASM_PITCH];
-    __shared__ __attribute__((aligned(16))) double Bs[2][TS * ASM_PITCH];
+    __shared__ __attribute__((aligned(16))) double As[2][TS * (KC + 2)];
+    __shared__ __attribute__((aligned(16))) double Bs[2][TS * (KC + 2)];
     int bi, bj;
     if (ntj > 0) {
         // rectangular enumeration (Cholesky in-panel update): all row tiles x the first ntj column tiles
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(64 * NW) void k_syrk(const double* __restrict__ A, 
     const double asign = mode != 0 ? -1.0 : 1.0;
 
     // staging assignment: TS rows x KC doubles per operand; each thread moves 2 doubles (16 B) per pass
-    constexpr int PER_ROW = ASM_KC / 2;                 // threads per row
+    constexpr int PER_ROW = KC / 2;                 // threads per row
     constexpr int ROWS_PER_PASS = 64 * NW / PER_ROW;
     constexpr int PASSES = TS / ROWS_PER_PASS;          // = 2T
     const int lr = tid / PER_ROW, lk = (tid % PER_ROW) * 2;
@@ -228,16 +230,16 @@ __global__ __launch_bounds__(64 * NW) void k_syrk(const double* __restrict__ A, 
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
             int r = ps * ROWS_PER_PASS + lr;
-            *reinterpret_cast<double2*>(&As[st][r * ASM_PITCH + lk]) = ra[ps];
-            *reinterpret_cast<double2*>(&Bs[st][r * ASM_PITCH + lk]) = rb[ps];
+            *reinterpret_cast<double2*>(&As[st][r * (KC + 2) + lk]) = ra[ps];
+            *reinterpret_cast<double2*>(&Bs[st][r * (KC + 2) + lk]) = rb[ps];
         }
     };
     // k-chunks to visit: all of them, or (Schur build of a sparse Jacobian) only those where both operand tiles
     // hold a non-zero - the skipped products are exact zeros, and the list keeps increasing k order, so the
     // result is bitwise the one of the dense sweep.
-    __shared__ int s_list[ASM_MAXCHUNKS];
+    __shared__ int s_list[KC == 32 ? ASM_MAXCHUNKS : 1];        // chunk lists exist at the 32-column granularity of the flags only
     __shared__ int s_cnt;
-    int nchunks = K / ASM_KC;
+    int nchunks = K / KC;
     if (nzflags) {
         if (w == 0) {
             const unsigned char* fa = nzflags + (int64_t)bi * nzpitch;
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(64 * NW) void k_syrk(const double* __restrict__ A, 
         __syncthreads();
         nchunks = s_cnt;
     }
-    auto chunk_k0 = [&](int i) { return (nzflags ? s_list[i] : i) * ASM_KC; };
+    auto chunk_k0 = [&](int i) { return (nzflags ? s_list[i] : i) * KC; };
     if (nchunks > 0) {
         gload(chunk_k0(0));
         lstore(0);
@@ -265,12 +267,12 @@ __global__ __launch_bounds__(64 * NW) void k_syrk(const double* __restrict__ A, 
         const int st = c & 1;
         if (c + 1 < nchunks) gload(chunk_k0(c + 1));
 #pragma unroll
-        for (int kk = 0; kk < ASM_KC; kk += 4) {
+        for (int kk = 0; kk < KC; kk += 4) {
             double af[TI], bf[TJ];
 #pragma unroll
-            for (int i = 0; i < TI; ++i) af[i] = As[st][(wr * 16 * TI + i * 16 + (lane & 15)) * ASM_PITCH + kk + (lane >> 4)];
+            for (int i = 0; i < TI; ++i) af[i] = As[st][(wr * 16 * TI + i * 16 + (lane & 15)) * (KC + 2) + kk + (lane >> 4)];
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) bf[j] = Bs[st][(wc * 16 * TJ + j * 16 + (lane & 15)) * ASM_PITCH + kk + (lane >> 4)];
+            for (int j = 0; j < TJ; ++j) bf[j] = Bs[st][(wc * 16 * TJ + j * 16 + (lane & 15)) * (KC + 2) + kk + (lane >> 4)];
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
