@@ -209,3 +209,65 @@ def test_full_size_c4_lp_properties():
     opt, out = hip_solve(sp)
     _lp_properties(sp, out, opt)
     opt.close()
+
+
+def _restoration_lp_properties(sp, out):
+    """Optimality certificates of a restoration-phase solution, recomputed in NumPy from the LP that subproblem.jl:250-382
+    poses: rows with the literal `b -= abs(viol)` shift and their +-unit slack columns, slack lower bounds, objective
+    sum(slacks).  Checks primal feasibility, dual sign feasibility, and the optimal value against HiGHS (the value is
+    unique also when the optimal point is not)."""
+    X, lam, mU, mL, ps, st = out
+    assert st == 1
+    n, m = sp['n'], sp['m']
+    J = np.zeros((m, n))
+    np.add.at(J, (sp['j_row'] - 1, sp['j_col'] - 1), sp['dE'])
+    c_lb, c_ub, b = sp['c_lb'], sp['c_ub'], sp['E']
+    viol = np.where(b > c_ub, c_ub - b, np.where(b < c_lb, c_lb - b, 0.0))
+    bs = b - np.abs(viol)
+    lb = np.maximum(-sp['delta'], sp['v_lb'] - sp['x_k']); ub = np.minimum(sp['delta'], sp['v_ub'] - sp['x_k'])
+    assert np.all(X >= lb - 1e-12) and np.all(X <= ub + 1e-12)
+    Jp = J @ X
+    two = np.isfinite(c_lb) & np.isfinite(c_ub)
+    eq = c_lb == c_ub
+    s1 = np.array([ps[i][0] for i in range(m)]); s2 = np.array([ps[i][1] if len(ps[i]) > 1 else 0.0 for i in range(m)])
+    slo1 = np.where(two, np.where(viol < 0, 0.0, -viol), -np.abs(viol))
+    slo2 = np.where(two, np.where(viol < 0, viol, 0.0), 0.0)
+    tol = 1e-8 * (1.0 + np.abs(bs) + np.abs(Jp))
+    assert np.all(s1 >= slo1 - tol) and np.all(s2[two] >= slo2[two] - tol[two])
+    r_lo = c_lb - bs; r_up = c_ub - bs
+    only_lo = np.isfinite(c_lb) & ~np.isfinite(c_ub); only_up = np.isfinite(c_ub) & ~np.isfinite(c_lb); rng = two & ~eq
+    assert np.all(np.abs(s1 - s2 + Jp - r_lo)[eq] <= tol[eq])
+    assert np.all((s1 + Jp - r_lo)[rng | only_lo] >= -tol[rng | only_lo])
+    assert np.all((-s2 + Jp - r_up)[rng] <= tol[rng])
+    assert np.all((-s1 + Jp - r_up)[only_up] <= tol[only_up])
+    assert np.all(lam[only_lo] >= 0) and np.all(lam[only_up] <= 0)
+    # optimal value against an independent LP code on the identical LP (the merged multiplier of a range row,
+    # subproblem.jl:513-515, does not determine the duals of its two LP rows, so strong duality cannot be recomputed
+    # from the outputs): SciPy's HiGHS on the sparse form with explicit slack columns
+    import scipy.sparse as sps
+    from scipy.optimize import linprog
+    from oracle.subproblem import QpData, QpModel, compute_jacobian_matrix
+    A0, stored = compute_jacobian_matrix(m, n, sp['j_row'] - 1, sp['j_col'] - 1, sp['dE'])
+    qp = QpModel(QpData(sp['df'], sp['f'], A0, sp['E'], c_lb, c_ub, sp['v_lb'], sp['v_ub'], stored), sp['j_row'], sp['j_col'])
+    lp = qp.build_lp(sp['x_k'], sp['delta'], True)
+    Afull = sps.hstack([sps.csr_matrix(lp.A), sps.csr_matrix((lp.scoef, (lp.srow, np.arange(lp.ns))), shape=(lp.M, lp.ns))]).tocsr()
+    e, g, l = lp.rtype == 0, lp.rtype == 1, lp.rtype == -1
+    res = linprog(np.concatenate([lp.q, lp.w]), A_ub=sps.vstack([-Afull[g], Afull[l]]).tocsr(), b_ub=np.concatenate([-lp.r[g], lp.r[l]]),
+                  A_eq=Afull[e], b_eq=lp.r[e], bounds=np.r_[np.c_[lp.lb, lp.ub], np.c_[lp.slo, np.full(lp.ns, np.inf)]], method="highs")
+    assert res.status == 0
+    primal = s1.sum() + s2[two].sum()
+    assert abs(primal - res.fun) <= 1e-7 * max(1.0, abs(res.fun)), (primal, res.fun)
+
+
+@pytest.mark.parametrize("name,delta", [("case118", 0.4), ("case1354pegase", 1000.0)])
+def test_full_size_restoration_lp_properties(name, delta):
+    """Restoration-phase LP at the flat start of the case118- and case1354pegase-sized grids (the latter is
+    BASELINE.json configs[3] size): checked through the LP's own optimality certificates."""
+    from activesetmethods_amd import acopf
+    pr = acopf.acopf_problem(acopf.synthetic_case(name, 1), name)
+    x = pr.x0.copy()
+    sp = dict(n=pr.n, m=pr.m, j_row=pr.j_row, j_col=pr.j_col, dE=pr.eval_jac_g(x, np.zeros(pr.nnz)), df=pr.eval_grad_f(x, np.zeros(pr.n)),
+              f=pr.eval_f(x), E=pr.eval_g(x, np.zeros(pr.m)), x_k=x, c_lb=pr.g_L, c_ub=pr.g_U, v_lb=pr.x_L, v_ub=pr.x_U, delta=delta)
+    opt, out = hip_solve(sp, True)
+    _restoration_lp_properties(sp, out)
+    opt.close()
