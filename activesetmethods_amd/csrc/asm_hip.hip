@@ -105,8 +105,7 @@ struct asm_handle {
     double *d_dE = nullptr, *d_J = nullptr, *d_Ah = nullptr, *d_S = nullptr;
     double *d_c = nullptr, *d_rho = nullptr, *d_theta = nullptr, *d_diag = nullptr, *d_diag0 = nullptr;
     double *d_vecN = nullptr, *d_vecM = nullptr, *d_vecM2 = nullptr, *d_part = nullptr, *d_partial = nullptr;
-    double *d_Linv = nullptr, *d_tpart = nullptr, *d_Binv = nullptr, *d_BinvT = nullptr, *d_wpart = nullptr, *d_wt = nullptr;
-    int64_t tpart_len = 0;
+    double *d_Linv = nullptr, *d_Binv = nullptr, *d_BinvT = nullptr, *d_wpart = nullptr, *d_wt = nullptr;
     unsigned char* d_nz = nullptr;  // (row tile, k-chunk) non-zero flags of Ah; second half: flags of a gathered row set
     int64_t nz_half = 0;
     // sparse copy of the fixed Jacobian pattern for the matrix-vector products (sparse patterns only)
@@ -1113,7 +1112,7 @@ void free_device(asm_handle* h) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(h->d_perm); F(h->d_ustart); F(h->d_uoff); F(h->d_adjoff);
     F(h->d_dE); F(h->d_J); F(h->d_Ah); F(h->d_S); F(h->d_c); F(h->d_rho); F(h->d_theta); F(h->d_diag); F(h->d_diag0);
-    F(h->d_vecN); F(h->d_vecM); F(h->d_vecM2); F(h->d_part); F(h->d_partial); F(h->d_idx); F(h->d_Linv); F(h->d_tpart); F(h->d_Binv); F(h->d_wpart); F(h->d_BinvT); F(h->d_wt);
+    F(h->d_vecN); F(h->d_vecM); F(h->d_vecM2); F(h->d_part); F(h->d_partial); F(h->d_idx); F(h->d_Linv); F(h->d_Binv); F(h->d_wpart); F(h->d_BinvT); F(h->d_wt);
     h->d_Binv = h->d_wpart = h->d_BinvT = h->d_wt = nullptr; F(h->d_ipm); F(h->d_ipm_i); F(h->d_nz);
     h->d_nz = nullptr; h->nz_valid = false;
     F(h->d_sp_ptr); F(h->d_sp_col); F(h->d_sc_ptr); F(h->d_sc_row); F(h->d_sc_pos); F(h->d_sp_off); F(h->d_spv_Ah); F(h->d_spv_J);
@@ -1126,7 +1125,7 @@ void free_device(asm_handle* h) {
     h->d_perm = h->d_ustart = h->d_uoff = h->d_adjoff = nullptr;
     h->d_dE = h->d_J = h->d_Ah = h->d_S = h->d_c = h->d_rho = h->d_theta = h->d_diag = h->d_diag0 = nullptr;
     h->d_vecN = h->d_vecM = h->d_vecM2 = h->d_part = h->d_partial = nullptr;
-    h->d_Linv = h->d_tpart = nullptr;
+    h->d_Linv = nullptr;
     h->d_idx = nullptr;
     h->h_pin = nullptr;
 }
@@ -1248,8 +1247,6 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     dmalloc(&h->d_BinvT, (h->Mp / ASM_WB + 1) * (int64_t)ASM_WB * ASM_WB);
     dmalloc(&h->d_wpart, (h->Mp / ASM_WBROWS + 2) * (int64_t)ASM_WB);
     dmalloc(&h->d_wt, ASM_WB);
-    h->tpart_len = (h->Mp / ASM_TRSV_ROWS + 2) * ASM_NB;
-    dmalloc(&h->d_tpart, 2 * h->tpart_len);
     h->nz_half = (h->Mp / 32 + 1) * (h->ldn / ASM_KC + 1);
     dmalloc(&h->d_nz, 2 * h->nz_half);
     if (h->sp_nnz > 0) {

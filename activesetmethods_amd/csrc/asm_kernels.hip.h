@@ -13,7 +13,8 @@
 //   k_syrk<T>         MFMA  S = Ah[idx,:] diag(theta) Ah[idx,:]' (+diag)  and  S22 -= P P'   (v_mfma_f64_16x16x4_f64)
 //   k_potrf_diag      LDS   64x64 diagonal block Cholesky with static pivot guard
 //   k_trsm_panel      LDS   panel  P = S21 L11^-T
-//   k_trsv_*          HBM   blocked forward / backward substitution (wave-shuffle dot products)
+//   k_trtri512, k_wtrsv_*  HBM   512-wide block inverses and the wide-block forward / backward substitution
+//   k_spmv_*          HBM   matrix-vector products on the CSR / CSC copy of sparse patterns
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -504,114 +505,6 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ S, int6
         int gi = i0 + rr;
         if (gi < Ms && c < nb) S[(int64_t)gi * ldS + k0 + c] = X[rr * ASM_DP + c];
     }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Blocked triangular solves with the row-major lower factor: ONE launch per 64-wide block and direction.
-// The diagonal blocks are applied through their explicit inverses (k_potrf_diag), so a step has no
-// sequential 64-stage substitution; every workgroup recomputes the 64 new unknowns redundantly from LDS.
-//
-// forward  (L z = b), step k, right-looking:   z_k = Linv_kk w[k0:k1] ;  w[i] -= L[i,k0:k1] . z_k   (i >= k1)
-//          one wavefront per row of the tall panel: a coalesced 512-B row segment and a wave-shuffle reduction.
-// backward (L' x = z), step k, left-looking:   x_k = Linv_kk' (z_k - s_k),  s_k[c] = sum_{i>=k1} L[i,k0+c] x[i]
-//          s_k arrives as per-workgroup partial sums written by step k+1 (summed in index order:
-//          deterministic); the same launch then produces the partial sums of block k-1 over rows >= k0.
-#define ASM_TRSV_ROWS 64      // rows of the tall panel per workgroup (forward)
-#define ASM_TRSV_BROWS 256    // rows per workgroup for the backward partial sums
-__global__ __launch_bounds__(256) void k_trsv_fwd_step(const double* __restrict__ L, int64_t ld, const double* __restrict__ Linv,
-                                                       int k0, int nb, int Ms, double* __restrict__ w, double* __restrict__ z) {
-    __shared__ double Li[ASM_NB * ASM_DP];      // Linv_kk, then re-used for the 64x64 tile of the panel
-    __shared__ double bk[ASM_NB], zk[ASM_NB];
-    __shared__ double red[4][ASM_NB];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const double* Lb = Linv + (int64_t)(k0 / ASM_NB) * ASM_NB * ASM_NB;
-    for (int e = tid; e < ASM_NB * ASM_NB; e += 256) Li[(e >> 6) * ASM_DP + (e & 63)] = Lb[e];
-    if (tid < ASM_NB) bk[tid] = tid < nb ? w[k0 + tid] : 0.0;
-    __syncthreads();
-    {   // z_k = Linv_kk b_k : row `lane`, the 64 columns split over the 4 wavefronts
-        double acc = 0.0;
-        for (int c = wv * 16; c < wv * 16 + 16; ++c) acc = fma(Li[lane * ASM_DP + c], bk[c], acc);
-        red[wv][lane] = acc;
-    }
-    __syncthreads();
-    if (tid < ASM_NB) {
-        double acc = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-        zk[tid] = acc;
-        if (blockIdx.x == 0 && tid < nb) z[k0 + tid] = acc;
-    }
-    __syncthreads();
-    const int k1 = k0 + nb;
-    const int base = k1 + blockIdx.x * ASM_TRSV_ROWS;
-    if (base >= Ms) return;
-    // stage this workgroup's 64 x 64 tile of the panel (coalesced 512-B row segments)
-    for (int e = tid; e < ASM_TRSV_ROWS * ASM_NB; e += 256) {
-        int rr = e >> 6, c = e & 63;
-        int i = base + rr;
-        Li[rr * ASM_DP + c] = (i < Ms && c < nb) ? L[(int64_t)i * ld + k0 + c] : 0.0;
-    }
-    __syncthreads();
-    {
-        double acc = 0.0;
-        for (int c = wv * 16; c < wv * 16 + 16; ++c) acc = fma(Li[lane * ASM_DP + c], zk[c], acc);
-        red[wv][lane] = acc;
-    }
-    __syncthreads();
-    if (tid < ASM_TRSV_ROWS) {
-        int i = base + tid;
-        if (i < Ms) w[i] -= (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-    }
-}
-
-__global__ __launch_bounds__(256) void k_trsv_bwd_step(const double* __restrict__ L, int64_t ld, const double* __restrict__ Linv,
-                                                       int k0, int nb, int Ms, const double* __restrict__ z, double* __restrict__ x,
-                                                       const double* __restrict__ part_in, int n_in, double* __restrict__ part_out) {
-    __shared__ double Li[ASM_NB * ASM_DP];
-    __shared__ double tk[ASM_NB], xk[ASM_NB];
-    __shared__ double red[4][ASM_NB];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const double* Lb = Linv + (int64_t)(k0 / ASM_NB) * ASM_NB * ASM_NB;
-    for (int e = tid; e < ASM_NB * ASM_NB; e += 256) Li[(e >> 6) * ASM_DP + (e & 63)] = Lb[e];
-    {   // s_k = sum of the partial sums of step k+1 (fixed order: group g = wv, wv+4, ... then the 4 wavefronts)
-        double s = 0.0;
-        for (int g = wv; g < n_in; g += 4) s += part_in[(int64_t)g * ASM_NB + lane];
-        red[wv][lane] = s;
-    }
-    __syncthreads();
-    if (tid < ASM_NB) tk[tid] = tid < nb ? z[k0 + tid] - ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) : 0.0;
-    __syncthreads();
-    {   // x_k = Linv' t : x_c = sum_r Linv[r][c] t[r], rows split over the 4 wavefronts
-        double acc = 0.0;
-        for (int r = wv * 16; r < wv * 16 + 16; ++r) acc = fma(Li[r * ASM_DP + lane], tk[r], acc);
-        __syncthreads();
-        red[wv][lane] = acc;
-    }
-    __syncthreads();
-    if (tid < ASM_NB) {
-        double acc = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-        xk[tid] = acc;
-        if (blockIdx.x == 0 && tid < nb) x[k0 + tid] = acc;
-    }
-    __syncthreads();
-    if (k0 == 0) return;
-    // partial sums for block k-1 (columns k0-64 .. k0-1) over this workgroup's rows i >= k0
-    const int cprev = k0 - ASM_NB;
-    const int base = k0 + blockIdx.x * ASM_TRSV_BROWS;
-    double acc = 0.0;
-    for (int r0 = wv; r0 < ASM_TRSV_BROWS; r0 += 32) {       // 8 rows per batch: the loads are issued together
-        double lv[8], xv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            int i = base + r0 + 4 * u;
-            bool ok = i < Ms;
-            lv[u] = ok ? L[(int64_t)i * ld + cprev + lane] : 0.0;
-            xv[u] = ok ? ((i < k0 + nb) ? xk[i - k0] : x[i]) : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc = fma(lv[u], xv[u], acc);
-    }
-    red[wv][lane] = acc;
-    __syncthreads();
-    if (tid < ASM_NB) part_out[(int64_t)blockIdx.x * ASM_NB + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
 // out[i] = || A[i, :] ||_2   (one wavefront per row) - KT_residuals / compute_nu! (common.jl:41, slp.jl:58)
