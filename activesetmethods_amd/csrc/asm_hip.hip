@@ -410,7 +410,7 @@ struct Dev {
             chol_launches(Ms, thr);
             hipLaunchKernelGGL(k_trtri512, dim3((unsigned)((Ms + ASM_WB - 1) / ASM_WB), ASM_WSUB), dim3(256), 0, h->stream, h->d_S, h->Mp,
                                h->d_Linv, Ms, h->d_Binv);
-            hipLaunchKernelGGL(k_transpose512, dim3((unsigned)((Ms + ASM_WB - 1) / ASM_WB), 64), dim3(256), 0, h->stream, h->d_Binv, h->d_BinvT);
+            hipLaunchKernelGGL(k_transpose512, dim3((unsigned)((Ms + ASM_WB - 1) / ASM_WB), ASM_WSUB * ASM_WSUB), dim3(256), 0, h->stream, h->d_Binv, h->d_BinvT);
         });
         end(id);
         h->stats.nfact += 1;

@@ -603,7 +603,9 @@ __global__ __launch_bounds__(256) void k_tile_nzflags(const double* __restrict__
 // (k_trtri512, from the 64 x 64 block inverses of k_potrf_diag), so a solve needs 2 launches per 512-wide block and
 // direction instead of one per 64-wide block: 148 launches instead of 582 at M = 18637.
 //   block inverse X = L_BB^-1 by block columns:  X_jj = Linv_j ;  X_ij = -Linv_i * sum_{k=j}^{i-1} L_ik X_kj   (i > j)
+#ifndef ASM_WB
 #define ASM_WB 512
+#endif
 #define ASM_WSUB (ASM_WB / ASM_NB)
 __global__ __launch_bounds__(256) void k_trtri512(const double* __restrict__ L, int64_t ld, const double* __restrict__ Linv, int Ms,
                                                   double* __restrict__ Binv) {
@@ -838,7 +840,7 @@ __global__ __launch_bounds__(256) void k_wtrsv_bwd_diag(const double* __restrict
 // XT_B = X_B'  (LDS-tiled transpose of every 512 x 512 block inverse)
 __global__ __launch_bounds__(256) void k_transpose512(const double* __restrict__ Binv, double* __restrict__ BinvT) {
     __shared__ double tile[64 * 65];
-    const int B = blockIdx.x, ti = blockIdx.y >> 3, tj = blockIdx.y & 7;
+    const int B = blockIdx.x, ti = blockIdx.y / ASM_WSUB, tj = blockIdx.y % ASM_WSUB;
     const double* X = Binv + (int64_t)B * ASM_WB * ASM_WB;
     double* XT = BinvT + (int64_t)B * ASM_WB * ASM_WB;
     for (int e = threadIdx.x; e < 64 * 64; e += 256) {
