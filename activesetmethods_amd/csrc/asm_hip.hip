@@ -106,6 +106,7 @@ struct asm_handle {
     double *d_c = nullptr, *d_rho = nullptr, *d_theta = nullptr, *d_diag = nullptr, *d_diag0 = nullptr;
     double *d_vecN = nullptr, *d_vecM = nullptr, *d_vecM2 = nullptr, *d_part = nullptr, *d_partial = nullptr;
     double *d_Linv = nullptr, *d_Binv = nullptr, *d_BinvT = nullptr, *d_wpart = nullptr, *d_wt = nullptr;
+    int wb = 512;                  // wide-block width of the triangular solves
     unsigned char* d_nz = nullptr;  // (row tile, k-chunk) non-zero flags of Ah; second half: flags of a gathered row set
     int64_t nz_half = 0;
     // sparse copy of the fixed Jacobian pattern for the matrix-vector products (sparse patterns only)
@@ -403,14 +404,26 @@ struct Dev {
         HIPCHK(hipGraphLaunch(it->second, h->stream));
     }
 
+    template <int WB>
+    void trtri_launches(int Ms) {
+        constexpr int WSUB = WB / ASM_NB;
+        const unsigned nW = (unsigned)((Ms + WB - 1) / WB);
+        hipLaunchKernelGGL((k_trtri_init<WB>), dim3(nW, WSUB * WSUB), dim3(256), 0, h->stream, h->d_Linv, Ms, h->d_Binv);
+        for (int hh = 1; hh < WSUB; hh *= 2)
+            for (int stage = 0; stage < 2; ++stage)
+                hipLaunchKernelGGL((k_trtri_level<WB>), dim3(nW, (unsigned)(WSUB / (2 * hh)), (unsigned)(hh * hh)), dim3(256), 0, h->stream,
+                                   h->d_S, h->Mp, Ms, h->d_Binv, h->d_BinvT, hh, stage);
+        hipLaunchKernelGGL((k_transpose_wb<WB>), dim3(nW, WSUB * WSUB), dim3(256), 0, h->stream, h->d_Binv, h->d_BinvT);
+    }
     void chol(int Ms, double thr = 1e-14) {
         if (Ms <= 0) return;
         int id = begin(ASM_K_CHOL, (double)Ms * Ms * Ms / 3.0, 8.0 * 1.5 * Ms * (double)Ms);
         run_sequence(thr == 1e-14 ? 1 : 2, Ms, Ms == (int)h->M, [&] {
             chol_launches(Ms, thr);
-            hipLaunchKernelGGL(k_trtri512, dim3((unsigned)((Ms + ASM_WB - 1) / ASM_WB), ASM_WSUB), dim3(256), 0, h->stream, h->d_S, h->Mp,
-                               h->d_Linv, Ms, h->d_Binv);
-            hipLaunchKernelGGL(k_transpose512, dim3((unsigned)((Ms + ASM_WB - 1) / ASM_WB), ASM_WSUB * ASM_WSUB), dim3(256), 0, h->stream, h->d_Binv, h->d_BinvT);
+            // explicit inverses of the wide diagonal blocks by divide and conquer over the 64-wide sub-blocks: diagonal
+            // blocks from k_potrf_diag, then log2 levels of two launches each (the scratch T uses the buffer of the
+            // transposed copy, which is written afterwards)
+            if (h->wb == 1024) trtri_launches<1024>(Ms); else trtri_launches<512>(Ms);
         });
         end(id);
         h->stats.nfact += 1;
@@ -486,31 +499,33 @@ struct Dev {
         d2h(out, h->d_vecM2, Ms);
     }
     void solve_launches(int Ms) {
+        if (h->wb == 1024) solve_launches_wb<1024>(Ms); else solve_launches_wb<512>(Ms);
+    }
+    template <int WB>
+    void solve_launches_wb(int Ms) {
         // forward: w = copy of rhs (d_vecM2, updated in place), z -> d_vecM ; backward: x -> d_vecM2 (w is dead by then)
         double* w = h->d_vecM2;
         double* z = h->d_vecM;
-        const int nB = (Ms + ASM_WB - 1) / ASM_WB;
+        const int nB = (Ms + WB - 1) / WB;
         for (int B = 0; B < nB; ++B) {
-            int b1 = std::min((B + 1) * ASM_WB, Ms);
-            hipLaunchKernelGGL(k_wtrsv_fwd_diag, dim3(ASM_WB / 4), dim3(256), 0, h->stream, h->d_Binv, B, Ms, w, z);
+            int b1 = std::min((B + 1) * WB, Ms);
+            hipLaunchKernelGGL((k_wtrsv_fwd_diag<WB>), dim3(WB / 4), dim3(256), 0, h->stream, h->d_Binv, B, Ms, w, z);
             int rem = Ms - b1;
             if (rem > 0)
-                hipLaunchKernelGGL(k_wtrsv_fwd_panel, dim3((unsigned)((rem + 31) / 32)), dim3(256), 0, h->stream, h->d_S, h->Mp, B, Ms, z, w);
+                hipLaunchKernelGGL((k_wtrsv_fwd_panel<WB>), dim3((unsigned)((rem + 31) / 32)), dim3(256), 0, h->stream, h->d_S, h->Mp, B, Ms, z, w);
         }
         for (int B = nB - 1; B >= 0; --B) {
-            int b1 = std::min((B + 1) * ASM_WB, Ms);
+            int b1 = std::min((B + 1) * WB, Ms);
             int rem = Ms - b1;
             int np = 0;
             if (rem > 0) {
                 np = (rem + ASM_WBROWS - 1) / ASM_WBROWS;
-                hipLaunchKernelGGL(k_wtrsv_bwd_panel, dim3((unsigned)np), dim3(256), 0, h->stream, h->d_S, h->Mp, B, Ms, w, h->d_wpart);
+                hipLaunchKernelGGL((k_wtrsv_bwd_panel<WB>), dim3((unsigned)np), dim3(256), 0, h->stream, h->d_S, h->Mp, B, Ms, w, h->d_wpart);
             }
-            hipLaunchKernelGGL(k_wtrsv_bwd_reduce, dim3(ASM_WSUB), dim3(256), 0, h->stream, B, Ms, z, h->d_wpart, np, h->d_wt);
-            hipLaunchKernelGGL(k_wtrsv_bwd_diag, dim3(ASM_WB / 4), dim3(256), 0, h->stream, h->d_BinvT, B, Ms, h->d_wt, w);
+            hipLaunchKernelGGL((k_wtrsv_bwd_reduce<WB>), dim3(WB / ASM_NB), dim3(256), 0, h->stream, B, Ms, z, h->d_wpart, np, h->d_wt);
+            hipLaunchKernelGGL((k_wtrsv_bwd_diag<WB>), dim3(WB / 4), dim3(256), 0, h->stream, h->d_BinvT, B, Ms, h->d_wt, w);
         }
     }
-
-    // COO values (device resident) -> dense J incl. the extra range rows (common.jl:12-20, subproblem.jl:438-457)
     void assemble() {
         h->spv_J_valid = false;
         int id = begin(ASM_K_ASSEMBLE, 0.0, 8.0 * h->nnz + 8.0 * h->nu + (h->dense_fast ? 0.0 : 24.0 * h->nu + 8.0 * h->nnz));
@@ -1243,10 +1258,11 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     dmalloc(&h->d_partial, (int64_t)ASM_TMAXCHUNKS * h->ldn);
     dmalloc(&h->d_idx, h->Mp);
     dmalloc(&h->d_Linv, (h->Mp / ASM_NB + 1) * ASM_NB * ASM_NB);
-    dmalloc(&h->d_Binv, (h->Mp / ASM_WB + 1) * (int64_t)ASM_WB * ASM_WB);
-    dmalloc(&h->d_BinvT, (h->Mp / ASM_WB + 1) * (int64_t)ASM_WB * ASM_WB);
-    dmalloc(&h->d_wpart, (h->Mp / ASM_WBROWS + 2) * (int64_t)ASM_WB);
-    dmalloc(&h->d_wt, ASM_WB);
+    h->wb = h->M > 1536 ? 1024 : 512;      // wide-block width of the triangular solves (k_wtrsv_*<WB>)
+    dmalloc(&h->d_Binv, (h->Mp / h->wb + 1) * (int64_t)h->wb * h->wb);
+    dmalloc(&h->d_BinvT, (h->Mp / h->wb + 1) * (int64_t)h->wb * h->wb);
+    dmalloc(&h->d_wpart, (h->Mp / ASM_WBROWS + 2) * (int64_t)h->wb);
+    dmalloc(&h->d_wt, h->wb);
     h->nz_half = (h->Mp / 32 + 1) * (h->ldn / ASM_KC + 1);
     dmalloc(&h->d_nz, 2 * h->nz_half);
     if (h->sp_nnz > 0) {

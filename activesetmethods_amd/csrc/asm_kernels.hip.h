@@ -13,7 +13,7 @@
 //   k_syrk<T>         MFMA  S = Ah[idx,:] diag(theta) Ah[idx,:]' (+diag)  and  S22 -= P P'   (v_mfma_f64_16x16x4_f64)
 //   k_potrf_diag      LDS   64x64 diagonal block Cholesky with static pivot guard
 //   k_trsm_panel      LDS   panel  P = S21 L11^-T
-//   k_trtri512, k_wtrsv_*  HBM   512-wide block inverses and the wide-block forward / backward substitution
+//   k_trtri_*, k_wtrsv_*<WB>  HBM   wide (512 / 1024) block inverses and the wide-block forward / backward substitution
 //   k_spmv_*          HBM   matrix-vector products on the CSR / CSC copy of sparse patterns
 #pragma once
 #include <hip/hip_runtime.h>
@@ -600,133 +600,113 @@ __global__ __launch_bounds__(256) void k_tile_nzflags(const double* __restrict__
 
 // ---------------------------------------------------------------------------------------------------
 // Wide-block triangular solves.  After the factorisation the 512 x 512 diagonal blocks of L are inverted explicitly
-// (k_trtri512, from the 64 x 64 block inverses of k_potrf_diag), so a solve needs 2 launches per 512-wide block and
-// direction instead of one per 64-wide block: 148 launches instead of 582 at M = 18637.
-//   block inverse X = L_BB^-1 by block columns:  X_jj = Linv_j ;  X_ij = -Linv_i * sum_{k=j}^{i-1} L_ik X_kj   (i > j)
-#ifndef ASM_WB
-#define ASM_WB 512
-#endif
-#define ASM_WSUB (ASM_WB / ASM_NB)
-__global__ __launch_bounds__(256) void k_trtri512(const double* __restrict__ L, int64_t ld, const double* __restrict__ Linv, int Ms,
-                                                  double* __restrict__ Binv) {
-    __shared__ double Ta[ASM_NB * ASM_DP];
-    __shared__ double Tb[ASM_NB * ASM_DP];
-    const int B = blockIdx.x, j = blockIdx.y;
-    const int tid = threadIdx.x;
-    const int b0 = B * ASM_WB;                                  // first row/col of the wide block
-    double* X = Binv + (int64_t)B * ASM_WB * ASM_WB;            // row-major 512 x 512
-    const int nsub = min(ASM_WSUB, (Ms - b0 + ASM_NB - 1) / ASM_NB);
-    // zero the blocks above the diagonal of this block column and pad missing sub-blocks with the identity
-    for (int i = 0; i < ASM_WSUB; ++i) {
-        if (i >= j && i < nsub && j < nsub) continue;
+// (k_trtri_init / k_trtri_level, from the 64 x 64 block inverses of k_potrf_diag), so a solve needs 2-3 launches per wide
+// block and direction instead of one per 64-wide block.
+// WB = width of a wide block (template parameter: 512 for small systems, 1024 otherwise - asm_hip.hip: pick_wb)
+// Block inversion by divide and conquer (dependent chain of 2*log2 launches).  The inverse of a lower-triangular 2h x 2h block [L11 0; L21 L22] is [X11 0; -X22 L21 X11  X22];
+// with X11, X22 (h x h) known, one level is two launches:
+//   stage 0:  T   = L21 X11      tile (i,j) = sum_{k>=j} L21[i][k] X11[k][j]      (X11 lower triangular)
+//   stage 1:  X21 = -X22 T       tile (i,j) = sum_{k<=i} X22[i][k] T[k][j]
+// h = 1, 2, 4, ... 64-blocks; T lives at the X21 position of the scratch buffer (BinvT, transposed copy written later).
+// 64x64x64 products on the matrix cores: wavefront w owns rows 16w..16w+15, four 16x16 tiles, 16 k-steps of
+// v_mfma_f64_16x16x4_f64; the right operand is staged transposed so that both fragment reads are conflict-free
+// (pitch = 2 mod 32 doubles).
+#define ASM_TP 66
+template <int WB>
+__global__ __launch_bounds__(256) void k_trtri_init(const double* __restrict__ Linv, int Ms, double* __restrict__ Binv) {
+    const int B = blockIdx.x, i = blockIdx.y / (WB / ASM_NB), j = blockIdx.y % (WB / ASM_NB);
+    const int b0 = B * WB;
+    const int nsub = min((WB / ASM_NB), (Ms - b0 + ASM_NB - 1) / ASM_NB);
+    double* X = Binv + (int64_t)B * WB * WB;
+    const double* src = (i == j && i < nsub) ? Linv + (int64_t)((b0 / ASM_NB) + i) * ASM_NB * ASM_NB : nullptr;
+    for (int e = threadIdx.x; e < ASM_NB * ASM_NB; e += 256) {
+        int rr = e >> 6, c = e & 63;
+        double v = src ? src[e] : ((i == j && rr == c) ? 1.0 : 0.0);      // missing sub-blocks: identity
+        X[(int64_t)(i * ASM_NB + rr) * WB + j * ASM_NB + c] = v;
+    }
+}
+template <int WB>
+__global__ __launch_bounds__(256) void k_trtri_level(const double* __restrict__ L, int64_t ld, int Ms, double* __restrict__ Binv,
+                                                     double* __restrict__ Tbuf, int h, int stage) {
+    __shared__ double Pa[ASM_NB * ASM_TP];      // left operand  P[r][k]
+    __shared__ double Qt[ASM_NB * ASM_TP];      // right operand transposed  Qt[c][k] = Q[k][c]
+    const int B = blockIdx.x, pr = blockIdx.y, ti = blockIdx.z / h, tj = blockIdx.z % h;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b0 = B * WB;
+    const int c0 = pr * 2 * h * ASM_NB, r0 = c0 + h * ASM_NB;          // inside the wide block: cols of "1", rows of "2"
+    double* X = Binv + (int64_t)B * WB * WB;
+    double* T = Tbuf + (int64_t)B * WB * WB;
+    v4f64 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    const int k_lo = stage == 0 ? tj : 0, k_hi = stage == 0 ? h - 1 : ti;
+    for (int k = k_lo; k <= k_hi; ++k) {
         for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
             int rr = e >> 6, c = e & 63;
-            X[(int64_t)(i * ASM_NB + rr) * ASM_WB + j * ASM_NB + c] = (i == j && rr == c) ? 1.0 : 0.0;
-        }
-    }
-    if (j >= nsub) return;
-    // X_jj = Linv_j
-    {
-        const double* src = Linv + (int64_t)((b0 / ASM_NB) + j) * ASM_NB * ASM_NB;
-        for (int e = tid; e < ASM_NB * ASM_NB; e += 256)
-            X[(int64_t)(j * ASM_NB + (e >> 6)) * ASM_WB + j * ASM_NB + (e & 63)] = src[e];
-    }
-    __threadfence_block();
-    __syncthreads();
-    // 64x64x64 products with a 4x4 register block per thread (8 LDS reads per 16 fma)
-    const int ty = tid >> 4, tx = tid & 15;
-    for (int i = j + 1; i < nsub; ++i) {
-        double acc[4][4];
-#pragma unroll
-        for (int a_ = 0; a_ < 4; ++a_)
-#pragma unroll
-            for (int b_ = 0; b_ < 4; ++b_) acc[a_][b_] = 0.0;
-        for (int k = j; k < i; ++k) {
-            // Ta = L_ik (rows b0+64i.., cols b0+64k..), Tb = X_kj
-            for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
-                int rr = e >> 6, c = e & 63;
-                int gi = b0 + i * ASM_NB + rr;
-                Ta[rr * ASM_DP + c] = gi < Ms ? L[(int64_t)gi * ld + b0 + k * ASM_NB + c] : 0.0;
-                Tb[rr * ASM_DP + c] = X[(int64_t)(k * ASM_NB + rr) * ASM_WB + j * ASM_NB + c];
+            double pv, qv;
+            if (stage == 0) {          // P = L21[ti][k] (rows of the factor), Q = X11[k][tj]
+                int gi = b0 + r0 + ti * ASM_NB + rr;
+                pv = gi < Ms ? L[(int64_t)gi * ld + b0 + c0 + k * ASM_NB + c] : 0.0;
+                qv = X[(int64_t)(c0 + k * ASM_NB + rr) * WB + c0 + tj * ASM_NB + c];
+            } else {                   // P = X22[ti][k], Q = T[k][tj]
+                pv = X[(int64_t)(r0 + ti * ASM_NB + rr) * WB + r0 + k * ASM_NB + c];
+                qv = T[(int64_t)(r0 + k * ASM_NB + rr) * WB + c0 + tj * ASM_NB + c];
             }
-            __syncthreads();
+            Pa[rr * ASM_TP + c] = pv;
+            Qt[c * ASM_TP + rr] = qv;
+        }
+        __syncthreads();
 #pragma unroll 4
-            for (int q = 0; q < ASM_NB; ++q) {
-                double av[4], bv[4];
+        for (int kk = 0; kk < ASM_NB; kk += 4) {
+            double af = Pa[(w * 16 + (lane & 15)) * ASM_TP + kk + (lane >> 4)];
 #pragma unroll
-                for (int a_ = 0; a_ < 4; ++a_) av[a_] = Ta[(ty * 4 + a_) * ASM_DP + q];
-#pragma unroll
-                for (int b_ = 0; b_ < 4; ++b_) bv[b_] = Tb[q * ASM_DP + tx * 4 + b_];
-#pragma unroll
-                for (int a_ = 0; a_ < 4; ++a_)
-#pragma unroll
-                    for (int b_ = 0; b_ < 4; ++b_) acc[a_][b_] = fma(av[a_], bv[b_], acc[a_][b_]);
+            for (int t = 0; t < 4; ++t) {
+                double bf = Qt[(t * 16 + (lane & 15)) * ASM_TP + kk + (lane >> 4)];
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc[t], 0, 0, 0);
             }
-            __syncthreads();
         }
-        // Tb = acc ; Ta = Linv_i ; X_ij = -Ta * Tb
-#pragma unroll
-        for (int a_ = 0; a_ < 4; ++a_)
-#pragma unroll
-            for (int b_ = 0; b_ < 4; ++b_) Tb[(ty * 4 + a_) * ASM_DP + tx * 4 + b_] = acc[a_][b_];
-        {
-            const double* src = Linv + (int64_t)((b0 / ASM_NB) + i) * ASM_NB * ASM_NB;
-            for (int e = tid; e < ASM_NB * ASM_NB; e += 256) Ta[(e >> 6) * ASM_DP + (e & 63)] = src[e];
-        }
-        __syncthreads();
-        double out[4][4];
-#pragma unroll
-        for (int a_ = 0; a_ < 4; ++a_)
-#pragma unroll
-            for (int b_ = 0; b_ < 4; ++b_) out[a_][b_] = 0.0;
-        for (int q = 0; q <= ty * 4 + 3; ++q) {          // Linv_i is lower triangular (entries above the diagonal are 0)
-            double av[4], bv[4];
-#pragma unroll
-            for (int a_ = 0; a_ < 4; ++a_) av[a_] = Ta[(ty * 4 + a_) * ASM_DP + q];
-#pragma unroll
-            for (int b_ = 0; b_ < 4; ++b_) bv[b_] = Tb[q * ASM_DP + tx * 4 + b_];
-#pragma unroll
-            for (int a_ = 0; a_ < 4; ++a_)
-#pragma unroll
-                for (int b_ = 0; b_ < 4; ++b_) out[a_][b_] = fma(av[a_], bv[b_], out[a_][b_]);
-        }
-#pragma unroll
-        for (int a_ = 0; a_ < 4; ++a_)
-#pragma unroll
-            for (int b_ = 0; b_ < 4; ++b_)
-                X[(int64_t)(i * ASM_NB + ty * 4 + a_) * ASM_WB + j * ASM_NB + tx * 4 + b_] = -out[a_][b_];
-        __threadfence_block();
         __syncthreads();
     }
+    double* out = stage == 0 ? T : X;
+    const double sgn = stage == 0 ? 1.0 : -1.0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int row = w * 16 + (lane >> 4) + 4 * r, col = t * 16 + (lane & 15);
+            out[(int64_t)(r0 + ti * ASM_NB + row) * WB + c0 + tj * ASM_NB + col] = sgn * acc[t][r];
+        }
 }
 
 // forward, wide block B:  z_B = X_B w_B   (one wavefront per row: 128 workgroups of 4 rows; all loads of a row in flight)
+template <int WB>
 __global__ __launch_bounds__(256) void k_wtrsv_fwd_diag(const double* __restrict__ Binv, int B, int Ms, const double* __restrict__ w,
                                                         double* __restrict__ z) {
-    const int b0 = B * ASM_WB;
-    const double* X = Binv + (int64_t)B * ASM_WB * ASM_WB;
+    const int b0 = B * WB;
+    const double* X = Binv + (int64_t)B * WB * WB;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wv;
     if (b0 + row >= Ms) return;
-    double v[ASM_WB / 64];
+    double v[WB / 64];
 #pragma unroll
-    for (int u = 0; u < ASM_WB / 64; ++u) {
+    for (int u = 0; u < WB / 64; ++u) {
         int c = u * 64 + lane;
-        v[u] = (c <= row) ? X[(int64_t)row * ASM_WB + c] * w[b0 + c] : 0.0;
+        v[u] = (c <= row) ? X[(int64_t)row * WB + c] * w[b0 + c] : 0.0;
     }
     double acc = 0.0;
 #pragma unroll
-    for (int u = 0; u < ASM_WB / 64; ++u) acc += v[u];
+    for (int u = 0; u < WB / 64; ++u) acc += v[u];
     acc = wave_sum(acc);
     if (lane == 0) z[b0 + row] = acc;
 }
 // forward panel update:  w[i] -= L[i, b0:b1] . z[b0:b1]   for i >= b1.  A wavefront owns 8 rows: their 64 loads are issued
 // together, the 8 sums are reduced, and lanes 0..7 apply the 8 read-modify-writes in parallel.
+template <int WB>
 __global__ __launch_bounds__(256) void k_wtrsv_fwd_panel(const double* __restrict__ L, int64_t ld, int B, int Ms, const double* __restrict__ z,
                                                          double* __restrict__ w) {
-    __shared__ double zs[ASM_WB];
-    const int b0 = B * ASM_WB, b1 = min(b0 + ASM_WB, Ms), wdt = b1 - b0;
-    for (int c = threadIdx.x; c < ASM_WB; c += 256) zs[c] = c < wdt ? z[b0 + c] : 0.0;
+    __shared__ double zs[WB];
+    const int b0 = B * WB, b1 = min(b0 + WB, Ms), wdt = b1 - b0;
+    for (int c = threadIdx.x; c < WB; c += 256) zs[c] = c < wdt ? z[b0 + c] : 0.0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int i0 = b1 + blockIdx.x * 32 + wv * 8;
@@ -740,7 +720,7 @@ __global__ __launch_bounds__(256) void k_wtrsv_fwd_panel(const double* __restric
         if (i < Ms) {
             const double* row = L + (int64_t)i * ld + b0;
 #pragma unroll
-            for (int u = 0; u < ASM_WB / 64; ++u) {
+            for (int u = 0; u < WB / 64; ++u) {
                 int c = u * 64 + lane;
                 a = fma(c < wdt ? row[c] : 0.0, zs[c], a);
             }
@@ -757,14 +737,15 @@ __global__ __launch_bounds__(256) void k_wtrsv_fwd_panel(const double* __restric
 }
 // backward partial sums for wide block B over chunks of 64 rows i >= b1:  part[g][c] = sum_i L[i, b0+c] x[i]
 #define ASM_WBROWS 64
+template <int WB>
 __global__ __launch_bounds__(256) void k_wtrsv_bwd_panel(const double* __restrict__ L, int64_t ld, int B, int Ms, const double* __restrict__ x,
                                                          double* __restrict__ part) {
-    __shared__ double red[4][ASM_WB];
-    const int b0 = B * ASM_WB, b1 = min(b0 + ASM_WB, Ms), wdt = b1 - b0;
+    __shared__ double red[4][WB];
+    const int b0 = B * WB, b1 = min(b0 + WB, Ms), wdt = b1 - b0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    double acc[ASM_WB / 64];
+    double acc[WB / 64];
 #pragma unroll
-    for (int u = 0; u < ASM_WB / 64; ++u) acc[u] = 0.0;
+    for (int u = 0; u < WB / 64; ++u) acc[u] = 0.0;
     const int base = b1 + blockIdx.x * ASM_WBROWS;
     for (int r0 = wv; r0 < ASM_WBROWS; r0 += 16) {            // 4 rows per batch and wavefront: 32 loads in flight
         double xi[4];
@@ -776,30 +757,31 @@ __global__ __launch_bounds__(256) void k_wtrsv_bwd_panel(const double* __restric
             xi[q] = ok ? x[i] : 0.0;
             rowp[q] = L + (int64_t)(ok ? i : b1) * ld + b0;
         }
-        double v[4][ASM_WB / 64];
+        double v[4][WB / 64];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int u = 0; u < ASM_WB / 64; ++u) {
+            for (int u = 0; u < WB / 64; ++u) {
                 int c = u * 64 + lane;
                 v[q][u] = c < wdt ? rowp[q][c] : 0.0;
             }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int u = 0; u < ASM_WB / 64; ++u) acc[u] = fma(v[q][u], xi[q], acc[u]);
+            for (int u = 0; u < WB / 64; ++u) acc[u] = fma(v[q][u], xi[q], acc[u]);
     }
 #pragma unroll
-    for (int u = 0; u < ASM_WB / 64; ++u) red[wv][u * 64 + lane] = acc[u];
+    for (int u = 0; u < WB / 64; ++u) red[wv][u * 64 + lane] = acc[u];
     __syncthreads();
-    for (int c = threadIdx.x; c < ASM_WB; c += 256)
-        part[(int64_t)blockIdx.x * ASM_WB + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    for (int c = threadIdx.x; c < WB; c += 256)
+        part[(int64_t)blockIdx.x * WB + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 // t = z_B - sum_g part[g]   (8 workgroups of 64 columns; partials split over the 4 wavefronts in a fixed order)
+template <int WB>
 __global__ __launch_bounds__(256) void k_wtrsv_bwd_reduce(int B, int Ms, const double* __restrict__ z, const double* __restrict__ part,
                                                           int n_part, double* __restrict__ t) {
     __shared__ double red[4][64];
-    const int b0 = B * ASM_WB, b1 = min(b0 + ASM_WB, Ms), wdt = b1 - b0;
+    const int b0 = B * WB, b1 = min(b0 + WB, Ms), wdt = b1 - b0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     double acc = 0.0;
@@ -808,7 +790,7 @@ __global__ __launch_bounds__(256) void k_wtrsv_bwd_reduce(int B, int Ms, const d
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             int g = g0 + 4 * q;
-            v[q] = g < n_part ? part[(int64_t)g * ASM_WB + c] : 0.0;
+            v[q] = g < n_part ? part[(int64_t)g * WB + c] : 0.0;
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc += v[q];
@@ -818,39 +800,41 @@ __global__ __launch_bounds__(256) void k_wtrsv_bwd_reduce(int B, int Ms, const d
     if (threadIdx.x < 64) t[c] = c < wdt ? z[b0 + c] - ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) : 0.0;
 }
 // x_B = X_B' t  through the transposed block inverse (row c of XT = column c of X): one wavefront per unknown
+template <int WB>
 __global__ __launch_bounds__(256) void k_wtrsv_bwd_diag(const double* __restrict__ BinvT, int B, int Ms, const double* __restrict__ t,
                                                         double* __restrict__ x) {
-    const int b0 = B * ASM_WB;
-    const double* XT = BinvT + (int64_t)B * ASM_WB * ASM_WB;
+    const int b0 = B * WB;
+    const double* XT = BinvT + (int64_t)B * WB * WB;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wv;
     if (b0 + row >= Ms) return;
-    double v[ASM_WB / 64];
+    double v[WB / 64];
 #pragma unroll
-    for (int u = 0; u < ASM_WB / 64; ++u) {
+    for (int u = 0; u < WB / 64; ++u) {
         int c = u * 64 + lane;
-        v[u] = (c >= row) ? XT[(int64_t)row * ASM_WB + c] * t[c] : 0.0;
+        v[u] = (c >= row) ? XT[(int64_t)row * WB + c] * t[c] : 0.0;
     }
     double acc = 0.0;
 #pragma unroll
-    for (int u = 0; u < ASM_WB / 64; ++u) acc += v[u];
+    for (int u = 0; u < WB / 64; ++u) acc += v[u];
     acc = wave_sum(acc);
     if (lane == 0) x[b0 + row] = acc;
 }
 // XT_B = X_B'  (LDS-tiled transpose of every 512 x 512 block inverse)
-__global__ __launch_bounds__(256) void k_transpose512(const double* __restrict__ Binv, double* __restrict__ BinvT) {
+template <int WB>
+__global__ __launch_bounds__(256) void k_transpose_wb(const double* __restrict__ Binv, double* __restrict__ BinvT) {
     __shared__ double tile[64 * 65];
-    const int B = blockIdx.x, ti = blockIdx.y / ASM_WSUB, tj = blockIdx.y % ASM_WSUB;
-    const double* X = Binv + (int64_t)B * ASM_WB * ASM_WB;
-    double* XT = BinvT + (int64_t)B * ASM_WB * ASM_WB;
+    const int B = blockIdx.x, ti = blockIdx.y / (WB / ASM_NB), tj = blockIdx.y % (WB / ASM_NB);
+    const double* X = Binv + (int64_t)B * WB * WB;
+    double* XT = BinvT + (int64_t)B * WB * WB;
     for (int e = threadIdx.x; e < 64 * 64; e += 256) {
         int r = e >> 6, c = e & 63;
-        tile[r * 65 + c] = X[(int64_t)(ti * 64 + r) * ASM_WB + tj * 64 + c];
+        tile[r * 65 + c] = X[(int64_t)(ti * 64 + r) * WB + tj * 64 + c];
     }
     __syncthreads();
     for (int e = threadIdx.x; e < 64 * 64; e += 256) {
         int r = e >> 6, c = e & 63;
-        XT[(int64_t)(tj * 64 + r) * ASM_WB + ti * 64 + c] = tile[c * 65 + r];
+        XT[(int64_t)(tj * 64 + r) * WB + ti * 64 + c] = tile[c * 65 + r];
     }
 }
 
