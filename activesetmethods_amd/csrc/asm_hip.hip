@@ -31,6 +31,9 @@ const int IPM_MAXIT = 60;
 const int IPM_MCC = 2;           // Gondzio centrality correctors per iteration (oracle/lp_solver.py)
 const double MCC_DELTA = 0.3, MCC_BMIN = 0.1, MCC_BMAX = 10.0, MCC_GAMMA = 0.1;
 const int CHOL_NBI = 256, CHOL_NBO = 1024;   // inner / outer panel widths of the three-level Cholesky
+// column (Sherman-Morrison-Woodbury) form of the Newton system for restoration LPs (oracle/lp_solver.py: COL_*)
+const int COL_MIN_M = 64, COL_MAX_CG = 6;
+const double COL_MAX_RATIO = 0.8, COL_FIXED = 1e200;
 const int PCG_MAXIT = 20;       // conjugate-gradient steps per Newton solve (preconditioner = the Cholesky factor)
 const double PCG_KAPPA = 1e-3;  // Newton-system residual tolerance relative to the current primal residual
 const double IPM_RHO_P = 1e-8;   // primal proximal regularisation of the Newton system
@@ -107,6 +110,12 @@ struct asm_handle {
     double *d_vecN = nullptr, *d_vecM = nullptr, *d_vecM2 = nullptr, *d_part = nullptr, *d_partial = nullptr;
     double *d_Linv = nullptr, *d_Binv = nullptr, *d_BinvT = nullptr, *d_wpart = nullptr, *d_wt = nullptr;
     int wb = 512;                  // wide-block width of the triangular solves
+    // column form: transposed copy of Ah (n x ldT), its chunk flags, work vectors
+    bool col_capable = false, ahT_valid = false, nzT_valid = false;
+    int64_t ldT = 0;
+    double nzT_fraction = 1.0;
+    double *d_AhT = nullptr, *d_cdinv = nullptr, *d_cth = nullptr, *d_cu = nullptr, *d_ct = nullptr, *d_cv = nullptr, *d_cw = nullptr;
+    unsigned char* d_nzT = nullptr;
     unsigned char* d_nz = nullptr;  // (row tile, k-chunk) non-zero flags of Ah; second half: flags of a gathered row set
     int64_t nz_half = 0;
     // sparse copy of the fixed Jacobian pattern for the matrix-vector products (sparse patterns only)
@@ -281,6 +290,34 @@ struct Dev {
                        8.0 * (Ms * (double)h->ldn + 0.5 * Ms * (double)Ms));
         launch_syrk(pick_tile(Ms), h->d_Ah, h->ldn, idx_dev, 0, Ms, (int)h->ldn, theta_dev, diag_dev, h->d_S, h->Mp, 0, 0, -1,
                     skip ? h->d_nz : nullptr, h->nz_pitch);
+        end(id);
+    }
+    // transposed copy of Ah and its chunk flags (column form of the restoration-phase Newton system), once per LP
+    void ensure_AhT() {
+        if (h->ahT_valid) return;
+        hipLaunchKernelGGL(k_transpose_dense, dim3((unsigned)((h->n + 63) / 64), (unsigned)((h->M + 63) / 64)), dim3(256), 0, h->stream, h->d_Ah,
+                           h->ldn, h->M, h->n, h->d_AhT, h->ldT);
+        h->nzT_valid = false;
+        const int nch = (int)(h->ldT / ASM_KC);
+        if (!h->dense_fast && nch <= ASM_MAXCHUNKS && h->nnz * 8 <= h->M * h->n) {
+            const int T = pick_tile(h->n), TS = 32 * T;
+            const int nt = (int)((h->n + TS - 1) / TS);
+            hipLaunchKernelGGL(k_tile_nzflags, dim3((unsigned)nt, (unsigned)((nch + 7) / 8)), dim3(256), 0, h->stream, h->d_AhT, h->ldT, h->n, TS, nch,
+                               h->d_nzT, nch, (const int*)nullptr);
+            h->nzT_fraction = executed_fraction(h->d_nzT, nt, nch);
+            h->nzT_valid = true;
+        }
+        h->ahT_valid = true;
+    }
+    // S[0:n,0:n] (lower) = AhT diag(dinv) AhT' + diag(th)
+    void syrk_col(const double* dinv_dev, const double* th_dev) {
+        ensure_AhT();
+        const int n = (int)h->n;
+        const int nch = (int)(h->ldT / ASM_KC);
+        const double frac = h->nzT_valid ? h->nzT_fraction : 1.0;
+        int id = begin(ASM_K_SYRK, frac * (double)n * (n + 1) * h->ldT, 8.0 * (n * (double)h->ldT + 0.5 * n * (double)n));
+        launch_syrk(pick_tile(n), h->d_AhT, h->ldT, nullptr, 0, n, (int)h->ldT, dinv_dev, th_dev, h->d_S, h->Mp, 0, 0, -1,
+                    h->nzT_valid ? h->d_nzT : nullptr, nch, frac);
         end(id);
     }
     // per (row tile, k-chunk) non-zero flags of Ah for the chunk-skipping Schur build (sparse Jacobians only)
@@ -558,6 +595,7 @@ struct Dev {
     // Ah = diag(1/rho) J diag(c);  rho (host, M)
     void scale(const double* c, double* rho) {
         h->spv_Ah_valid = false;
+        h->ahT_valid = false;
         if (h->M == 0) return;
         h2d(h->d_c, c, h->n, h->ldn);
         int id = begin(ASM_K_SCALE, 0.0, 8.0 * 3.0 * h->M * h->ldn);
@@ -607,6 +645,8 @@ struct Solver {
         int64_t ncomp = 1;
         vec pinf_hist;
         bool stalled = false;
+        bool col_ok = false, col_off = false;     // column form available / abandoned for this LP
+        int col_iters = 0;
         int iters = 0;
         int status = ASM_OTHER;
         double mu = 0, pinf = 0, dinf = 0, gap = 0, ymax = 0, rpmax = 0;
@@ -672,6 +712,7 @@ struct Solver {
         for (int64_t i = 0; i < M; ++i) nineq += lp.rtype[i] != 0;
         for (int64_t j = 0; j < n; ++j) nfree += lp.ub[j] > lp.lb[j];
         ip.ncomp = std::max<int64_t>(2 * nfree + lp.ns + nineq, 1);
+        ip.col_ok = h->col_capable && lp.ns > 0 && M >= COL_MIN_M && (double)n <= COL_MAX_RATIO * (double)M;   // every row owns a slack (setup)
         ipm_upload_lp();
         P.ncomp = ip.ncomp;
         hipLaunchKernelGGL(k_ipm_init_p, dim3(grid_all()), dim3(256), 0, h->stream, P);
@@ -723,15 +764,29 @@ struct Solver {
         return ynr - lhs;
     }
 
+    bool use_col = false;     // form of the current factorisation
+    int cg_max = 0;           // most CG steps any solve of the current iteration needed
+    bool cg_fail = false;     // a solve of the current iteration left its CG loop without reaching the tolerance
+    // out = (approximate) S^-1 in : the Cholesky factor of S (row form) or Sherman-Morrison-Woodbury through the factor of K
+    void precond(const double* in, double* out) {
+        const int M = (int)lp.M;
+        if (!use_col) { dev.chol_solve_dev(in, out, M); return; }
+        const unsigned gm = (unsigned)((lp.M + 255) / 256);
+        hipLaunchKernelGGL(k_col_scale, dim3(gm), dim3(256), 0, h->stream, h->d_cdinv, in, h->d_cu, lp.M);      // u = D^-1 r
+        dev.gemv_t_dev(h->d_Ah, h->d_cu, h->d_ct);                                                                 // Ah' u
+        dev.chol_solve_dev(h->d_ct, h->d_cv, (int)lp.n);                                                           // K^-1
+        dev.gemv_n_dev(h->d_Ah, h->d_cv, h->d_cw);                                                                 // Ah v
+        hipLaunchKernelGGL(k_col_finish, dim3(gm), dim3(256), 0, h->stream, h->d_cdinv, h->d_cu, h->d_cw, out, lp.M);
+    }
     // one Newton solve with the current factor (oracle: IPM.run.solve); mode 0 affine, 1 Mehrotra corrector built on
     // `base`, 2 Gondzio centrality corrector for `base` at the trial steps (tp, td)
     void ipm_solve(int mode, const IpmDir& base, IpmDir& D, double tp = 0.0, double td = 0.0) {
         const unsigned g = grid_all();
-        const int M = (int)lp.M;
+        
         hipLaunchKernelGGL(k_ipm_rhs1, dim3(g), dim3(256), 0, h->stream, P, base, mode, tp, td, MCC_BMIN, MCC_BMAX);
         dev.gemv_n_dev(h->d_Ah, P.tmpn, P.t1);
         hipLaunchKernelGGL(k_ipm_rhs2, dim3(g), dim3(256), 0, h->stream, P, mode == 2 ? 0.0 : 1.0);
-        dev.chol_solve_dev(P.rhs, D.dy, M);
+        precond(P.rhs, D.dy);
         {
             // preconditioned CG on the unregularised Schur system, the Cholesky factor as preconditioner (oracle: IPM.run.solve).
             // The residual of this system is exactly the primal residual the step leaves behind, hence the tolerance.
@@ -745,17 +800,21 @@ struct Solver {
             read_scal();
             const double tol = std::max(1e-10 * h->h_scal[SC_RMAX], PCG_KAPPA * ip.rpmax);
             if (h->h_scal[SC_EMAX] > tol) {
-                dev.chol_solve_dev(P.res, d_corr, M);
+                precond(P.res, d_corr);
                 hipLaunchKernelGGL(k_pcg_start, dim3(1), dim3(1024), 0, h->stream, P, d_corr, d_pcg);
+                bool converged = false;
                 for (int it = 0; it < PCG_MAXIT; ++it) {
                     applyS(d_pcg);
                     hipLaunchKernelGGL(k_pcg_step1, dim3(1), dim3(1024), 0, h->stream, P, d_sres, d_pcg, D.dy);
                     read_scal();
                     h->stats_pcg += 1;
-                    if (h->h_scal[SC_STOP] != 0.0 || h->h_scal[SC_EMAX] <= tol) break;
-                    dev.chol_solve_dev(P.res, d_corr, M);
+                    cg_max = std::max(cg_max, it + 1);
+                    if (h->h_scal[SC_STOP] != 0.0) break;
+                    if (h->h_scal[SC_EMAX] <= tol) { converged = true; break; }
+                    precond(P.res, d_corr);
                     hipLaunchKernelGGL(k_pcg_step2, dim3(1), dim3(1024), 0, h->stream, P, d_corr, d_pcg);
                 }
+                if (!converged) cg_fail = true;
             }
         }
         dev.gemv_t_dev(h->d_Ah, D.dy, d_tN);
@@ -782,11 +841,24 @@ struct Solver {
                 return ip.status = ASM_OTHER;
             }
             hipLaunchKernelGGL(k_ipm_theta, dim3(grid_all()), dim3(256), 0, h->stream, P, IPM_RHO_P);
-            dev.syrk_dev(nullptr, M, P.thp_inv, P.dS);
-            dev.diag_prepare(M, 0, 1e-13, 1e-30);
-            dev.chol(M);
+            // column form (oracle: IPM.run): K = Th + Ah' D^-1 Ah (n x n) while its Sherman-Morrison-Woodbury preconditioner
+            // keeps the CG short, the row form S = Ah Th^-1 Ah' + D (M x M) otherwise
+            use_col = ip.col_ok && !ip.col_off;
+            if (use_col) {
+                ip.col_iters += 1;
+                hipLaunchKernelGGL(k_ipm_col_prep, dim3(grid_all()), dim3(256), 0, h->stream, P, IPM_RHO_P, COL_FIXED, h->d_cdinv, h->d_cth);
+                dev.syrk_col(h->d_cdinv, h->d_cth);
+                dev.diag_prepare((int)lp.n, 0, 1e-13, 1e-30);
+                dev.chol((int)lp.n);
+            } else {
+                dev.syrk_dev(nullptr, M, P.thp_inv, P.dS);
+                dev.diag_prepare(M, 0, 1e-13, 1e-30);
+                dev.chol(M);
+            }
             ip.iters += 1;
             done += 1;
+            cg_max = 0;
+            cg_fail = false;
             ipm_solve(0, dirA, dirA);
             hipLaunchKernelGGL(k_ipm_steps, dim3(1), dim3(1024), 0, h->stream, P, dirA);
             hipLaunchKernelGGL(k_ipm_muaff, dim3(1), dim3(1024), 0, h->stream, P, dirA);
@@ -808,8 +880,13 @@ struct Solver {
                 ap = ap2; ad = ad2;
             }
             if (h->verbose) std::fprintf(stderr, "[asm]     ap %.3e ad %.3e  cg steps so far %lld\n", ap, ad, (long long)h->stats_pcg);
+            if (use_col && cg_fail) {      // column-form preconditioner lost its accuracy: redo this iteration in row form (oracle: IPM.run)
+                ip.col_off = true;
+                continue;
+            }
             const double eta = ip.mu >= 1.0 ? 0.995 : std::min(std::max(0.995, 1.0 - ip.mu / lp.scale_q), 0.999999);
             hipLaunchKernelGGL(k_ipm_update, dim3(grid_all()), dim3(256), 0, h->stream, P, dirC, std::min(1.0, eta * ap), std::min(1.0, eta * ad));
+            if (use_col && cg_max > COL_MAX_CG) ip.col_off = true;
         }
     }
 
@@ -1130,6 +1207,9 @@ void free_device(asm_handle* h) {
     F(h->d_vecN); F(h->d_vecM); F(h->d_vecM2); F(h->d_part); F(h->d_partial); F(h->d_idx); F(h->d_Linv); F(h->d_Binv); F(h->d_wpart); F(h->d_BinvT); F(h->d_wt);
     h->d_Binv = h->d_wpart = h->d_BinvT = h->d_wt = nullptr; F(h->d_ipm); F(h->d_ipm_i); F(h->d_nz);
     h->d_nz = nullptr; h->nz_valid = false;
+    F(h->d_AhT); F(h->d_cdinv); F(h->d_cth); F(h->d_cu); F(h->d_ct); F(h->d_cv); F(h->d_cw); F(h->d_nzT);
+    h->d_AhT = h->d_cdinv = h->d_cth = h->d_cu = h->d_ct = h->d_cv = h->d_cw = nullptr; h->d_nzT = nullptr;
+    h->col_capable = h->ahT_valid = h->nzT_valid = false;
     F(h->d_sp_ptr); F(h->d_sp_col); F(h->d_sc_ptr); F(h->d_sc_row); F(h->d_sc_pos); F(h->d_sp_off); F(h->d_spv_Ah); F(h->d_spv_J);
     h->d_sp_ptr = h->d_sp_col = h->d_sc_ptr = h->d_sc_row = h->d_sc_pos = nullptr;
     h->d_sp_off = nullptr; h->d_spv_Ah = h->d_spv_J = nullptr;
@@ -1259,6 +1339,22 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     dmalloc(&h->d_idx, h->Mp);
     dmalloc(&h->d_Linv, (h->Mp / ASM_NB + 1) * ASM_NB * ASM_NB);
     h->wb = h->M > 1536 ? 1024 : 512;      // wide-block width of the triangular solves (k_wtrsv_*<WB>)
+    // column form of the restoration-phase Newton system (every row owns a slack column there): n x n instead of M x M
+    h->col_capable = h->M >= COL_MIN_M && (double)n <= COL_MAX_RATIO * (double)h->M && n <= h->Mp;
+    if (h->col_capable) {
+        h->ldT = round_up(h->M, 32);
+        dmalloc(&h->d_AhT, n * h->ldT);
+        HIPCHK(hipMemsetAsync(h->d_AhT, 0, n * h->ldT * sizeof(double), h->stream));
+        dmalloc(&h->d_cdinv, h->ldT); dmalloc(&h->d_cth, h->ldn); dmalloc(&h->d_cu, h->Mp); dmalloc(&h->d_ct, h->ldn);
+        dmalloc(&h->d_cv, h->ldn); dmalloc(&h->d_cw, h->Mp);
+        HIPCHK(hipMemsetAsync(h->d_cdinv, 0, h->ldT * sizeof(double), h->stream));
+        HIPCHK(hipMemsetAsync(h->d_cth, 0, h->ldn * sizeof(double), h->stream));
+        HIPCHK(hipMemsetAsync(h->d_cu, 0, h->Mp * sizeof(double), h->stream));
+        HIPCHK(hipMemsetAsync(h->d_ct, 0, h->ldn * sizeof(double), h->stream));
+        HIPCHK(hipMemsetAsync(h->d_cv, 0, h->ldn * sizeof(double), h->stream));
+        HIPCHK(hipMemsetAsync(h->d_cw, 0, h->Mp * sizeof(double), h->stream));
+        dmalloc(&h->d_nzT, (n / 32 + 2) * (h->ldT / ASM_KC + 1));
+    }
     dmalloc(&h->d_Binv, (h->Mp / h->wb + 1) * (int64_t)h->wb * h->wb);
     dmalloc(&h->d_BinvT, (h->Mp / h->wb + 1) * (int64_t)h->wb * h->wb);
     dmalloc(&h->d_wpart, (h->Mp / ASM_WBROWS + 2) * (int64_t)h->wb);

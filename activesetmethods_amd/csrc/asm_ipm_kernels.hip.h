@@ -433,3 +433,25 @@ __global__ __launch_bounds__(256) void k_ipm_init_rest(IpmPtrs P) {
         P.y[t] = sg * pi;
     }
 }
+
+// ---- column form of the Newton system (restoration LPs): K = Th + Ah' D^-1 Ah, preconditioner by Sherman-Morrison-Woodbury
+// dinv = 1/dS (rows; the padding up to the k-chunk multiple stays 0), th = Theta + rho_p for free columns, `fixed` else
+__global__ __launch_bounds__(256) void k_ipm_col_prep(IpmPtrs P, double rho_p, double fixed, double* __restrict__ dinv, double* __restrict__ th) {
+    int64_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < P.M) dinv[t] = 1.0 / P.dS[t];
+    if (t < P.n) {
+        bool fr = P.ub[t] > P.lb[t];
+        th[t] = fr ? P.muL[t] / P.tL[t] + P.muU[t] / P.tU[t] + rho_p : fixed;
+    }
+}
+// u = dinv .* r
+__global__ __launch_bounds__(256) void k_col_scale(const double* __restrict__ dinv, const double* __restrict__ r, double* __restrict__ u, int64_t M) {
+    int64_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < M) u[t] = dinv[t] * r[t];
+}
+// out = u - dinv .* w
+__global__ __launch_bounds__(256) void k_col_finish(const double* __restrict__ dinv, const double* __restrict__ u, const double* __restrict__ w,
+                                                    double* __restrict__ out, int64_t M) {
+    int64_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < M) out[t] = u[t] - dinv[t] * w[t];
+}

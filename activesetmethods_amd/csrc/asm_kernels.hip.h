@@ -865,3 +865,20 @@ __global__ __launch_bounds__(256) void k_spmv_t(const int* __restrict__ cptr, co
         for (int k = cptr[j]; k < cptr[j + 1]; ++k) acc += vals[pos[k]] * y[row[k]];
     out[j] = acc;
 }
+
+// out[j][i] = A[i][j]   (64 x 64 LDS tiles; A is rows x ld_in, out is cols x ld_out) - transposed copy of the scaled LP
+// matrix for the column form of the Newton system
+__global__ __launch_bounds__(256) void k_transpose_dense(const double* __restrict__ A, int64_t ld_in, int64_t rows, int64_t cols,
+                                                         double* __restrict__ out, int64_t ld_out) {
+    __shared__ double tile[64 * 65];
+    const int64_t i0 = (int64_t)blockIdx.y * 64, j0 = (int64_t)blockIdx.x * 64;
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        int r = e >> 6, c = e & 63;
+        tile[r * 65 + c] = (i0 + r < rows && j0 + c < cols) ? A[(i0 + r) * ld_in + j0 + c] : 0.0;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        int r = e >> 6, c = e & 63;          // out row j0 + r, out col i0 + c
+        if (j0 + r < cols && i0 + c < rows) out[(j0 + r) * ld_out + i0 + c] = tile[c * 65 + r];
+    }
+}

@@ -17,7 +17,10 @@ Algorithm (all decisions deterministic, no randomisation):
      (active-set Schur complement  S = A_HF A_HF' , Cholesky/LDLt, two solves) and accept if it
      passes the LP optimality check (skipped for a few solves after repeated failures);
   2. otherwise a Mehrotra predictor-corrector interior-point method with Gondzio's multiple centrality
-     correctors in row (Schur) form S = A Th^-1 A' + D, to 1e-8, which identifies the optimal partition;
+     correctors in row (Schur) form S = A Th^-1 A' + D, to 1e-8, which identifies the optimal partition; every
+     Newton system is solved by conjugate gradients preconditioned with the Cholesky factor.  Restoration LPs
+     (every row owns a slack, D > 0) with n <= 0.8 M factor the n x n column form K = Th + A' D^-1 A instead and
+     apply it through Sherman-Morrison-Woodbury until its CG gets long, then return to the row form;
   3. active-set polish: the same Schur solve on the identified set gives the vertex and its
      multipliers to ~1e-13; a short correction loop (drop wrong-sign multipliers, add violated
      constraints) repairs near-degenerate mis-identifications.
@@ -34,6 +37,10 @@ TOL_P = 1e-9      # primal feasibility of the accepted vertex (scaled units)
 TOL_D = 1e-6      # dual feasibility of the accepted vertex (scaled units)
 IPM_TOL = 1e-8
 IPM_MAXIT = 60
+COL_MIN_M = 64        # column (Sherman-Morrison-Woodbury) form of the Newton system: smallest M, largest n/M, CG steps
+COL_MAX_RATIO = 0.8   # per solve beyond which the rest of the LP returns to the row form, pivot of fixed columns
+COL_MAX_CG = 6
+COL_FIXED = 1e200
 PCG_MAXIT = 20       # conjugate-gradient steps per Newton solve
 PCG_KAPPA = 1e-3     # Newton-system residual tolerance relative to the current primal residual
 IPM_MCC = 2          # Gondzio multiple centrality correctors per iteration (a solve costs ~1/50 of a factorisation)
@@ -196,6 +203,10 @@ class IPM:
         self.log = []
         self.pinf_hist = []
         self.stalled = False
+        # column form is available when every row has a slack column (restoration phase) and pays when n is well below M
+        self.col_ok = bool(ns > 0 and M >= COL_MIN_M and n <= COL_MAX_RATIO * M and np.all(np.bincount(lp.srow, minlength=M) > 0))
+        self.col_off = False
+        self.col_iters = 0
 
     def measures(self):
         lp, ineq, sg, free = self.lp, self.ineq, self.sg, self.free
@@ -244,14 +255,39 @@ class IPM:
             dS = np.where(ineq, g / np.where(ineq, pi, 1.0), 0.0)
             if ns:
                 np.add.at(dS, lp.srow, ths_inv)
-            S = dsyrk(1.0, A * np.sqrt(thp_inv), lower=True) if M else np.zeros((0, 0))   # lower triangle of A diag(thp_inv) A'
-            idx = np.arange(M)
-            S[idx, idx] += dS
-            diag0 = S[idx, idx].copy()
-            S[idx, idx] += 1e-13 * diag0 + 1e-30
-            L = chol_guard(S, diag0)
+            # Column form (restoration LPs, where every row carries a slack and hence D_ii > 0): by Sherman-Morrison-
+            # Woodbury  S^-1 = D^-1 - D^-1 A K^-1 A' D^-1  with  K = Th + A' D^-1 A  (n x n instead of M x M).  Used as the
+            # CG preconditioner while it is accurate; once active rows drive D_ii towards 0 the CG step count rises and the
+            # rest of the LP goes back to the row form.
+            use_col = self.col_ok and not self.col_off
+            if use_col:
+                self.col_iters += 1
+                dinv = 1.0 / dS
+                th = np.where(free, muL / tL + muU / tU + IPM_RHO_P, COL_FIXED)      # fixed columns: huge pivot, dp = 0
+                K = dsyrk(1.0, (A * np.sqrt(dinv)[:, None]).T, lower=True)          # lower triangle of A' D^-1 A
+                jdx = np.arange(lp.n)
+                K[jdx, jdx] += th
+                kd0 = K[jdx, jdx].copy()
+                K[jdx, jdx] += 1e-13 * kd0 + 1e-30
+                LK = chol_guard(K, kd0)
+
+                def precond(r):
+                    u = dinv * r
+                    return u - dinv * (A @ chol_solve(LK, A.T @ u))
+            else:
+                S = dsyrk(1.0, A * np.sqrt(thp_inv), lower=True) if M else np.zeros((0, 0))   # lower triangle of A diag(thp_inv) A'
+                idx = np.arange(M)
+                S[idx, idx] += dS
+                diag0 = S[idx, idx].copy()
+                S[idx, idx] += 1e-13 * diag0 + 1e-30
+                L = chol_guard(S, diag0)
+
+                def precond(r):
+                    return chol_solve(L, r)
             self.iters += 1
             done += 1
+            cg_max = [0]
+            cg_fail = [False]
 
             def solve(rcL, rcU, rcs, rcg, res=1.0):
                 hp = np.where(free, -res * rdp + rcL / tL - rcU / tU, 0.0)
@@ -261,16 +297,18 @@ class IPM:
                     tmp = np.zeros(M)
                     np.add.at(tmp, lp.srow, lp.scoef * ths_inv * hs)
                     rhs -= tmp
-                dy = chol_solve(L, rhs)
+                dy = precond(rhs)
                 # preconditioned CG on the unregularised S (preconditioner = the Cholesky factor).  The residual of this
                 # system is exactly the primal residual the step leaves behind, hence the tolerance.
                 res = rhs - (A @ (thp_inv * (A.T @ dy)) + dS * dy)
                 tol = max(1e-10 * max(1.0, np.abs(rhs).max(initial=0.0)), PCG_KAPPA * rpmax)
                 if np.abs(res).max(initial=0.0) > tol:
-                    z = chol_solve(L, res)
+                    z = precond(res)
                     pv = z.copy()
                     rz = rz0 = float(res @ z)
-                    for _ in range(PCG_MAXIT):
+                    converged = False
+                    for _cg in range(PCG_MAXIT):
+                        cg_max[0] = max(cg_max[0], _cg + 1)
                         Sp = A @ (thp_inv * (A.T @ pv)) + dS * pv
                         pSp = float(pv @ Sp)
                         if not (pSp > 0.0 and rz > 1e-30 * rz0 and rz < 1e12 * pSp):
@@ -279,12 +317,15 @@ class IPM:
                         dy = dy + alpha * pv
                         res = res - alpha * Sp
                         if np.abs(res).max(initial=0.0) <= tol:
+                            converged = True
                             break
-                        z = chol_solve(L, res)
+                        z = precond(res)
                         rzn = float(res @ z)
                         beta = rzn / rz
                         pv = z + beta * pv
                         rz = rzn
+                    if not converged:
+                        cg_fail[0] = True
                 dp = thp_inv * (hp + A.T @ dy)
                 ds = ths_inv * (hs + lp.scoef * dy[lp.srow])
                 dmuL = np.where(free, (rcL - muL * dp) / tL, 0.0)
@@ -331,6 +372,11 @@ class IPM:
                     break
                 dp, ds, dg, dy, dmuL, dmuU, dmus, dpi = cand
                 ap, ad = ap2, ad2
+            if use_col and cg_fail[0]:
+                # the column-form preconditioner has lost its accuracy (active rows drove D_ii to ~0): drop this
+                # iteration's directions and redo the iteration in row form
+                self.col_off = True
+                continue
             a, b = min(1.0, eta * ap), min(1.0, eta * ad)      # separate primal / dual step lengths
             self.p = self.p + a * dp
             self.s = self.s + a * ds
@@ -343,6 +389,8 @@ class IPM:
             self.mus = mus + b * dmus
             self.pi = pi + b * dpi
             self.y = np.where(ineq, sg * self.pi, self.y + b * dy)
+            if use_col and cg_max[0] > COL_MAX_CG:
+                self.col_off = True
 
 
 # ----------------------------------------------------------------------------- active-set machinery
