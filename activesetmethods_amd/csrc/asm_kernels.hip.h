@@ -472,39 +472,46 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int6
     for (int e = tid; e < ASM_NB * ASM_NB; e += 256) out[e] = W[(e >> 6) * ASM_DP + (e & 63)];
 }
 
-// Panel solve through the explicit inverse:  S[i, k0:k1] <- S[i, k0:k1] * Linv11'  for the 64 rows of this tile.
-// X[r][c] = sum_{q<=c} tile[r][q] * Linv[c][q] ; thread (r, g) produces 16 columns, no barrier inside the loops.
+// Panel solve through the explicit inverse:  S[i, k0:k1] <- S[i, k0:k1] * Linv11'  for the 64 rows of this tile, as one
+// 64x64x64 product on the matrix cores: wavefront w owns rows 16w..16w+15 (four 16x16 tiles, 16 k-steps of
+// v_mfma_f64_16x16x4_f64).  X Linv' = sum_q X[r][q] Linv[c][q], so the right operand is needed transposed - which is the
+// row-major Linv itself; both operands sit in LDS with pitch = 2 mod 32 doubles (conflict-free fragment reads).  Linv is
+// lower triangular with explicit zeros above the diagonal, so the full product is the triangular one.
+#define ASM_XP 66
 __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ S, int64_t ldS, int k0, int nb, int Ms,
                                                     const double* __restrict__ Linv) {
-    __shared__ double Li[ASM_NB * ASM_DP];
-    __shared__ double X[ASM_NB * ASM_DP];
-    const int tid = threadIdx.x, r = tid & 63, g = tid >> 6;
+    __shared__ double Xa[ASM_NB * ASM_XP];      // the tile  X[r][q]
+    __shared__ double Li[ASM_NB * ASM_XP];      // Linv[c][q]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i0 = k0 + nb + blockIdx.x * ASM_NB;
     const double* Lb = Linv + (int64_t)(k0 / ASM_NB) * ASM_NB * ASM_NB;
     for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
         int rr = e >> 6, c = e & 63;
-        Li[rr * ASM_DP + c] = Lb[e];
+        Li[rr * ASM_XP + c] = Lb[e];
         int gi = i0 + rr;
-        X[rr * ASM_DP + c] = (gi < Ms && c < nb) ? S[(int64_t)gi * ldS + k0 + c] : 0.0;
+        Xa[rr * ASM_XP + c] = (gi < Ms && c < nb) ? S[(int64_t)gi * ldS + k0 + c] : 0.0;
     }
     __syncthreads();
-    double out[16];
+    v4f64 acc[4];
 #pragma unroll
-    for (int cc = 0; cc < 16; ++cc) {
-        int c = g * 16 + cc;
-        double acc = 0.0;
-        for (int q = 0; q <= c; ++q) acc = fma(X[r * ASM_DP + q], Li[c * ASM_DP + q], acc);
-        out[cc] = acc;
-    }
-    __syncthreads();
+    for (int t = 0; t < 4; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int kk = 0; kk < ASM_NB; kk += 4) {
+        double af = Xa[(w * 16 + (lane & 15)) * ASM_XP + kk + (lane >> 4)];
 #pragma unroll
-    for (int cc = 0; cc < 16; ++cc) X[r * ASM_DP + g * 16 + cc] = out[cc];
-    __syncthreads();
-    for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
-        int rr = e >> 6, c = e & 63;
-        int gi = i0 + rr;
-        if (gi < Ms && c < nb) S[(int64_t)gi * ldS + k0 + c] = X[rr * ASM_DP + c];
+        for (int t = 0; t < 4; ++t) {
+            double bf = Li[(t * 16 + (lane & 15)) * ASM_XP + kk + (lane >> 4)];
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc[t], 0, 0, 0);
+        }
     }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int row = w * 16 + (lane >> 4) + 4 * r, col = t * 16 + (lane & 15);
+            int gi = i0 + row;
+            if (gi < Ms && col < nb) S[(int64_t)gi * ldS + k0 + col] = acc[t][r];
+        }
 }
 
 // out[i] = || A[i, :] ||_2   (one wavefront per row) - KT_residuals / compute_nu! (common.jl:41, slp.jl:58)
