@@ -477,8 +477,9 @@ struct Dev {
                 if (k1 < Ms) {
                     int rem = Ms - k1;
                     hipLaunchKernelGGL(k_trsm_panel, dim3((unsigned)((rem + 63) / 64)), dim3(256), 0, cur, h->d_S, h->Mp, k0, nb, Ms, h->d_Linv);
-                    if (k1 < I1)   // update the remaining columns of this inner panel only
-                        launch_syrk(pick_tile(rem), h->d_S + k0, h->Mp, nullptr, k1, rem, nb, nullptr, nullptr, h->d_S, h->Mp, k1, 1, I1 - k1);
+                    if (k1 < I1)   // update the remaining columns of this inner panel only (rank 64: dedicated 64 x 64-tile kernel)
+                        hipLaunchKernelGGL(k_panel_update64, dim3((unsigned)((rem + 63) / 64), (unsigned)((std::min(I1, Ms) - k1 + 63) / 64)), dim3(256), 0,
+                                           cur, h->d_S, h->Mp, k0, k1, std::min(I1, Ms), Ms);
                 }
             }
             if (I1 < K1 && I1 < Ms) {

@@ -514,6 +514,49 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ S, int6
         }
 }
 
+// In-panel rank-64 update of the Cholesky:  S[r, c] -= P[r, :] . P[c, :]  for rows r >= k1 and columns k1 <= c < c_end
+// (c <= r), P = S[:, k0:k0+64] the panel just solved.  One workgroup per 64 x 64 tile: both operand tiles are staged whole
+// (pitch = 2 mod 32 doubles), 16 k-steps of v_mfma_f64_16x16x4_f64 per wavefront, the accumulators start from the S tile
+// and the left operand is negated - the generic k_syrk pays its k-chunk pipeline and 128 x 128 tiles for K = 64.
+__global__ __launch_bounds__(256) void k_panel_update64(double* __restrict__ S, int64_t ldS, int k0, int k1, int c_end, int Ms) {
+    __shared__ double Pa[ASM_NB * ASM_XP];
+    __shared__ double Pb[ASM_NB * ASM_XP];
+    const int ti = blockIdx.x, tj = blockIdx.y;
+    if (tj > ti) return;                                   // strictly upper tile
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r0 = k1 + ti * ASM_NB, c0 = k1 + tj * ASM_NB;
+    for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
+        int rr = e >> 6, c = e & 63;
+        Pa[rr * ASM_XP + c] = (r0 + rr < Ms) ? -S[(int64_t)(r0 + rr) * ldS + k0 + c] : 0.0;
+        Pb[rr * ASM_XP + c] = (c0 + rr < Ms) ? S[(int64_t)(c0 + rr) * ldS + k0 + c] : 0.0;
+    }
+    v4f64 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int row = r0 + w * 16 + (lane >> 4) + 4 * r, col = c0 + t * 16 + (lane & 15);
+            acc[t][r] = (row < Ms && col < c_end && col <= row) ? S[(int64_t)row * ldS + col] : 0.0;
+        }
+    __syncthreads();
+#pragma unroll 4
+    for (int kk = 0; kk < ASM_NB; kk += 4) {
+        double af = Pa[(w * 16 + (lane & 15)) * ASM_XP + kk + (lane >> 4)];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            double bf = Pb[(t * 16 + (lane & 15)) * ASM_XP + kk + (lane >> 4)];
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int row = r0 + w * 16 + (lane >> 4) + 4 * r, col = c0 + t * 16 + (lane & 15);
+            if (row < Ms && col < c_end && col <= row) S[(int64_t)row * ldS + col] = acc[t][r];
+        }
+}
+
 // out[i] = || A[i, :] ||_2   (one wavefront per row) - KT_residuals / compute_nu! (common.jl:41, slp.jl:58)
 __global__ __launch_bounds__(256) void k_row_norms(const double* __restrict__ A, int64_t ld, double* __restrict__ out, int64_t M,
                                                    int64_t ncols) {

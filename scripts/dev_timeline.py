@@ -7,7 +7,7 @@ rows = c.execute("select name,start,end,stream_id,grid_x,workgroup_x from kernel
 short = lambda n: re.sub(r"\(.*", "", n).replace("void ", "")
 # a factorisation = from a k_diag_prepare (or first k_potrf_diag after a k_syrk with big grid) to the k_trtri512
 starts = [i for i, r in enumerate(rows) if short(r[0]).startswith("k_diag_prepare")]
-ends = [i for i, r in enumerate(rows) if short(r[0]).startswith("k_trtri512")]
+ends = [i for i, r in enumerate(rows) if short(r[0]).startswith("k_trtri_init") or short(r[0]).startswith("k_trtri512")]
 i0 = starts[which]; i1 = min(e for e in ends if e > i0)
 seg = rows[i0:i1 + 1]
 t0 = seg[0][1]; t1 = max(r[2] for r in seg)
