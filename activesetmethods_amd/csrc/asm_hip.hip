@@ -1406,6 +1406,7 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     HIPCHK(hipStreamSynchronize(h->stream));
     h->warm[0] = ActiveSet(); h->warm[1] = ActiveSet(); h->last = ActiveSet();
     h->hint[0] = SolveHint(); h->hint[1] = SolveHint();
+    h->hint[1].prefer_ref = true;     // restoration LPs usually have a non-unique optimum (oracle/subproblem.py)
     std::memset(&h->stats, 0, sizeof(h->stats));
     h->setup_done = true;
 }
@@ -1659,6 +1660,7 @@ int asm_sublp_reset_warm(asm_handle* h) {
     h->warm[1] = ActiveSet();
     h->hint[0] = SolveHint();
     h->hint[1] = SolveHint();
+    h->hint[1].prefer_ref = true;
     return ASM_OK;
 }
 

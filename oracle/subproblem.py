@@ -101,7 +101,9 @@ class QpModel:
         # entries currently stored in A[val,:]); create_model! starts them with slack terms only.
         self.A_adj = np.zeros((len(self.adj), n))
         self.warm = {False: None, True: None}     # last accepted active set per phase
-        self.hint = {False: {}, True: {}}         # adaptive solver decisions per phase (lp_solver.solve_scaled)
+        # adaptive solver decisions per phase (lp_solver.solve_scaled); restoration LPs (min sum of slacks) usually have a
+        # non-unique optimum, so that phase starts with the polish from the interior-point iterate preferred
+        self.hint = {False: {}, True: {'prefer_ref': True}}
 
     # ------------------------------------------------------------------ sub_optimize!
     def build_lp(self, x_k, Delta, feasibility):
