@@ -799,7 +799,8 @@ struct Solver {
             applyS(D.dy);
             hipLaunchKernelGGL(k_ipm_res, dim3(1), dim3(1024), 0, h->stream, P, d_sres, D.dy);
             read_scal();
-            const double tol = std::max(1e-10 * h->h_scal[SC_RMAX], PCG_KAPPA * ip.rpmax);
+            // the approximate preconditioner (column form) gets the tighter floor (oracle: IPM.run.solve)
+            const double tol = std::max((use_col ? 1e-13 : 1e-10) * h->h_scal[SC_RMAX], PCG_KAPPA * ip.rpmax);
             if (h->h_scal[SC_EMAX] > tol) {
                 precond(P.res, d_corr);
                 hipLaunchKernelGGL(k_pcg_start, dim3(1), dim3(1024), 0, h->stream, P, d_corr, d_pcg);

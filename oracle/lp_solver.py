@@ -41,6 +41,8 @@ COL_MIN_M = 64        # column (Sherman-Morrison-Woodbury) form of the Newton sy
 COL_MAX_RATIO = 0.8   # per solve beyond which the rest of the LP returns to the row form, pivot of fixed columns
 COL_MAX_CG = 6
 COL_FIXED = 1e200
+PCG_FLOOR = 1e-10    # residual floor of a Newton solve relative to |rhs|: exact factor / approximate preconditioner
+PCG_FLOOR_APPROX = 1e-13
 PCG_MAXIT = 20       # conjugate-gradient steps per Newton solve
 PCG_KAPPA = 1e-3     # Newton-system residual tolerance relative to the current primal residual
 IPM_MCC = 2          # Gondzio multiple centrality correctors per iteration (a solve costs ~1/50 of a factorisation)
@@ -301,7 +303,10 @@ class IPM:
                 # preconditioned CG on the unregularised S (preconditioner = the Cholesky factor).  The residual of this
                 # system is exactly the primal residual the step leaves behind, hence the tolerance.
                 res = rhs - (A @ (thp_inv * (A.T @ dy)) + dS * dy)
-                tol = max(1e-10 * max(1.0, np.abs(rhs).max(initial=0.0)), PCG_KAPPA * rpmax)
+                # the approximate preconditioner (column form) must earn its keep: tighter floor, so that a loss of accuracy
+                # shows up as CG steps (and ends the form) instead of as a growing primal residual
+                floor = PCG_FLOOR_APPROX if use_col else PCG_FLOOR
+                tol = max(floor * max(1.0, np.abs(rhs).max(initial=0.0)), PCG_KAPPA * rpmax)
                 if np.abs(res).max(initial=0.0) > tol:
                     z = precond(res)
                     pv = z.copy()
