@@ -397,18 +397,24 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int6
             for (int c = 0; c < 16; ++c) D[r * ASM_DP + c0 + c] = x[c];
         }
         __syncthreads();
-        {                                                // (3) rank-16 update of the remaining lower triangle
-            const int r = c0 + 16 + lane;
-            if (r < ASM_NB) {
-                double pr[16];
+        {                                                // (3) rank-16 update of the remaining lower triangle, 16x16 tiles on
+            const int rb = c0 + 16;                      //     the matrix cores: A22[ti][tj] -= X[ti] X[tj]'  (tj <= ti)
+            const int nt = (ASM_NB - rb) / 16;
+            for (int t = wv; t < nt * (nt + 1) / 2; t += 4) {
+                int ti = 0;
+                while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+                const int tj = t - ti * (ti + 1) / 2;
+                v4f64 acc;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) pr[q] = D[r * ASM_DP + c0 + q];
-                for (int c = c0 + 16 + wv; c <= r; c += 4) {
-                    double acc = D[r * ASM_DP + c];
+                for (int r = 0; r < 4; ++r) acc[r] = D[(rb + 16 * ti + (lane >> 4) + 4 * r) * ASM_DP + rb + 16 * tj + (lane & 15)];
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) acc = fma(-pr[q], D[c * ASM_DP + c0 + q], acc);
-                    D[r * ASM_DP + c] = acc;
+                for (int kk = 0; kk < 16; kk += 4) {
+                    double af = -D[(rb + 16 * ti + (lane & 15)) * ASM_DP + c0 + kk + (lane >> 4)];
+                    double bf = D[(rb + 16 * tj + (lane & 15)) * ASM_DP + c0 + kk + (lane >> 4)];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
                 }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) D[(rb + 16 * ti + (lane >> 4) + 4 * r) * ASM_DP + rb + 16 * tj + (lane & 15)] = acc[r];
             }
         }
         __syncthreads();
@@ -435,36 +441,33 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int6
         }
     }
     __syncthreads();
-    for (int dlev = 1; dlev < 4; ++dlev) {               // off-diagonal blocks (i, j = i - dlev), one wavefront per block
-        const int i = wv + dlev, j = wv;
+    for (int dlev = 1; dlev < 4; ++dlev) {               // off-diagonal blocks (i, j = i - dlev), one wavefront per block,
+        const int i = wv + dlev, j = wv;                 // 16x16x16 products on the matrix cores
         if (i < 4) {
-            // T = sum_{k=j}^{i-1} L_ik W_kj : entry (rr, cc), 4 entries per lane
-            double tv[4];
+            // T = sum_{k=j}^{i-1} L_ik W_kj
+            v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+            for (int k = j; k < i; ++k)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int e = u * 64 + lane, rr = e >> 4, cc = e & 15;
-                double acc = 0.0;
-                for (int k = j; k < i; ++k)
+                for (int kk = 0; kk < 16; kk += 4) {
+                    double af = D[(i * 16 + (lane & 15)) * ASM_DP + k * 16 + kk + (lane >> 4)];
+                    double bf = W[(k * 16 + kk + (lane >> 4)) * ASM_DP + j * 16 + (lane & 15)];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
+                }
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) acc = fma(D[(i * 16 + rr) * ASM_DP + k * 16 + q], W[(k * 16 + q) * ASM_DP + j * 16 + cc], acc);
-                tv[u] = acc;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int e = u * 64 + lane;
-                T[wv][(e >> 4) * 17 + (e & 15)] = tv[u];
-            }
+            for (int r = 0; r < 4; ++r) T[wv][((lane >> 4) + 4 * r) * 17 + (lane & 15)] = acc[r];
         }
         __syncthreads();
         if (i < 4) {
+            // W_ij = -W_ii T
+            v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int e = u * 64 + lane, rr = e >> 4, cc = e & 15;
-                double acc = 0.0;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc = fma(W[(i * 16 + rr) * ASM_DP + i * 16 + q], T[wv][q * 17 + cc], acc);
-                W[(i * 16 + rr) * ASM_DP + j * 16 + cc] = -acc;
+            for (int kk = 0; kk < 16; kk += 4) {
+                double af = -W[(i * 16 + (lane & 15)) * ASM_DP + i * 16 + kk + (lane >> 4)];
+                double bf = T[wv][(kk + (lane >> 4)) * 17 + (lane & 15)];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) W[(i * 16 + (lane >> 4) + 4 * r) * ASM_DP + j * 16 + (lane & 15)] = acc[r];
         }
         __syncthreads();
     }
