@@ -367,8 +367,8 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int6
             for (int j = 0; j < 16; ++j) {
                 double d = readlane_f64(a[j], j);
                 if (!(d > thr * d0[c0 + j])) d = 1e256;
-                double ljj = sqrt(d);
-                double inv = 1.0 / ljj;
+                double inv = rsqrt(d);                   // one transcendental on the dependent chain instead of sqrt + division
+                double ljj = d * inv;
                 double l = a[j] * inv;
                 if (t == j) { l = ljj; my_inv = inv; }
                 a[j] = l;
