@@ -1137,6 +1137,7 @@ struct Solver {
             int st = ipm_run(tols[stage], more[stage]);
             t_ipm += now_ms() - t0;
             h->stats.ipm_iters = ip.iters;
+            h->stats.col_iters = ip.col_iters;
             h->stats.ipm_pinf = ip.pinf; h->stats.ipm_dinf = ip.dinf; h->stats.ipm_gap = ip.gap;
             if (st == ASM_INFEASIBLE) { h->stats.path = 6; return ASM_INFEASIBLE; }
             if (st == ASM_OTHER && stage == 0) {

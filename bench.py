@@ -150,8 +150,10 @@ def run_steps(pr, algorithm, device, n_steps, state):
                 slp.optimizer = state["opt"]
         slp = state["slp"]
         before = slp.lp_solves
+        ntrace = len(slp.trace)
         target = before + (n_steps - done)
         slp.run(max_lp_solves=target, resume=state["resume"])
+        state.setdefault("trace_all", []).extend(slp.trace[ntrace:])
         state["resume"] = True
         state["opt"] = slp.optimizer
         done += slp.lp_solves - before
@@ -188,11 +190,11 @@ def highs_baseline(lp):
         return dict(error=repr(e))
 
 
-def cpu_baseline(pr, algorithm, budget_s, fact_per_step):
+def cpu_baseline(pr, algorithm, budget_s, mix):
     """Oracle (NumPy restatement of the same path) on a bounded sample of the same workload.
-    Small NLPs: whole SLP iterations from x0.  Large NLPs (one LP would take minutes on the host): the first
-    sub-LP's interior-point iterations (Schur build + Cholesky + solves, the same work the GPU does per
-    factorisation) are timed one by one and scaled by the factorisations per SLP step measured on the GPU run."""
+    Small NLPs: whole SLP iterations from x0.  Large NLPs (one LP would take minutes on the host): single
+    interior-point iterations of the oracle are timed in both forms of the Newton system and priced with the mix of
+    iterations (`mix`: row-form, column-form, active-set solves) the timed GPU steps actually took."""
     import numpy as np
     from oracle import slp as O
     from oracle import lp_solver as L
@@ -218,28 +220,45 @@ def cpu_baseline(pr, algorithm, budget_s, fact_per_step):
         return dict(value=steps / t_total, unit="iter/s", cores=cores, kind="port",
                     sample="oracle SLP (%s) from x0, first %d SLP iterations of the same NLP, %.1f s" % (algorithm, steps, t_total),
                     highs=highs_baseline(qp.build_lp(x, 1000.0 if algorithm == "Line Search" else 0.4, False)))
+    # large NLPs: one oracle LP takes many minutes.  Time single interior-point iterations of the oracle in the two forms the
+    # solver uses - the M x M row form on the first (normal-phase) sub-LP, the n x n column form on the restoration LP at
+    # the same point - and price the GPU run's own mix of iterations with them (active-set solves by their cubic size ratio).
     x = pr.x0.copy()
     t0 = time.perf_counter()
     dE = pr.eval_jac_g(x, np.zeros(pr.nnz))
     A, st = compute_jacobian_matrix(pr.m, pr.n, pr.j_row - 1, pr.j_col - 1, dE)
     qp = QpModel(QpData(pr.eval_grad_f(x, np.zeros(pr.n)), pr.eval_f(x), A, pr.eval_g(x, np.zeros(pr.m)), pr.g_L, pr.g_U, pr.x_L, pr.x_U, st),
                  pr.j_row, pr.j_col)
-    lp = qp.build_lp(x, 1000.0 if algorithm == "Line Search" else 0.4, False)
+    delta = 1000.0 if algorithm == "Line Search" else 0.4
+    lp = qp.build_lp(x, delta, False)
     slp, _, _, _ = L.scale_lp(lp)
     t_setup = time.perf_counter() - t0
-    ip = L.IPM(slp)
-    its, t_ipm = 0, 0.0
-    while t_ipm < budget_s and its < 8:
-        t1 = time.perf_counter()
-        ip.run(0.0, 1)
-        t_ipm += time.perf_counter() - t1
-        its += 1
-    per_fact = t_ipm / its
-    step_s = t_setup + per_fact * fact_per_step
+
+    def time_iterations(scaled_lp, budget, cap):
+        ip = L.IPM(scaled_lp)
+        its, t_ipm = 0, 0.0
+        while t_ipm < budget and its < cap:
+            t1 = time.perf_counter()
+            ip.run(0.0, 1)
+            t_ipm += time.perf_counter() - t1
+            its += 1
+        return t_ipm / its, its, ip
+
+    t_row, n_row, _ = time_iterations(slp, 0.6 * budget_s, 4)
+    t_col, n_col = t_row, 0
+    if mix["col_iters"] > 0:
+        slp_fr, _, _, _ = L.scale_lp(qp.build_lp(x, delta, True))
+        t_col, n_col, ipc = time_iterations(slp_fr, 0.4 * budget_s, 3)
+        if not ipc.col_ok:
+            t_col = t_row
+    eqp_cost = t_row * 0.2                      # an active-set factorisation has ~0.58 M rows: 0.58^3
+    step_s = t_setup + (mix["row_iters"] * t_row + mix["col_iters"] * t_col + mix["eqp"] * eqp_cost) / max(mix["steps"], 1)
     return dict(value=1.0 / step_s, unit="iter/s", cores=cores, kind="port",
-                sample="oracle: assembly+formulation+scaling of the first sub-LP (%.1f s) and %d interior-point iterations of it "
-                       "(%.1f s each: Schur build + Cholesky + solves), scaled by the %.1f factorisations per SLP step measured on the GPU run"
-                       % (t_setup, its, per_fact, fact_per_step),
+                sample="oracle: assembly+formulation+scaling of the first sub-LP (%.1f s), %d row-form interior-point iterations of it (%.1f s each) and "
+                       "%d column-form iterations of the restoration LP at the same point (%.1f s each), priced with the GPU run's own mix per SLP "
+                       "step: %.1f row-form + %.1f column-form iterations + %.1f active-set solves (0.2 row-form iterations each)"
+                       % (t_setup, n_row, t_row, n_col, t_col, mix["row_iters"] / max(mix["steps"], 1), mix["col_iters"] / max(mix["steps"], 1),
+                          mix["eqp"] / max(mix["steps"], 1)),
                 highs=highs_baseline(lp))
 
 
@@ -342,7 +361,13 @@ def main():
             "kernels_ms": {k: round(v["ms"], 3) for k, v in ks.items()},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(pr, args.algorithm, args.cpu_seconds, nfact / max(args.steps, 1))
+            timed = trace[-args.steps:] if trace else []
+            mix = dict(steps=args.steps, col_iters=sum(r["stats"].get("col_iters", 0) for r in timed),
+                       row_iters=sum(r["stats"]["ipm_iters"] - r["stats"].get("col_iters", 0) for r in timed),
+                       eqp=sum(r["stats"]["eqp"] for r in timed))
+            if not timed:
+                mix = dict(steps=args.steps, col_iters=0, row_iters=nfact, eqp=0)
+            out["cpu_baseline"] = cpu_baseline(pr, args.algorithm, args.cpu_seconds, mix)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

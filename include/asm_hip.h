@@ -88,6 +88,7 @@ typedef struct {
     int32_t nfact;         /* Cholesky factorisations */
     int32_t eqp;           /* active-set (EQP) solves */
     int32_t M, n, ns;      /* LP rows, columns, slack columns */
+    int32_t col_iters;     /* interior-point iterations that factored the n x n column form (restoration LPs) */
     double  ipm_pinf, ipm_dinf, ipm_gap;
     double  kkt_pr, kkt_du;
     double  wall_ms;       /* host wall time of the solve */

@@ -608,6 +608,7 @@ def solve_scaled(lp, warm=None, stats=None, hint=None):
         st = ip.run(tol, more)
         stats['nfact'] += ip.iters - stats['ipm_iters']
         stats['ipm_iters'] = ip.iters
+        stats['col_iters'] = ip.col_iters
         if st == INFEASIBLE:
             stats['path'] = 'ipm-infeasible'
             return INFEASIBLE, None, None, None, None
