@@ -69,7 +69,8 @@ struct ActiveSet {
 
 // adaptive decisions carried from one LP of a phase to the next (oracle/lp_solver.py: solve_scaled `hint`)
 struct SolveHint {
-    int warm_fail = 0, warm_skip = 0;
+    int warm_fail = 0, warm_skip = 1;     // the first re-solve of a phase is not attempted
+    bool stable = false;                  // the last two LPs of the phase ended on the same active sets
     bool prefer_ref = false;
 };
 
@@ -1115,15 +1116,17 @@ struct Solver {
         h->stats.path = -1;
         h->stats.polished = 1;
         if (warm && warm->valid && (int64_t)warm->rowst.size() == M && (int64_t)warm->bst.size() == n && (int64_t)warm->sst.size() == ns) {
-            if (hint.warm_skip > 0) {
+            // attempt when the last two LPs ended on the same sets or the back-off has run out (oracle: solve_scaled)
+            if (!hint.stable && hint.warm_skip > 0) {
                 hint.warm_skip -= 1;
             } else {
                 double t0 = now_ms();
                 bool okw = eqp_loop(*warm, zero_p, zero_y, 1, o, out_as);
                 t_warm += now_ms() - t0;
-                if (okw) { hint.warm_fail = 0; h->stats.path = 0; return ASM_OPTIMAL; }
+                if (okw) { hint.warm_fail = 0; hint.warm_skip = 0; h->stats.path = 0; return ASM_OPTIMAL; }
                 hint.warm_fail = std::min(hint.warm_fail + 1, 3);
-                hint.warm_skip = hint.warm_fail;
+                hint.warm_skip = (1 << hint.warm_fail) - 1;
+                hint.stable = false;
             }
         }
         const bool prefer_ref = hint.prefer_ref;
@@ -1499,6 +1502,10 @@ void do_solve(asm_handle* h, double delta, int feasibility, double* p_out, doubl
     for (int64_t j = 0; j < n; ++j) { p_out[j] = 0.0; mult_x_U[j] = 0.0; mult_x_L[j] = 0.0; }
     for (int64_t i = 0; i < m; ++i) { lambda[i] = 0.0; p_slack[2 * i] = 0.0; p_slack[2 * i + 1] = h->nslack[i] == 2 ? 0.0 : std::nan(""); }
     if (st == ASM_OPTIMAL) {
+        {
+            const ActiveSet& prev = h->warm[fr ? 1 : 0];
+            h->hint[fr ? 1 : 0].stable = prev.valid && Solver::same(prev, as);
+        }
         h->warm[fr ? 1 : 0] = as;
         h->last = as;
         // unscale (oracle: solve_lp) - bound-active components are exactly on their bound

@@ -579,7 +579,8 @@ def phase1_infeasible(lp, stats):
 
 def solve_scaled(lp, warm=None, stats=None, hint=None):
     """`hint` (dict, updated in place) carries two adaptive decisions from one LP of a phase to the next:
-      warm_fail / warm_skip : after k consecutive failed warm attempts the next min(k,3) solves skip the attempt;
+      warm_fail / warm_skip / stable : the warm attempt is made when the last two LPs ended on the same active sets or
+                              when the back-off (1, 3, 7 solves after 1, 2, 3+ consecutive failures; 1 initially) has run out;
       prefer_ref            : the last LP was only polishable from the interior-point iterate (non-unique
                               optimum, typical of the restoration LPs) -> run the IPM straight to the last stage and
                               try that polish first."""
@@ -591,16 +592,21 @@ def solve_scaled(lp, warm=None, stats=None, hint=None):
     zero_p = np.clip(np.zeros(lp.n), lp.lb, lp.ub)
     zero_y = np.zeros(lp.M)
     if warm is not None and len(warm[0]) == lp.M and len(warm[1]) == lp.n and len(warm[2]) == lp.ns:
-        if hint.get('warm_skip', 0) > 0:
-            hint['warm_skip'] -= 1
+        # attempt when the last two LPs of this phase ended on the same sets ('stable', set by the caller) or when the
+        # back-off has run out; the first re-solve of a phase is not attempted (warm_skip starts at 1): early in an SLP
+        # run the sets move at every iteration and an attempt costs two active-set factorisations
+        if not hint.get('stable', False) and hint.get('warm_skip', 1) > 0:
+            hint['warm_skip'] = hint.get('warm_skip', 1) - 1
         else:
             ok, p, s, y, sets = eqp_loop(lp, warm, zero_p, zero_y, 1, stats)
             if ok:
                 hint['warm_fail'] = 0
+                hint['warm_skip'] = 0
                 stats['path'] = 'warm'
                 return OPTIMAL, p, s, y, sets
             hint['warm_fail'] = min(hint.get('warm_fail', 0) + 1, 3)
-            hint['warm_skip'] = hint['warm_fail']
+            hint['warm_skip'] = 2 ** hint['warm_fail'] - 1          # 1, 3, 7 solves
+            hint['stable'] = False
     prefer_ref = bool(hint.get('prefer_ref', False))
     ip = IPM(lp)
     sets0 = None

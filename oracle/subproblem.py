@@ -155,6 +155,8 @@ class QpModel:
         Xsol = np.zeros(n); lam = np.zeros(m); mult_x_U = np.zeros(n); mult_x_L = np.zeros(n)
         p_slack = {}
         if status == L.OPTIMAL:
+            prev = self.warm[bool(feasibility)]
+            self.hint[bool(feasibility)]['stable'] = bool(prev is not None and all(np.array_equal(a, b) for a, b in zip(prev, out['sets'])))
             self.warm[bool(feasibility)] = out['sets']
             rowst, bst, sst = out['sets']
             Xsol[:] = out['p']                                                      # :502
