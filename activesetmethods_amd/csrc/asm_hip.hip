@@ -77,6 +77,7 @@ struct SolveHint {
 struct TimedRegion {
     hipEvent_t a, b;
     int kind;
+    hipStream_t stream;     // the stream the timed launches go to (the look-ahead stream has its own regions)
 };
 
 }  // namespace
@@ -177,7 +178,7 @@ struct Dev {
         HIPCHK(hipEventCreate(&e));
         return e;
     }
-    int begin(int kind, double flops, double bytes) {
+    int begin(int kind, double flops, double bytes, hipStream_t on = nullptr) {
         h->kstats.flops[kind] += flops;
         h->kstats.bytes[kind] += bytes;
         h->kstats.calls[kind] += 1;
@@ -186,17 +187,19 @@ struct Dev {
         r.a = get_event();
         r.b = get_event();
         r.kind = kind;
-        HIPCHK(hipEventRecord(r.a, h->stream));
+        r.stream = on ? on : h->stream;
+        HIPCHK(hipEventRecord(r.a, r.stream));
         h->regions.push_back(r);
         return (int)h->regions.size() - 1;
     }
     void end(int id) {
         if (id < 0) return;
-        HIPCHK(hipEventRecord(h->regions[id].b, h->stream));
+        HIPCHK(hipEventRecord(h->regions[id].b, h->regions[id].stream));
     }
     void resolve_timing() {
         if (h->regions.empty()) return;
         HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream2));
         for (auto& r : h->regions) {
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
@@ -379,7 +382,8 @@ struct Dev {
         // per-launch timing of the MFMA kernel itself (algorithmic flops: Ms*MsB*K over the stored triangle/rectangle)
         double fl = (MsB == Ms && ntj == 0) ? (double)Ms * (Ms + 1) * K : 2.0 * ((double)Ms * MsB - 0.5 * (double)MsB * MsB) * K;
         if (nz) fl *= nzfrac >= 0.0 ? nzfrac : h->nz_fraction;
-        int kid = (h->use_graphs || cur != h->stream) ? -1 : begin(ASM_K_SYRK_KERNEL, fl, 8.0 * ((double)(Ms + MsB) * K + (double)Ms * MsB));
+        // timed on the stream it is launched on (HIP events see only their own stream)
+        int kid = h->use_graphs ? -1 : begin(ASM_K_SYRK_KERNEL, fl, 8.0 * ((double)(Ms + MsB) * K + (double)Ms * MsB), cur);
         struct EndGuard { Dev* d; int id; ~EndGuard() { d->end(id); } } guard_{this, kid};
         if (T == 4 && mode == 1 && !nz && K % 16 == 0)      // Cholesky updates: 16-wide k-chunks, two workgroups per CU
             hipLaunchKernelGGL((k_syrk<4, 8, 16, 4>), dim3((unsigned)blocks), dim3(512), 0, cur, A, ld, idx, row0, Ms, K, theta, diag, S,
