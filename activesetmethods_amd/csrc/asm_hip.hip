@@ -109,7 +109,7 @@ struct asm_handle {
     // ---- device buffers ----
     double *d_dE = nullptr, *d_J = nullptr, *d_Ah = nullptr, *d_S = nullptr;
     double *d_c = nullptr, *d_rho = nullptr, *d_theta = nullptr, *d_diag = nullptr, *d_diag0 = nullptr;
-    double *d_vecN = nullptr, *d_vecM = nullptr, *d_vecM2 = nullptr, *d_part = nullptr, *d_partial = nullptr;
+    double *d_vecN = nullptr, *d_vecM = nullptr, *d_vecM2 = nullptr, *d_partial = nullptr;
     double *d_Linv = nullptr, *d_Binv = nullptr, *d_BinvT = nullptr, *d_wpart = nullptr, *d_wt = nullptr;
     int wb = 512;                  // wide-block width of the triangular solves
     // column form: transposed copy of Ah (n x ldT), its chunk flags, work vectors
@@ -1214,7 +1214,7 @@ void free_device(asm_handle* h) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(h->d_perm); F(h->d_ustart); F(h->d_uoff); F(h->d_adjoff);
     F(h->d_dE); F(h->d_J); F(h->d_Ah); F(h->d_S); F(h->d_c); F(h->d_rho); F(h->d_theta); F(h->d_diag); F(h->d_diag0);
-    F(h->d_vecN); F(h->d_vecM); F(h->d_vecM2); F(h->d_part); F(h->d_partial); F(h->d_idx); F(h->d_Linv); F(h->d_Binv); F(h->d_wpart); F(h->d_BinvT); F(h->d_wt);
+    F(h->d_vecN); F(h->d_vecM); F(h->d_vecM2); F(h->d_partial); F(h->d_idx); F(h->d_Linv); F(h->d_Binv); F(h->d_wpart); F(h->d_BinvT); F(h->d_wt);
     h->d_Binv = h->d_wpart = h->d_BinvT = h->d_wt = nullptr; F(h->d_ipm); F(h->d_ipm_i); F(h->d_nz);
     h->d_nz = nullptr; h->nz_valid = false;
     F(h->d_AhT); F(h->d_cdinv); F(h->d_cth); F(h->d_cu); F(h->d_ct); F(h->d_cv); F(h->d_cw); F(h->d_nzT);
@@ -1229,7 +1229,7 @@ void free_device(asm_handle* h) {
     if (h->h_pin) (void)hipHostFree(h->h_pin);
     h->d_perm = h->d_ustart = h->d_uoff = h->d_adjoff = nullptr;
     h->d_dE = h->d_J = h->d_Ah = h->d_S = h->d_c = h->d_rho = h->d_theta = h->d_diag = h->d_diag0 = nullptr;
-    h->d_vecN = h->d_vecM = h->d_vecM2 = h->d_part = h->d_partial = nullptr;
+    h->d_vecN = h->d_vecM = h->d_vecM2 = h->d_partial = nullptr;
     h->d_Linv = nullptr;
     h->d_idx = nullptr;
     h->h_pin = nullptr;
@@ -1344,7 +1344,7 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     dmalloc(&h->d_S, h->Mp * h->Mp);
     dmalloc(&h->d_c, h->ldn); dmalloc(&h->d_rho, h->Mp); dmalloc(&h->d_theta, h->ldn);
     dmalloc(&h->d_diag, h->Mp); dmalloc(&h->d_diag0, h->Mp);
-    dmalloc(&h->d_vecN, h->ldn); dmalloc(&h->d_vecM, h->Mp); dmalloc(&h->d_vecM2, h->Mp); dmalloc(&h->d_part, ASM_NB);
+    dmalloc(&h->d_vecN, h->ldn); dmalloc(&h->d_vecM, h->Mp); dmalloc(&h->d_vecM2, h->Mp);
     dmalloc(&h->d_partial, (int64_t)ASM_TMAXCHUNKS * h->ldn);
     dmalloc(&h->d_idx, h->Mp);
     dmalloc(&h->d_Linv, (h->Mp / ASM_NB + 1) * ASM_NB * ASM_NB);

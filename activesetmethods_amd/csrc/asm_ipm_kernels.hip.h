@@ -21,7 +21,7 @@ struct IpmPtrs {
 struct IpmDir {
     double *dp, *ds, *dg, *dy, *dmuL, *dmuU, *dmus, *dpi;
 };
-enum { SC_PINF = 0, SC_DINF, SC_MU, SC_YMAX, SC_AP, SC_AD, SC_SM, SC_ALPHA, SC_EMAX, SC_RMAX, SC_RZ, SC_RPMAX, SC_RZ0, SC_STOP, SC_COUNT };
+enum { SC_PINF = 0, SC_DINF, SC_MU, SC_YMAX, SC_AP, SC_AD, SC_SM, SC_EMAX, SC_RMAX, SC_RZ, SC_RPMAX, SC_RZ0, SC_STOP, SC_COUNT };
 
 __device__ __forceinline__ double blk_reduce_max(double v, double* sh) {
     v = wave_max(v);
@@ -207,10 +207,6 @@ __global__ __launch_bounds__(256) void k_ipm_rhs2(IpmPtrs P, double res) {
 __global__ __launch_bounds__(256) void k_vec_mul(double* __restrict__ x, const double* __restrict__ a, int64_t len) {
     int64_t t = blockIdx.x * 256 + threadIdx.x;
     if (t < len) x[t] *= a[t];
-}
-__global__ __launch_bounds__(256) void k_vec_add(double* __restrict__ x, const double* __restrict__ a, int64_t len) {
-    int64_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t < len) x[t] += a[t];
 }
 
 // res = rhs - (sres + dS dy) ; scal[EMAX] = max|res| ; scal[RMAX] = max(1, max|rhs|)
