@@ -34,6 +34,9 @@ const int CHOL_NBI = 256, CHOL_NBO = 1024;   // inner / outer panel widths of th
 // column (Sherman-Morrison-Woodbury) form of the Newton system for restoration LPs (oracle/lp_solver.py: COL_*)
 const int COL_MIN_M = 64, COL_MAX_CG = 6;
 const double COL_MAX_RATIO = 0.8, COL_FIXED = 1e200;
+// reduced row form of the normal-phase Newton system, large sparse problems only (oracle/lp_solver.py: RED_*)
+const int RED_MIN_M = 4096, RED_MAX_CG = 10;
+const double RED_TAU = 100.0, RED_MIN_FRAC = 0.1;
 const int PCG_MAXIT = 20;       // conjugate-gradient steps per Newton solve (preconditioner = the Cholesky factor)
 const double PCG_KAPPA = 1e-3;  // Newton-system residual tolerance relative to the current primal residual
 const double IPM_RHO_P = 1e-8;   // primal proximal regularisation of the Newton system
@@ -118,6 +121,9 @@ struct asm_handle {
     double nzT_fraction = 1.0;
     double *d_AhT = nullptr, *d_cdinv = nullptr, *d_cth = nullptr, *d_cu = nullptr, *d_ct = nullptr, *d_cv = nullptr, *d_cw = nullptr;
     unsigned char* d_nzT = nullptr;
+    // reduced row form: dropped-row index list, its diagonal, gathered work vectors, s_ii
+    int* d_idxI = nullptr;
+    double *d_rdI = nullptr, *d_rce = nullptr, *d_rze = nullptr, *d_sdiag = nullptr;
     unsigned char* d_nz = nullptr;  // (row tile, k-chunk) non-zero flags of Ah; second half: flags of a gathered row set
     int64_t nz_half = 0;
     // sparse copy of the fixed Jacobian pattern for the matrix-vector products (sparse patterns only)
@@ -295,6 +301,29 @@ struct Dev {
         launch_syrk(pick_tile(Ms), h->d_Ah, h->ldn, idx_dev, 0, Ms, (int)h->ldn, theta_dev, diag_dev, h->d_S, h->Mp, 0, 0, -1,
                     skip ? h->d_nz : nullptr, h->nz_pitch);
         end(id);
+    }
+    // S[0:Ms,0:Ms] (lower) = Ah[idx,:] diag(theta) Ah[idx,:]' + diag   with idx / theta / diag already on the device and the
+    // chunk flags of the gathered row set (reduced row form of the interior-point system)
+    void syrk_gathered_dev(const int* idx_dev, int Ms, const double* theta_dev, const double* diag_dev) {
+        const int nch = (int)(h->ldn / ASM_KC);
+        const int T = pick_tile(Ms), TS = 32 * T;
+        const int nt = (Ms + TS - 1) / TS;
+        const bool skip = h->nz_valid && nt > 0;
+        unsigned char* nz2 = h->d_nz + h->nz_half;
+        double frac = 1.0;
+        if (skip) {
+            hipLaunchKernelGGL(k_tile_nzflags, dim3((unsigned)nt, (unsigned)((nch + 7) / 8)), dim3(256), 0, h->stream, h->d_Ah, h->ldn, (int64_t)Ms, TS, nch,
+                               nz2, nch, idx_dev);
+            frac = executed_fraction(nz2, nt, nch);
+        }
+        int id = begin(ASM_K_SYRK, frac * (double)Ms * (Ms + 1) * h->ldn, 8.0 * (Ms * (double)h->ldn + 0.5 * Ms * (double)Ms));
+        launch_syrk(T, h->d_Ah, h->ldn, idx_dev, 0, Ms, (int)h->ldn, theta_dev, diag_dev, h->d_S, h->Mp, 0, 0, -1, skip ? nz2 : nullptr, nch, frac);
+        end(id);
+    }
+    // out[i] = sum_j Ah_ij^2 thinv_j   (sparse patterns only)
+    void schur_diag(const double* thinv_dev, double* out_dev) {
+        const double* v = sparse_vals(h->d_Ah);
+        hipLaunchKernelGGL(k_ipm_sdiag_csr, dim3((unsigned)((h->M + 255) / 256)), dim3(256), 0, h->stream, h->d_sp_ptr, h->d_sp_col, v, thinv_dev, out_dev, h->M);
     }
     // transposed copy of Ah and its chunk flags (column form of the restoration-phase Newton system), once per LP
     void ensure_AhT() {
@@ -653,6 +682,8 @@ struct Solver {
         bool stalled = false;
         bool col_ok = false, col_off = false;     // column form available / abandoned for this LP
         int col_iters = 0;
+        bool red_ok = false, red_off = false;     // reduced row form (normal phase, large sparse problems)
+        int red_iters = 0;
         int iters = 0;
         int status = ASM_OTHER;
         double mu = 0, pinf = 0, dinf = 0, gap = 0, ymax = 0, rpmax = 0;
@@ -718,6 +749,7 @@ struct Solver {
         for (int64_t i = 0; i < M; ++i) nineq += lp.rtype[i] != 0;
         for (int64_t j = 0; j < n; ++j) nfree += lp.ub[j] > lp.lb[j];
         ip.ncomp = std::max<int64_t>(2 * nfree + lp.ns + nineq, 1);
+        ip.red_ok = lp.ns == 0 && M >= RED_MIN_M && h->sp_ok;
         ip.col_ok = h->col_capable && lp.ns > 0 && M >= COL_MIN_M && (double)n <= COL_MAX_RATIO * (double)M;   // every row owns a slack (setup)
         ipm_upload_lp();
         P.ncomp = ip.ncomp;
@@ -770,14 +802,24 @@ struct Solver {
         return ynr - lhs;
     }
 
+    bool use_red = false;     // reduced row form: factor of the rows redE, diagonal on the rows redI
+    std::vector<int> redE, redI;
+    int nE = 0, nI = 0;
+    vec tmpM2;
     bool use_col = false;     // form of the current factorisation
     int cg_max = 0;           // most CG steps any solve of the current iteration needed
     bool cg_fail = false;     // a solve of the current iteration left its CG loop without reaching the tolerance
     // out = (approximate) S^-1 in : the Cholesky factor of S (row form) or Sherman-Morrison-Woodbury through the factor of K
     void precond(const double* in, double* out) {
         const int M = (int)lp.M;
-        if (!use_col) { dev.chol_solve_dev(in, out, M); return; }
         const unsigned gm = (unsigned)((lp.M + 255) / 256);
+        if (use_red) {
+            hipLaunchKernelGGL(k_red_gather, dim3((unsigned)((nE + 255) / 256)), dim3(256), 0, h->stream, h->d_idx, nE, in, h->d_rce);
+            dev.chol_solve_dev(h->d_rce, h->d_rze, nE);
+            hipLaunchKernelGGL(k_red_scatter, dim3(gm), dim3(256), 0, h->stream, h->d_idx, nE, h->d_rze, h->d_idxI, nI, h->d_rdI, in, out);
+            return;
+        }
+        if (!use_col) { dev.chol_solve_dev(in, out, M); return; }
         hipLaunchKernelGGL(k_col_scale, dim3(gm), dim3(256), 0, h->stream, h->d_cdinv, in, h->d_cu, lp.M);      // u = D^-1 r
         dev.gemv_t_dev(h->d_Ah, h->d_cu, h->d_ct);                                                                 // Ah' u
         dev.chol_solve_dev(h->d_ct, h->d_cv, (int)lp.n);                                                           // K^-1
@@ -805,7 +847,7 @@ struct Solver {
             hipLaunchKernelGGL(k_ipm_res, dim3(1), dim3(1024), 0, h->stream, P, d_sres, D.dy);
             read_scal();
             // the approximate preconditioner (column form) gets the tighter floor (oracle: IPM.run.solve)
-            const double tol = std::max((use_col ? 1e-13 : 1e-10) * h->h_scal[SC_RMAX], PCG_KAPPA * ip.rpmax);
+            const double tol = std::max(((use_col || use_red) ? 1e-13 : 1e-10) * h->h_scal[SC_RMAX], PCG_KAPPA * ip.rpmax);
             if (h->h_scal[SC_EMAX] > tol) {
                 precond(P.res, d_corr);
                 hipLaunchKernelGGL(k_pcg_start, dim3(1), dim3(1024), 0, h->stream, P, d_corr, d_pcg);
@@ -850,6 +892,7 @@ struct Solver {
             hipLaunchKernelGGL(k_ipm_theta, dim3(grid_all()), dim3(256), 0, h->stream, P, IPM_RHO_P);
             // column form (oracle: IPM.run): K = Th + Ah' D^-1 Ah (n x n) while its Sherman-Morrison-Woodbury preconditioner
             // keeps the CG short, the row form S = Ah Th^-1 Ah' + D (M x M) otherwise
+            use_red = false;
             use_col = ip.col_ok && !ip.col_off;
             if (use_col) {
                 ip.col_iters += 1;
@@ -858,9 +901,39 @@ struct Solver {
                 dev.diag_prepare((int)lp.n, 0, 1e-13, 1e-30);
                 dev.chol((int)lp.n);
             } else {
-                dev.syrk_dev(nullptr, M, P.thp_inv, P.dS);
-                dev.diag_prepare(M, 0, 1e-13, 1e-30);
-                dev.chol(M);
+                // reduced row form (oracle: IPM.run): inequality rows whose slack term dominates their Schur diagonal stay out
+                // of the factor and get a diagonal preconditioner
+                if (ip.red_ok && !ip.red_off) {
+                    dev.schur_diag(P.thp_inv, h->d_sdiag);
+                    down(tmpM, P.dS, lp.M);
+                    down(tmpM2, h->d_sdiag, lp.M);
+                    HIPCHK(hipStreamSynchronize(h->stream));
+                    redE.clear(); redI.clear();
+                    for (int64_t i = 0; i < lp.M; ++i) {
+                        if (lp.rtype[i] != 0 && tmpM[i] > RED_TAU * tmpM2[i]) redI.push_back((int)i);
+                        else redE.push_back((int)i);
+                    }
+                    use_red = (double)redI.size() >= RED_MIN_FRAC * (double)lp.M && !redE.empty();
+                }
+                if (use_red) {
+                    ip.red_iters += 1;
+                    nE = (int)redE.size(); nI = (int)redI.size();
+                    vec dE_(nE), dI_(nI);
+                    for (int a = 0; a < nE; ++a) dE_[a] = tmpM[redE[a]];
+                    for (int b = 0; b < nI; ++b) dI_[b] = tmpM2[redI[b]] + tmpM[redI[b]];
+                    HIPCHK(hipMemcpyAsync(h->d_idx, redE.data(), nE * sizeof(int), hipMemcpyHostToDevice, h->stream));
+                    HIPCHK(hipMemcpyAsync(h->d_idxI, redI.data(), nI * sizeof(int), hipMemcpyHostToDevice, h->stream));
+                    HIPCHK(hipMemcpyAsync(h->d_diag, dE_.data(), nE * sizeof(double), hipMemcpyHostToDevice, h->stream));
+                    HIPCHK(hipMemcpyAsync(h->d_rdI, dI_.data(), nI * sizeof(double), hipMemcpyHostToDevice, h->stream));
+                    HIPCHK(hipStreamSynchronize(h->stream));      // the host vectors go out of scope
+                    dev.syrk_gathered_dev(h->d_idx, nE, P.thp_inv, h->d_diag);
+                    dev.diag_prepare(nE, 0, 1e-13, 1e-30);
+                    dev.chol(nE);
+                } else {
+                    dev.syrk_dev(nullptr, M, P.thp_inv, P.dS);
+                    dev.diag_prepare(M, 0, 1e-13, 1e-30);
+                    dev.chol(M);
+                }
             }
             ip.iters += 1;
             done += 1;
@@ -891,9 +964,14 @@ struct Solver {
                 ip.col_off = true;
                 continue;
             }
+            if (use_red && cg_fail) {      // same safety net for the reduced row form
+                ip.red_off = true;
+                continue;
+            }
             const double eta = ip.mu >= 1.0 ? 0.995 : std::min(std::max(0.995, 1.0 - ip.mu / lp.scale_q), 0.999999);
             hipLaunchKernelGGL(k_ipm_update, dim3(grid_all()), dim3(256), 0, h->stream, P, dirC, std::min(1.0, eta * ap), std::min(1.0, eta * ad));
             if (use_col && cg_max > COL_MAX_CG) ip.col_off = true;
+            if (use_red && cg_max > RED_MAX_CG) ip.red_off = true;
         }
     }
 
@@ -1217,6 +1295,8 @@ void free_device(asm_handle* h) {
     F(h->d_vecN); F(h->d_vecM); F(h->d_vecM2); F(h->d_partial); F(h->d_idx); F(h->d_Linv); F(h->d_Binv); F(h->d_wpart); F(h->d_BinvT); F(h->d_wt);
     h->d_Binv = h->d_wpart = h->d_BinvT = h->d_wt = nullptr; F(h->d_ipm); F(h->d_ipm_i); F(h->d_nz);
     h->d_nz = nullptr; h->nz_valid = false;
+    F(h->d_idxI); F(h->d_rdI); F(h->d_rce); F(h->d_rze); F(h->d_sdiag);
+    h->d_idxI = nullptr; h->d_rdI = h->d_rce = h->d_rze = h->d_sdiag = nullptr;
     F(h->d_AhT); F(h->d_cdinv); F(h->d_cth); F(h->d_cu); F(h->d_ct); F(h->d_cv); F(h->d_cw); F(h->d_nzT);
     h->d_AhT = h->d_cdinv = h->d_cth = h->d_cu = h->d_ct = h->d_cv = h->d_cw = nullptr; h->d_nzT = nullptr;
     h->col_capable = h->ahT_valid = h->nzT_valid = false;
@@ -1349,6 +1429,9 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     dmalloc(&h->d_idx, h->Mp);
     dmalloc(&h->d_Linv, (h->Mp / ASM_NB + 1) * ASM_NB * ASM_NB);
     h->wb = h->M > 1536 ? 1024 : 512;      // wide-block width of the triangular solves (k_wtrsv_*<WB>)
+    if (h->M >= RED_MIN_M) {
+        dmalloc(&h->d_idxI, h->Mp); dmalloc(&h->d_rdI, h->Mp); dmalloc(&h->d_rce, h->Mp); dmalloc(&h->d_rze, h->Mp); dmalloc(&h->d_sdiag, h->Mp);
+    }
     // column form of the restoration-phase Newton system (every row owns a slack column there): n x n instead of M x M
     h->col_capable = h->M >= COL_MIN_M && (double)n <= COL_MAX_RATIO * (double)h->M && n <= h->Mp;
     if (h->col_capable) {

@@ -451,3 +451,29 @@ __global__ __launch_bounds__(256) void k_col_finish(const double* __restrict__ d
     int64_t t = blockIdx.x * 256 + threadIdx.x;
     if (t < M) out[t] = u[t] - dinv[t] * w[t];
 }
+
+// ---- reduced row form (normal phase of large sparse problems): s_ii = sum_j Ah_ij^2 / Th_j over the CSR copy of the pattern,
+// gather / scatter between the full row space and the factored subset E, diagonal preconditioner on the dropped rows I
+__global__ __launch_bounds__(256) void k_ipm_sdiag_csr(const int* __restrict__ ptr, const int* __restrict__ col, const double* __restrict__ vals,
+                                                       const double* __restrict__ thinv, double* __restrict__ out, int64_t M) {
+    int64_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    double acc = 0.0;
+    for (int k = ptr[i]; k < ptr[i + 1]; ++k) {
+        double a = vals[k];
+        acc = fma(a * a, thinv[col[k]], acc);
+    }
+    out[i] = acc;
+}
+// ce[a] = r[E[a]]
+__global__ __launch_bounds__(256) void k_red_gather(const int* __restrict__ E, int nE, const double* __restrict__ r, double* __restrict__ ce) {
+    int a = blockIdx.x * 256 + threadIdx.x;
+    if (a < nE) ce[a] = r[E[a]];
+}
+// z[E[a]] = ze[a] ; z[I[b]] = r[I[b]] / dI[b]
+__global__ __launch_bounds__(256) void k_red_scatter(const int* __restrict__ E, int nE, const double* __restrict__ ze, const int* __restrict__ I,
+                                                     int nI, const double* __restrict__ dI, const double* __restrict__ r, double* __restrict__ z) {
+    int a = blockIdx.x * 256 + threadIdx.x;
+    if (a < nE) z[E[a]] = ze[a];
+    if (a < nI) z[I[a]] = r[I[a]] / dI[a];
+}

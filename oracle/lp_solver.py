@@ -41,6 +41,10 @@ COL_MIN_M = 64        # column (Sherman-Morrison-Woodbury) form of the Newton sy
 COL_MAX_RATIO = 0.8   # per solve beyond which the rest of the LP returns to the row form, pivot of fixed columns
 COL_MAX_CG = 6
 COL_FIXED = 1e200
+RED_MIN_M = 4096      # reduced row form (normal phase): smallest M, slack-dominance factor, smallest dropped share of the
+RED_TAU = 100.0       # rows that is worth a separate factor, CG steps per solve beyond which the LP returns to the full factor
+RED_MIN_FRAC = 0.1
+RED_MAX_CG = 10
 PCG_FLOOR = 1e-10    # residual floor of a Newton solve relative to |rhs|: exact factor / approximate preconditioner
 PCG_FLOOR_APPROX = 1e-13
 PCG_MAXIT = 20       # conjugate-gradient steps per Newton solve
@@ -209,6 +213,11 @@ class IPM:
         self.col_ok = bool(ns > 0 and M >= COL_MIN_M and n <= COL_MAX_RATIO * M and np.all(np.bincount(lp.srow, minlength=M) > 0))
         self.col_off = False
         self.col_iters = 0
+        # reduced row form: normal phase of large problems with a sparse matrix only (the selection and the extra CG steps
+        # cost more than they save on small or dense ones)
+        self.red_ok = bool(ns == 0 and M >= RED_MIN_M and np.count_nonzero(lp.A) * 16 <= M * n)
+        self.red_off = False
+        self.red_iters = 0
 
     def measures(self):
         lp, ineq, sg, free = self.lp, self.ineq, self.sg, self.free
@@ -276,6 +285,33 @@ class IPM:
                 def precond(r):
                     u = dinv * r
                     return u - dinv * (A @ chol_solve(LK, A.T @ u))
+            # Reduced row form (normal phase of large sparse problems): an inequality row whose slack term dominates its own
+            # Schur diagonal (D_ii > RED_TAU * s_ii, s_ii = sum_j A_ij^2 / Th_j) is almost decoupled from the rest - it is
+            # left out of the factor and preconditioned by its diagonal alone; the CG on the full system restores the coupling.
+            use_red = False
+            if not use_col and self.red_ok and not self.red_off:
+                sdiag = (A * A) @ thp_inv
+                drop = ineq & (dS > RED_TAU * sdiag)
+                use_red = RED_MIN_FRAC * M <= int(drop.sum()) < M
+            if use_col:
+                pass
+            elif use_red:
+                self.red_iters += 1
+                E = np.nonzero(~drop)[0]
+                Idx = np.nonzero(drop)[0]
+                SE = dsyrk(1.0, A[E] * np.sqrt(thp_inv), lower=True)
+                edx = np.arange(len(E))
+                SE[edx, edx] += dS[E]
+                ed0 = SE[edx, edx].copy()
+                SE[edx, edx] += 1e-13 * ed0 + 1e-30
+                LE = chol_guard(SE, ed0)
+                dI = sdiag[Idx] + dS[Idx]
+
+                def precond(r):
+                    z = np.empty(M)
+                    z[E] = chol_solve(LE, r[E])
+                    z[Idx] = r[Idx] / dI
+                    return z
             else:
                 S = dsyrk(1.0, A * np.sqrt(thp_inv), lower=True) if M else np.zeros((0, 0))   # lower triangle of A diag(thp_inv) A'
                 idx = np.arange(M)
@@ -305,7 +341,7 @@ class IPM:
                 res = rhs - (A @ (thp_inv * (A.T @ dy)) + dS * dy)
                 # the approximate preconditioner (column form) must earn its keep: tighter floor, so that a loss of accuracy
                 # shows up as CG steps (and ends the form) instead of as a growing primal residual
-                floor = PCG_FLOOR_APPROX if use_col else PCG_FLOOR
+                floor = PCG_FLOOR_APPROX if (use_col or use_red) else PCG_FLOOR
                 tol = max(floor * max(1.0, np.abs(rhs).max(initial=0.0)), PCG_KAPPA * rpmax)
                 if np.abs(res).max(initial=0.0) > tol:
                     z = precond(res)
@@ -382,6 +418,9 @@ class IPM:
                 # iteration's directions and redo the iteration in row form
                 self.col_off = True
                 continue
+            if use_red and cg_fail[0]:
+                self.red_off = True                 # same safety net for the reduced row form
+                continue
             a, b = min(1.0, eta * ap), min(1.0, eta * ad)      # separate primal / dual step lengths
             self.p = self.p + a * dp
             self.s = self.s + a * ds
@@ -396,6 +435,8 @@ class IPM:
             self.y = np.where(ineq, sg * self.pi, self.y + b * dy)
             if use_col and cg_max[0] > COL_MAX_CG:
                 self.col_off = True
+            if use_red and cg_max[0] > RED_MAX_CG:
+                self.red_off = True
 
 
 # ----------------------------------------------------------------------------- active-set machinery
@@ -615,6 +656,7 @@ def solve_scaled(lp, warm=None, stats=None, hint=None):
         stats['nfact'] += ip.iters - stats['ipm_iters']
         stats['ipm_iters'] = ip.iters
         stats['col_iters'] = ip.col_iters
+        stats['red_iters'] = ip.red_iters
         if st == INFEASIBLE:
             stats['path'] = 'ipm-infeasible'
             return INFEASIBLE, None, None, None, None
