@@ -170,3 +170,39 @@ def test_edge_case_shapes_have_their_hand_worked_answers():
         p_ref, lam_ref = EDGE_CASE_ANSWERS[name]
         assert np.allclose(out[0], p_ref, atol=1e-12), name
         assert np.allclose(out[1], lam_ref, atol=1e-12), name
+
+
+def test_newton_system_forms_agree():
+    """The column form (restoration LPs) and the reduced row form (normal phase) are only cheaper ways to precondition
+    the same Newton systems: switched off, the LP solver must end on the same active sets and the same point."""
+    from oracle import lp_solver as L
+    from tests.util import random_subproblem, oracle_solve
+    # restoration LP with n well below M -> column form
+    sp = random_subproblem(61, 40, 120, 0.3, 0.1, 4, infeasible=True)
+    qp, out = oracle_solve(sp)
+    assert out[5] == 2
+    qp, a = oracle_solve(sp, True, qp)
+    assert a[5] == 1 and a[6]['stats']['col_iters'] > 0
+    saved = L.COL_MAX_RATIO
+    try:
+        L.COL_MAX_RATIO = 0.0
+        qp2, out2 = oracle_solve(sp)
+        qp2, b = oracle_solve(sp, True, qp2)
+    finally:
+        L.COL_MAX_RATIO = saved
+    assert b[5] == 1 and b[6]['stats']['col_iters'] == 0
+    assert all(np.array_equal(x, y) for x, y in zip(a[6]['sets'], b[6]['sets']))
+    assert np.abs(a[0] - b[0]).max() < 1e-9 and np.abs(a[1] - b[1]).max() < 1e-8
+    # sparse normal-phase LP with many slack-dominated inequality rows -> reduced row form (size gate lowered for the test)
+    sp = random_subproblem(62, 300, 260, 0.01, 0.0, 0, delta=0.05)
+    saved = L.RED_MIN_M
+    try:
+        L.RED_MIN_M = 64
+        qp, a = oracle_solve(sp)
+    finally:
+        L.RED_MIN_M = saved
+    qp, b = oracle_solve(sp)
+    assert a[5] == b[5] == 1 and b[6]['stats']['red_iters'] == 0
+    assert all(np.array_equal(x, y) for x, y in zip(a[6]['sets'], b[6]['sets']))
+    assert np.abs(a[0] - b[0]).max() < 1e-9 and np.abs(a[1] - b[1]).max() < 1e-8
+    assert a[6]['stats']['red_iters'] > 0, a[6]['stats']
