@@ -216,23 +216,23 @@ __global__ __launch_bounds__(64 * NW, WPE) void k_syrk(const double* __restrict_
         if (ga < Ms) arow[ps] = A + (idx ? (int64_t)idx[ga] : row0 + ga) * ld;
         if (gb < MsB) brow[ps] = A + (idx ? (int64_t)idx[gb] : row0 + gb) * ld;
     }
-    double2 ra[PASSES], rb[PASSES];
+    // gload only issues the loads; the scaling (sign of A, theta on B) happens in lstore, i.e. after the MFMAs of the current
+    // chunk - a multiply right behind the load would put the s_waitcnt vmcnt(0) in front of them and expose the load latency
+    double2 ra[PASSES], rb[PASSES], rth;
     auto gload = [&](int k0) {
-        double2 th = theta ? *reinterpret_cast<const double2*>(theta + k0 + lk) : make_double2(1.0, 1.0);
+        rth = theta ? *reinterpret_cast<const double2*>(theta + k0 + lk) : make_double2(1.0, 1.0);
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
-            double2 a = arow[ps] ? *reinterpret_cast<const double2*>(arow[ps] + k0 + lk) : make_double2(0.0, 0.0);
-            ra[ps] = make_double2(asign * a.x, asign * a.y);
-            double2 b = brow[ps] ? *reinterpret_cast<const double2*>(brow[ps] + k0 + lk) : make_double2(0.0, 0.0);
-            rb[ps] = make_double2(b.x * th.x, b.y * th.y);
+            ra[ps] = arow[ps] ? *reinterpret_cast<const double2*>(arow[ps] + k0 + lk) : make_double2(0.0, 0.0);
+            rb[ps] = brow[ps] ? *reinterpret_cast<const double2*>(brow[ps] + k0 + lk) : make_double2(0.0, 0.0);
         }
     };
     auto lstore = [&](int st) {
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
             int r = ps * ROWS_PER_PASS + lr;
-            *reinterpret_cast<double2*>(&As[st][r * (KC + 2) + lk]) = ra[ps];
-            *reinterpret_cast<double2*>(&Bs[st][r * (KC + 2) + lk]) = rb[ps];
+            *reinterpret_cast<double2*>(&As[st][r * (KC + 2) + lk]) = make_double2(asign * ra[ps].x, asign * ra[ps].y);
+            *reinterpret_cast<double2*>(&Bs[st][r * (KC + 2) + lk]) = make_double2(rb[ps].x * rth.x, rb[ps].y * rth.y);
         }
     };
     // k-chunks to visit: all of them, or (Schur build of a sparse Jacobian) only those where both operand tiles
