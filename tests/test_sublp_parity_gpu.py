@@ -120,7 +120,7 @@ def test_random_campaign():
     INFEASIBLE outcome and a perturbed re-solve on the same handle (warm path): status, path decision, active sets and
     the 1e-10 bar on every call.  Instances with more equality rows than variables are left out: their active rows are
     linearly dependent, the multipliers are not unique and which dependent row the pivot guard drops is a rounding-level
-    decision (scripts/dev_fuzz_parity.py runs them too: 5 of 1840 LPs differ, all of that kind)."""
+    decision (tests/tools/dev_fuzz_parity.py runs them too: 5 of 1840 LPs differ, all of that kind)."""
     checked = 0
     for k in range(60):
         seed = 7000 + k
