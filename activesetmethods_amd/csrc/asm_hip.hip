@@ -1692,6 +1692,7 @@ int asm_destroy(asm_handle* h) {
     if (!h) return ASM_ERR_ARG;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->stream2) (void)hipStreamSynchronize(h->stream2);   // look-ahead chain may still be running after an exception
     for (auto& r : h->regions) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : h->event_pool) (void)hipEventDestroy(e);
     free_device(h);

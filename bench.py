@@ -3,10 +3,16 @@
 
   python bench.py --gpus N --steps K --warmup W [--workload c2|c2small] [--algorithm "Trust Region"]
 
-A "step" is one SLP outer iteration that reaches the LP solve: evaluation callbacks,
-Jacobian assembly, LP formulation, the HIP LP solve and the merit/step logic.  At N>1 every rank runs
-its own independent NLP replica (the path does not shard inside one NLP - "replicas only", DESIGN.md);
-value = total steps of all ranks / max-over-ranks time.  One JSON line is printed by rank 0.
+N = 1 (default workload c4): a "step" is one SLP outer iteration that reaches the LP solve:
+evaluation, Jacobian assembly, LP formulation, the HIP LP solve and the merit/step logic.
+N > 1 (default workload c5, BASELINE.json configs[4] / the "batch-NLP solves/sec @8 GPU" half of the metric): scenario
+ACOPF instances are block-partitioned over the ranks, a "step" is one complete scenario solve per GPU (default 64 per GPU =
+512 over 8), no data-path collective, one all-reduce of the convergence statistics.  An explicit --workload c2|c3|c4 at
+N > 1 runs independent replicas (the path does not shard inside one NLP - "replicas only").
+value = work of all ranks / max-over-ranks time.  One JSON line is printed by rank 0.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (one child process per
+GPU, spawned before anything touches the GPU); under `python -m torch.distributed.run` the ranks already exist and are used.
 
 The dominant kernel's roofline numbers come from HIP events recorded on the solver's own stream
 around each launch (include/asm_hip.h: asm_kernel_stats_get); the CPU baseline is the oracle's NumPy
@@ -65,7 +71,7 @@ WORKLOADS = {
     "c5": dict(desc="batch of scenario ACOPF, case300-sized synthetic grid (300 bus / 69 gen / 411 branch), load_scale 0.5, loads x U(0.9,1.1) per "
                     "scenario (BASELINE.json configs[4] has 512 scenarios over 8 GPUs = 64 per GPU; --scenarios-per-gpu sets the share), "
                     "n=2382 m=3889; one step = one complete scenario solve",
-               algorithm="Line Search", steps=2, warmup=0),
+               algorithm="Line Search", steps=64, warmup=1),
     "c3": dict(desc="ACOPF case118-sized synthetic grid (118 bus / 54 gen / 186 branch; BASELINE.json configs[2]), n=1088 m=1725",
                algorithm="Line Search", steps=10, warmup=2),
     "c2": dict(desc="synthetic dense NLP n=1000 m=500 (BASELINE.json configs[1])", algorithm="Trust Region", steps=20, warmup=3),
@@ -101,14 +107,14 @@ def run_batch(args, rank, world, local_rank, dist, torch):
     torch.cuda.synchronize()
     thr0 = _cpu_throttled_s()
     t0 = time.perf_counter()
-    slps, stats = batch.solve_batch(make_model, total, rank, world, run=run, reduce_device="cuda" if dist is not None else None,
+    slps, stats = batch.solve_batch(make_model, total, rank, world, run=run, reduce_device=args.reduce_device,
                                     concurrency=args.concurrency)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=args.reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
@@ -262,12 +268,45 @@ def cpu_baseline(pr, algorithm, budget_s, mix):
                 highs=highs_baseline(lp))
 
 
+def launch_ranks(n, argv, script=None):
+    """Start `n` ranks of `script` (default: this file) as child processes, one per GPU, with the rendezvous variables of
+    torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT).  Called before anything
+    touches the GPU (a process that has initialised HIP must not fork/exec workers).  Returns the first non-zero exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, script or os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(cmd, env=env))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in pending:               # a failed rank would leave the others waiting at the next barrier
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: c4 on one GPU (the configuration the metric is quoted on), c5 (scenario batch) on several")
     ap.add_argument("--algorithm", default=None)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--scenarios-per-gpu", type=int, default=None, help="workload c5: scenarios per GPU (alias of --steps)")
@@ -275,25 +314,37 @@ def main():
     ap.add_argument("--concurrency", type=int, default=3, help="workload c5: scenarios in flight per GPU (one handle / HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.workload is None:
+        args.workload = "c4" if world == 1 else "c5"
     wl = WORKLOADS[args.workload]
     args.steps = wl["steps"] if args.steps is None else args.steps
     args.warmup = wl["warmup"] if args.warmup is None else args.warmup
     args.algorithm = wl["algorithm"] if args.algorithm is None else args.algorithm
 
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.workload == "c5":
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # one hardware queue per concurrent scenario stream (ROCm default: 4)
     import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    rehearsal = ndev < world            # more ranks than GPUs (1-GPU box): ranks share devices, statistics go over gloo
+    local_rank = local_rank % ndev
+    torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))      # RCCL over xGMI
+    args.reduce_device = None if dist is None else ("cpu" if rehearsal else "cuda")
 
     if args.workload == "c5":
         if args.scenarios_per_gpu is not None:
@@ -318,7 +369,7 @@ def main():
     elapsed = time.perf_counter() - t0
     assert done == args.steps
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=args.reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -158,3 +158,29 @@ def test_batch_statistics_all_reduce_gloo_world2():
     assert s0 == s1                                              # every rank holds the reduced statistics
     assert s0["scenarios"] == 5 and s0["converged"] == 5
     assert s0["lp_solves"] >= s0["iterations"] - 5 and s0["wall_s"] > 0
+
+
+def test_bench_launcher_starts_one_rank_per_gpu(tmp_path):
+    """`bench.py --gpus N` (N > 1, no WORLD_SIZE) starts N ranks itself with the torch.distributed.run rendezvous
+    variables; here the ranks are a stand-in script that joins a gloo group and all-reduces its rank."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    child = tmp_path / "child.py"
+    child.write_text(
+        "import os, sys, json, torch, torch.distributed as dist\n"
+        "dist.init_process_group('gloo')\n"
+        "t = torch.tensor([float(os.environ['RANK'])], dtype=torch.float64)\n"
+        "dist.all_reduce(t)\n"
+        "open(sys.argv[1] + '.' + os.environ['RANK'], 'w').write(json.dumps(dict(rank=int(os.environ['RANK']), local=int(os.environ['LOCAL_RANK']),\n"
+        "    world=int(os.environ['WORLD_SIZE']), addr=os.environ['MASTER_ADDR'], total=float(t.item()))))\n"
+        "dist.destroy_process_group()\n"
+        "sys.exit(int(sys.argv[2]) if os.environ['RANK'] == '1' else 0)\n")
+    out = str(tmp_path / "res")
+    assert bench.launch_ranks(3, [out, "0"], script=str(child)) == 0
+    res = [json.load(open("%s.%d" % (out, r))) for r in range(3)]
+    assert [r["rank"] for r in res] == [0, 1, 2] and [r["local"] for r in res] == [0, 1, 2]
+    assert all(r["world"] == 3 and r["addr"] == "127.0.0.1" and r["total"] == 3.0 for r in res)
+    assert bench.launch_ranks(2, [out, "7"], script=str(child)) == 7      # a failing rank's exit code is returned
