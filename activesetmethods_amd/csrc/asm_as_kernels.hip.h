@@ -1,0 +1,608 @@
+// Device-resident active-set machinery (oracle/lp_solver.py: identify, eqp, kkt_measures, correct, face_primal, face_dual).
+// The working sets, the index lists derived from them and every O(M+n) vector of the equality-constrained solves live in
+// HBM; the host sequences launches and reads back one small block of counters / scalars per solve (the size of the
+// gathered Schur system, which fixes the launch grids of the SYRK and the factorisation, and the optimality measures).
+// Reductions and compactions run in one 1024-thread workgroup with a fixed order, so every decision is deterministic.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// integer counters / double scalars handed back to the host
+enum { AC_NH = 0, AC_NF, AC_ANYSOFT, AC_NCHG, AC_NDIFF, AC_NVIOL, AC_NREL, AC_COUNT };
+enum { AS_PR = 0, AS_DU, AS_EQRES, AS_HARDRES, AS_COUNT };
+
+struct AsSets {
+    int *rowst, *bst, *sst;      // M / n / ns : row active, bound state (-1 lower, +1 upper, 0 free), slack basic
+};
+
+struct AsPtrs {
+    // scaled LP (the arrays of the interior-point arena)
+    const double *q, *lb, *ub, *r, *w, *slo, *scoef;
+    const int *rtype, *srow, *rs0, *rs1;
+    int64_t n, M, ns;
+    double scale_q;
+    // derived from the current working set
+    int *ksoft;                  // M : first basic slack of the row, -1 if none
+    int *Hidx, *hpos;            // hard rows (active, no basic slack) in ascending order / inverse map (-1)
+    int *Fidx, *fpos;            // free variables in ascending order / inverse map (-1)
+    double *Fmask, *Hmask;       // 1.0 / 0.0 over the (padded) columns / rows: theta operands of the two Gram builds
+    double *sl;                  // M : sum_k scoef_k slo_k of the row's slack columns (all slacks at their bound)
+    // solution of the last solve
+    double *p, *s, *y, *act, *z;
+    // work vectors: n-sized ...
+    double *pB, *pF, *cF, *rd, *tN, *xfull, *nu;
+    // ... and M-sized (compact vectors are indexed by position in Hidx / Fidx; both fit max(M, n))
+    double *t, *bH, *v, *u, *yH, *yfull, *uacc, *ax;
+    int* cnt;
+    double* scal;
+};
+
+// ---- block-wide ordered compaction helper: returns the output position of a set flag, advances `base` by the chunk's count
+__device__ __forceinline__ int blk_compact_pos(bool flag, int& base, int* sh_cnt) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    unsigned long long m = __ballot(flag);
+    if (lane == 0) sh_cnt[wv] = __popcll(m);
+    __syncthreads();
+    int off = 0, tot = 0;
+    for (int k = 0; k < nw; ++k) {
+        int c = sh_cnt[k];
+        if (k < wv) off += c;
+        tot += c;
+    }
+    int pos = base + off + __popcll(m & ((1ull << lane) - 1ull));
+    base += tot;
+    __syncthreads();
+    return pos;
+}
+
+// optimal-partition guess from the interior-point iterate (oracle: identify)
+__global__ __launch_bounds__(256) void k_as_identify(IpmPtrs P, AsSets S) {
+    int64_t t = blockIdx.x * 256 + threadIdx.x;
+    const double sq = P.scale_q;
+    if (t < P.n) {
+        int b = 0;
+        if (!(P.ub[t] > P.lb[t])) b = -1;
+        else {
+            double width = P.ub[t] - P.lb[t];
+            if ((P.tL[t] / width) < (P.muL[t] / sq)) b = -1;
+            if ((P.tU[t] / width) < (P.muU[t] / sq)) b = 1;
+        }
+        S.bst[t] = b;
+    }
+    if (t < P.ns) S.sst[t] = ((P.ts[t] / (1.0 + fabs(P.slo[t]))) >= (P.mus[t] / sq)) ? 1 : 0;
+    if (t < P.M) {
+        int a = P.rtype[t] == 0 ? 1 : (((P.g[t] / (1.0 + fabs(P.r[t]))) < (P.pi[t] / sq)) ? 1 : 0);
+        if (P.ns) {
+            int k0 = P.rs0[t], k1 = P.rs1[t];
+            if (k0 >= 0 && (P.ts[k0] / (1.0 + fabs(P.slo[k0]))) >= (P.mus[k0] / sq)) a = 1;
+            if (k1 >= 0 && (P.ts[k1] / (1.0 + fabs(P.slo[k1]))) >= (P.mus[k1] / sq)) a = 1;
+        }
+        S.rowst[t] = a;
+    }
+}
+
+// out = src (0 when src is null) clipped into [lb, ub]: reference points of the two projections (oracle: zero_p, np.clip(ip.p))
+__global__ __launch_bounds__(256) void k_as_clip0(const double* __restrict__ lb, const double* __restrict__ ub, const double* __restrict__ src,
+                                                  double* __restrict__ out, int64_t n) {
+    int64_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j < n) out[j] = fmin(fmax(src ? src[j] : 0.0, lb[j]), ub[j]);
+}
+
+// sl[i] = sum of scoef*slo over the row's slack columns (once per LP)
+__global__ __launch_bounds__(256) void k_as_sl(AsPtrs A) {
+    int64_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= A.M) return;
+    double a = 0.0;
+    if (A.ns) {
+        int k0 = A.rs0[i], k1 = A.rs1[i];
+        if (k0 >= 0) a += A.scoef[k0] * A.slo[k0];
+        if (k1 >= 0) a += A.scoef[k1] * A.slo[k1];
+    }
+    A.sl[i] = a;
+}
+
+// Everything an equality-constrained solve derives from its working set: soft rows and their known multiplier, the ordered
+// lists of hard rows and free variables with their inverse maps and masks, the bound-active part of p.  One workgroup.
+__global__ __launch_bounds__(1024) void k_as_setup(AsPtrs A, AsSets S, const double* __restrict__ p_ref, int64_t ldn, int64_t ldT) {
+    __shared__ int sh_cnt[16];
+    int baseH = 0, baseF = 0, any_soft = 0;
+    for (int64_t i0 = 0; i0 < A.M; i0 += 1024) {
+        int64_t i = i0 + threadIdx.x;
+        bool hard = false;
+        if (i < A.M) {
+            int ks = -1;
+            if (A.ns) {
+                int k0 = A.rs0[i], k1 = A.rs1[i];
+                if (k0 >= 0 && S.sst[k0] == 1) ks = k0;
+                else if (k1 >= 0 && S.sst[k1] == 1) ks = k1;
+            }
+            A.ksoft[i] = ks;
+            A.y[i] = ks >= 0 ? A.w[ks] * A.scoef[ks] : 0.0;
+            hard = S.rowst[i] == 1 && ks < 0;
+            A.Hmask[i] = hard ? 1.0 : 0.0;
+            if (ks >= 0) any_soft = 1;
+        }
+        int pos = blk_compact_pos(hard, baseH, sh_cnt);
+        if (i < A.M) {
+            A.hpos[i] = hard ? pos : -1;
+            if (hard) A.Hidx[pos] = (int)i;
+        }
+    }
+    for (int64_t i = A.M + threadIdx.x; i < ldT; i += 1024) A.Hmask[i] = 0.0;
+    for (int64_t j0 = 0; j0 < A.n; j0 += 1024) {
+        int64_t j = j0 + threadIdx.x;
+        bool fr = false;
+        if (j < A.n) {
+            int b = S.bst[j];
+            fr = b == 0;
+            A.Fmask[j] = fr ? 1.0 : 0.0;
+            double ref = p_ref ? p_ref[j] : 0.0;
+            double pj = b < 0 ? A.lb[j] : (b > 0 ? A.ub[j] : ref);
+            A.p[j] = pj;
+            A.pB[j] = fr ? 0.0 : pj;
+            A.pF[j] = fr ? ref : 0.0;
+        }
+        int pos = blk_compact_pos(fr, baseF, sh_cnt);
+        if (j < A.n) {
+            A.fpos[j] = fr ? pos : -1;
+            if (fr) A.Fidx[pos] = (int)j;
+        }
+    }
+    for (int64_t j = A.n + threadIdx.x; j < ldn; j += 1024) { A.Fmask[j] = 0.0; A.pB[j] = 0.0; A.pF[j] = 0.0; A.p[j] = 0.0; }
+    for (int64_t k = threadIdx.x; k < A.ns; k += 1024) A.s[k] = A.slo[k];
+    sh_cnt[0] = 0;
+    __syncthreads();
+    if (any_soft) sh_cnt[0] = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        A.cnt[AC_NH] = baseH;
+        A.cnt[AC_NF] = baseF;
+        A.cnt[AC_ANYSOFT] = sh_cnt[0];
+    }
+}
+
+// right-hand sides of the two projections:  bH = r_H - (Ah pB)_H - sl_H ;  cF = q_F - (Ah' y_soft)_F ;  yH = y_ref_H
+// t = Ah pB and (when any_soft) tN = Ah' y_soft were produced by the matrix-vector kernels.
+__global__ __launch_bounds__(256) void k_as_rhs(AsPtrs A, const double* __restrict__ y_ref) {
+    int64_t t = blockIdx.x * 256 + threadIdx.x;
+    const int nH = A.cnt[AC_NH];
+    const bool soft = A.cnt[AC_ANYSOFT] != 0;
+    if (t < nH) {
+        int i = A.Hidx[t];
+        A.bH[t] = A.r[i] - A.t[i] - A.sl[i];
+        A.yH[t] = y_ref ? y_ref[i] : 0.0;
+        A.uacc[t] = 0.0;
+    }
+    if (t < A.n) A.cF[t] = A.Fmask[t] != 0.0 ? A.q[t] - (soft ? A.tN[t] : 0.0) : 0.0;
+}
+// v[a] = bH[a] - t[H[a]]
+__global__ __launch_bounds__(256) void k_as_res_p(AsPtrs A) {
+    int64_t a = blockIdx.x * 256 + threadIdx.x;
+    if (a < A.cnt[AC_NH]) A.v[a] = A.bH[a] - A.t[A.Hidx[a]];
+}
+// yfull = scatter of a compact H-vector (zero elsewhere); optionally accumulate it into uacc
+__global__ __launch_bounds__(256) void k_as_scatter_h(AsPtrs A, const double* __restrict__ src, int accumulate) {
+    int64_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= A.M) return;
+    int pos = A.hpos[i];
+    A.yfull[i] = pos >= 0 ? src[pos] : 0.0;
+    if (accumulate && pos >= 0) A.uacc[pos] += src[pos];
+}
+// pF += Fmask .* tN
+__global__ __launch_bounds__(256) void k_as_add_f(AsPtrs A) {
+    int64_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j < A.n) A.pF[j] += A.Fmask[j] * A.tN[j];
+}
+// rd = Fmask .* (cF - tN)
+__global__ __launch_bounds__(256) void k_as_rd(AsPtrs A) {
+    int64_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j < A.n) A.rd[j] = A.Fmask[j] * (A.cF[j] - A.tN[j]);
+}
+// v[a] = t[H[a]]
+__global__ __launch_bounds__(256) void k_as_gather_h(AsPtrs A) {
+    int64_t a = blockIdx.x * 256 + threadIdx.x;
+    if (a < A.cnt[AC_NH]) A.v[a] = A.t[A.Hidx[a]];
+}
+// yH += u
+__global__ __launch_bounds__(256) void k_as_add_yh(AsPtrs A) {
+    int64_t a = blockIdx.x * 256 + threadIdx.x;
+    if (a < A.cnt[AC_NH]) A.yH[a] += A.u[a];
+}
+// p_F <- pF ; y_H <- yH (soft rows keep their known multiplier, inactive rows 0)
+__global__ __launch_bounds__(256) void k_as_merge(AsPtrs A, int with_y) {
+    int64_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < A.n && A.Fmask[t] != 0.0) A.p[t] = A.pF[t];
+    if (with_y && t < A.M) {
+        int pos = A.hpos[t];
+        if (pos >= 0) A.y[t] = A.yH[pos];
+    }
+}
+
+// Final stage of an equality-constrained solve (oracle: eqp tail, kkt_measures, correct).  Inputs: t = Ah p, tN = Ah' y.
+// Computes the basic slack values, act = Ah p + E s, z = q - Ah' y, the LP optimality measures of (p, s, y) on the working
+// set `cur`, the corrected working set `nx` with the number of changes, and the number of positions where `nx` differs
+// from `prev` (cycle detection).  One workgroup.
+__global__ __launch_bounds__(1024) void k_as_finish(AsPtrs A, AsSets cur, AsSets nx, AsSets prev, int have_prev, double tol_p, double tol_d) {
+    __shared__ double sh[16];
+    double pr = 0.0, du = 0.0, nchg = 0.0, ndiff = 0.0;
+    const double td = tol_d * A.scale_q;
+    for (int64_t i = threadIdx.x; i < A.M; i += 1024) {
+        double a = A.t[i] + A.sl[i];
+        int ks = A.ksoft[i];
+        if (ks >= 0) {
+            double snew = A.slo[ks] + (A.r[i] - a) / A.scoef[ks];
+            a += A.scoef[ks] * (snew - A.slo[ks]);
+            A.s[ks] = snew;
+        }
+        A.act[i] = a;
+        const int rt = A.rtype[i];
+        const double den = 1.0 + fabs(A.r[i]);
+        double viol = rt == 0 ? fabs(a - A.r[i]) : fmax(0.0, rt * (A.r[i] - a));
+        pr = fmax(pr, viol / den);
+        const double y = A.y[i];
+        const int st = cur.rowst[i];
+        double dr = st == 0 ? fabs(y) : (rt == 1 ? fmax(-y, 0.0) : (rt == -1 ? fmax(y, 0.0) : 0.0));
+        du = fmax(du, dr);
+        int ns_ = st;
+        if (rt != 0) {
+            double v2 = rt * (A.r[i] - a) / den;
+            if (st == 1 && rt * y < -td) { ns_ = 0; nchg += 1.0; }
+            else if (st == 0 && v2 > tol_p) { ns_ = 1; nchg += 1.0; }
+        }
+        nx.rowst[i] = ns_;
+    }
+    for (int64_t j = threadIdx.x; j < A.n; j += 1024) {
+        const double z = A.q[j] - A.tN[j];
+        A.z[j] = z;
+        const double pj = A.p[j], lb = A.lb[j], ub = A.ub[j];
+        pr = fmax(pr, fmax(lb - pj, 0.0));
+        pr = fmax(pr, fmax(pj - ub, 0.0));
+        const int b = cur.bst[j];
+        const bool fixed = ub <= lb;
+        if (!fixed) {
+            double dz = b < 0 ? fmax(-z, 0.0) : (b > 0 ? fmax(z, 0.0) : fabs(z));
+            du = fmax(du, dz);
+        }
+        int nb = b;
+        if (!fixed && ((b < 0 && z < -td) || (b > 0 && z > td))) { nb = 0; nchg += 1.0; }
+        else if (b == 0 && pj < lb - tol_p) { nb = -1; nchg += 1.0; }
+        else if (b == 0 && pj > ub + tol_p) { nb = 1; nchg += 1.0; }
+        nx.bst[j] = nb;
+    }
+    __syncthreads();                                   // s[] of the basic slacks is complete
+    for (int64_t k = threadIdx.x; k < A.ns; k += 1024) {
+        const double slo = A.slo[k], sk = A.s[k];
+        pr = fmax(pr, fmax(slo - sk, 0.0) / (1.0 + fabs(slo)));
+        const double zs = A.w[k] - A.scoef[k] * A.y[A.srow[k]];
+        const int st = cur.sst[k];
+        du = fmax(du, st == 0 ? fmax(-zs, 0.0) : fabs(zs));
+        int ns_ = st;
+        if (st == 0 && zs < -td) { ns_ = 1; nchg += 1.0; }
+        else if (st == 1 && sk < slo - tol_p * (1.0 + fabs(slo))) { ns_ = 0; nchg += 1.0; }
+        nx.sst[k] = ns_;
+    }
+    __syncthreads();
+    for (int64_t k = threadIdx.x; k < A.ns; k += 1024)
+        if (nx.sst[k] == 1) nx.rowst[A.srow[k]] = 1;
+    __syncthreads();
+    if (have_prev) {
+        for (int64_t i = threadIdx.x; i < A.M; i += 1024) ndiff += nx.rowst[i] != prev.rowst[i];
+        for (int64_t j = threadIdx.x; j < A.n; j += 1024) ndiff += nx.bst[j] != prev.bst[j];
+        for (int64_t k = threadIdx.x; k < A.ns; k += 1024) ndiff += nx.sst[k] != prev.sst[k];
+    }
+    pr = blk_reduce_max(pr, sh);
+    du = blk_reduce_max(du, sh);
+    nchg = blk_reduce_sum(nchg, sh);
+    ndiff = blk_reduce_sum(ndiff, sh);
+    if (threadIdx.x == 0) {
+        A.scal[AS_PR] = pr;
+        A.scal[AS_DU] = du / A.scale_q;
+        A.cnt[AC_NCHG] = (int)nchg;
+        A.cnt[AC_NDIFF] = have_prev ? (int)ndiff : -1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Canonical pair of a non-unique optimum (oracle: face_primal / face_dual).
+// Primal round tail.  Inputs: t = Ah p, tN = Ah' u_full (u = multipliers of the least-norm problem on the hard rows).
+// Violated inequalities of the face join the working set W (in place); when none is violated, non-mandatory members of W
+// with a wrong-sign multiplier leave; when nothing changes the hard rows must hold (AS_HARDRES).
+__global__ __launch_bounds__(1024) void k_face_primal_finish(AsPtrs A, AsSets W, AsSets part, double tol_p, double tol_m) {
+    __shared__ double sh[16];
+    __shared__ int s_viol;
+    double nviol = 0.0, nrel = 0.0, hres = 0.0;
+    // ---- pass 1: slack values, activities, violations
+    for (int64_t i = threadIdx.x; i < A.M; i += 1024) {
+        double a = A.t[i] + A.sl[i];
+        int ks = A.ksoft[i];
+        if (ks >= 0) {
+            double snew = A.slo[ks] + (A.r[i] - a) / A.scoef[ks];
+            a += A.scoef[ks] * (snew - A.slo[ks]);
+            A.s[ks] = snew;
+        }
+        A.act[i] = a;
+        const int rt = A.rtype[i];
+        const double den = 1.0 + fabs(A.r[i]);
+        if (rt != 0 && W.rowst[i] == 0 && rt * (A.r[i] - a) / den > tol_p) nviol += 1.0;
+        if (A.hpos[i] >= 0) hres = fmax(hres, fabs(a - A.r[i]) / den);
+    }
+    for (int64_t j = threadIdx.x; j < A.n; j += 1024) {
+        const double pj = A.p[j];
+        A.nu[j] = pj - A.tN[j];
+        if (W.bst[j] == 0 && (pj < A.lb[j] - tol_p || pj > A.ub[j] + tol_p)) nviol += 1.0;
+    }
+    __syncthreads();
+    for (int64_t k = threadIdx.x; k < A.ns; k += 1024)
+        if (W.sst[k] == 1 && A.s[k] < A.slo[k] - tol_p * (1.0 + fabs(A.slo[k]))) nviol += 1.0;
+    nviol = blk_reduce_sum(nviol, sh);
+    hres = blk_reduce_max(hres, sh);
+    if (threadIdx.x == 0) s_viol = nviol > 0.0;
+    __syncthreads();
+    if (s_viol) {
+        // ---- grow
+        for (int64_t i = threadIdx.x; i < A.M; i += 1024) {
+            const int rt = A.rtype[i];
+            if (rt != 0 && W.rowst[i] == 0 && rt * (A.r[i] - A.act[i]) / (1.0 + fabs(A.r[i])) > tol_p) W.rowst[i] = 1;
+        }
+        for (int64_t j = threadIdx.x; j < A.n; j += 1024) {
+            if (W.bst[j] != 0) continue;
+            const double pj = A.p[j];
+            if (pj < A.lb[j] - tol_p) W.bst[j] = -1;
+            else if (pj > A.ub[j] + tol_p) W.bst[j] = 1;
+        }
+        for (int64_t k = threadIdx.x; k < A.ns; k += 1024)
+            if (W.sst[k] == 1 && A.s[k] < A.slo[k] - tol_p * (1.0 + fabs(A.slo[k]))) W.sst[k] = 0;
+    } else {
+        // ---- release non-mandatory members with a wrong-sign multiplier of the least-norm problem
+        for (int64_t i = threadIdx.x; i < A.M; i += 1024) {
+            const int rt = A.rtype[i];
+            const int pos = A.hpos[i];
+            if (pos >= 0 && part.rowst[i] != 1 && rt != 0 && rt * A.uacc[pos] < -tol_m) { W.rowst[i] = 0; nrel += 1.0; }
+        }
+        for (int64_t k = threadIdx.x; k < A.ns; k += 1024) {
+            const int i = A.srow[k];
+            const int pos = A.hpos[i];
+            if (W.sst[k] == 0 && part.sst[k] != 0 && pos >= 0 && A.scoef[k] * A.uacc[pos] > tol_m) { W.sst[k] = 1; nrel += 1.0; }
+        }
+        for (int64_t j = threadIdx.x; j < A.n; j += 1024) {
+            const int b = W.bst[j];
+            if (b == 0 || part.bst[j] != 0 || A.ub[j] <= A.lb[j]) continue;
+            const double nu = A.nu[j];
+            if ((b < 0 && nu < -tol_m) || (b > 0 && nu > tol_m)) { W.bst[j] = 0; nrel += 1.0; }
+        }
+        __syncthreads();
+        for (int64_t k = threadIdx.x; k < A.ns; k += 1024)
+            if (W.sst[k] == 1) W.rowst[A.srow[k]] = 1;
+    }
+    nrel = blk_reduce_sum(nrel, sh);
+    if (threadIdx.x == 0) {
+        A.cnt[AC_NVIOL] = (int)nviol;
+        A.cnt[AC_NREL] = (int)nrel;
+        A.scal[AS_HARDRES] = hres;
+    }
+}
+
+// Anchored (feasible-direction) step of the primal least-norm problem (oracle: face_primal, second stage).
+// Inputs: the least-norm point of aff(W) in (p, s, act) with its multipliers (uacc on the hard rows, tN = Ah' u_full), the
+// feasible anchor (pa, sa, acta).  If the point is feasible: the most wrong-signed non-mandatory member of W leaves (rows,
+// then slacks, then lower, then upper bounds; lowest index among equals) and the point becomes the anchor - or, when every
+// sign is right, the method is done (AC_NREL = 0, AC_NVIOL = 0).  Otherwise the anchor moves towards the point until the
+// first inequality blocks; every inequality tight there joins W (AC_NCHG = their number).  One workgroup.
+__device__ __forceinline__ double as_ratio(double g0, double g1, double tol) {
+    if (!(g1 < -tol)) return 2.0;
+    double a = fmax(g0, 0.0);
+    return a / (a - g1);
+}
+__global__ __launch_bounds__(1024) void k_face_anchor_step(AsPtrs A, AsSets W, AsSets part, double* __restrict__ pa, double* __restrict__ sa,
+                                                           double* __restrict__ acta, double tol_p, double tol_m) {
+    __shared__ double sh[16];
+    __shared__ double s_val;
+    __shared__ int s_idx[16];
+    const int64_t M = A.M, n = A.n, ns = A.ns;
+    // ---- basic slack values and activities of the candidate (t = Ah p)
+    for (int64_t i = threadIdx.x; i < M; i += 1024) {
+        double a = A.t[i] + A.sl[i];
+        const int ks = A.ksoft[i];
+        if (ks >= 0) {
+            const double snew = A.slo[ks] + (A.r[i] - a) / A.scoef[ks];
+            a += A.scoef[ks] * (snew - A.slo[ks]);
+            A.s[ks] = snew;
+        }
+        A.act[i] = a;
+    }
+    __syncthreads();
+    // ---- margins of the candidate and the step length to the first blocking inequality
+    double nviol = 0.0, alpha = 1.0, hres = 0.0;
+    for (int64_t i = threadIdx.x; i < M; i += 1024) {
+        const int rt = A.rtype[i];
+        const double den = 1.0 + fabs(A.r[i]);
+        if (A.hpos[i] >= 0) hres = fmax(hres, fabs(A.act[i] - A.r[i]) / den);
+        if (rt == 0 || W.rowst[i] != 0) continue;
+        const double g1 = rt * (A.act[i] - A.r[i]) / den, g0 = rt * (acta[i] - A.r[i]) / den;
+        if (g1 < -tol_p) { nviol += 1.0; alpha = fmin(alpha, as_ratio(g0, g1, tol_p)); }
+    }
+    for (int64_t j = threadIdx.x; j < n; j += 1024) {
+        A.nu[j] = A.p[j] - A.tN[j];
+        if (W.bst[j] != 0) continue;
+        double g1 = A.p[j] - A.lb[j], g0 = pa[j] - A.lb[j];
+        if (g1 < -tol_p) { nviol += 1.0; alpha = fmin(alpha, as_ratio(g0, g1, tol_p)); }
+        g1 = A.ub[j] - A.p[j]; g0 = A.ub[j] - pa[j];
+        if (g1 < -tol_p) { nviol += 1.0; alpha = fmin(alpha, as_ratio(g0, g1, tol_p)); }
+    }
+    for (int64_t k = threadIdx.x; k < ns; k += 1024) {
+        if (W.sst[k] != 1) continue;
+        const double den = 1.0 + fabs(A.slo[k]);
+        const double g1 = (A.s[k] - A.slo[k]) / den, g0 = (sa[k] - A.slo[k]) / den;
+        if (g1 < -tol_p) { nviol += 1.0; alpha = fmin(alpha, as_ratio(g0, g1, tol_p)); }
+    }
+    nviol = blk_reduce_sum(nviol, sh);
+    alpha = blk_reduce_min(alpha, sh);
+    hres = blk_reduce_max(hres, sh);
+    if (nviol > 0.0) {
+        // ---- move the anchor, add what blocks there
+        double nadd = 0.0;
+        for (int64_t i = threadIdx.x; i < M; i += 1024) {
+            const double an = acta[i] + alpha * (A.act[i] - acta[i]);
+            acta[i] = an;
+            const int rt = A.rtype[i];
+            if (rt == 0 || W.rowst[i] != 0) continue;
+            const double den = 1.0 + fabs(A.r[i]);
+            if (rt * (A.act[i] - A.r[i]) / den < -tol_p && rt * (an - A.r[i]) / den <= tol_p * 1e-3) { W.rowst[i] = 1; nadd += 1.0; }
+        }
+        for (int64_t j = threadIdx.x; j < n; j += 1024) {
+            const double pn = pa[j] + alpha * (A.p[j] - pa[j]);
+            pa[j] = pn;
+            if (W.bst[j] != 0) continue;
+            if (A.p[j] - A.lb[j] < -tol_p && pn - A.lb[j] <= tol_p * 1e-3) { W.bst[j] = -1; nadd += 1.0; }
+            else if (A.ub[j] - A.p[j] < -tol_p && A.ub[j] - pn <= tol_p * 1e-3) { W.bst[j] = 1; nadd += 1.0; }
+        }
+        for (int64_t k = threadIdx.x; k < ns; k += 1024) {
+            const double sn = sa[k] + alpha * (A.s[k] - sa[k]);
+            sa[k] = sn;
+            if (W.sst[k] != 1) continue;
+            const double den = 1.0 + fabs(A.slo[k]);
+            if ((A.s[k] - A.slo[k]) / den < -tol_p && (sn - A.slo[k]) / den <= tol_p * 1e-3) { W.sst[k] = 0; nadd += 1.0; }
+        }
+        nadd = blk_reduce_sum(nadd, sh);
+        if (threadIdx.x == 0) {
+            A.cnt[AC_NVIOL] = (int)nviol;
+            A.cnt[AC_NCHG] = (int)nadd;
+            A.cnt[AC_NREL] = 0;
+            A.scal[AS_HARDRES] = hres;
+        }
+        return;
+    }
+    // ---- feasible: worst wrong-signed non-mandatory member
+    double worst = 0.0;
+    for (int64_t i = threadIdx.x; i < M; i += 1024) {
+        const int rt = A.rtype[i], pos = A.hpos[i];
+        if (pos >= 0 && part.rowst[i] != 1 && rt != 0) worst = fmax(worst, -rt * A.uacc[pos]);
+    }
+    for (int64_t k = threadIdx.x; k < ns; k += 1024) {
+        const int pos = A.hpos[A.srow[k]];
+        if (W.sst[k] == 0 && part.sst[k] != 0 && pos >= 0) worst = fmax(worst, A.scoef[k] * A.uacc[pos]);
+    }
+    for (int64_t j = threadIdx.x; j < n; j += 1024) {
+        const int b = W.bst[j];
+        if (b == 0 || part.bst[j] != 0 || A.ub[j] <= A.lb[j]) continue;
+        worst = fmax(worst, b < 0 ? -A.nu[j] : A.nu[j]);
+    }
+    worst = blk_reduce_max(worst, sh);
+    int released = 0;
+    if (worst > tol_m) {
+        // lowest index holding the worst value, family by family (rows, slacks, lower bounds, upper bounds)
+        for (int fam = 0; fam < 4 && !released; ++fam) {
+            double best = 1e300;                                     // smallest index as a double (exact below 2^53)
+            if (fam == 0) {
+                for (int64_t i = threadIdx.x; i < M; i += 1024) {
+                    const int rt = A.rtype[i], pos = A.hpos[i];
+                    if (pos >= 0 && part.rowst[i] != 1 && rt != 0 && -rt * A.uacc[pos] == worst) best = fmin(best, (double)i);
+                }
+            } else if (fam == 1) {
+                for (int64_t k = threadIdx.x; k < ns; k += 1024) {
+                    const int pos = A.hpos[A.srow[k]];
+                    if (W.sst[k] == 0 && part.sst[k] != 0 && pos >= 0 && A.scoef[k] * A.uacc[pos] == worst) best = fmin(best, (double)k);
+                }
+            } else {
+                for (int64_t j = threadIdx.x; j < n; j += 1024) {
+                    const int b = W.bst[j];
+                    if (b == 0 || part.bst[j] != 0 || A.ub[j] <= A.lb[j]) continue;
+                    if (fam == 2 && b < 0 && -A.nu[j] == worst) best = fmin(best, (double)j);
+                    if (fam == 3 && b > 0 && A.nu[j] == worst) best = fmin(best, (double)j);
+                }
+            }
+            best = blk_reduce_min(best, sh);
+            if (best < 1e299) {
+                released = 1;
+                if (threadIdx.x == 0) {
+                    const int64_t e = (int64_t)best;
+                    if (fam == 0) W.rowst[e] = 0;
+                    else if (fam == 1) { W.sst[e] = 1; W.rowst[A.srow[e]] = 1; }
+                    else W.bst[e] = 0;
+                }
+            }
+        }
+        // the feasible point becomes the anchor
+        for (int64_t i = threadIdx.x; i < M; i += 1024) acta[i] = A.act[i];
+        for (int64_t j = threadIdx.x; j < n; j += 1024) pa[j] = A.p[j];
+        for (int64_t k = threadIdx.x; k < ns; k += 1024) sa[k] = A.s[k];
+    }
+    (void)s_val; (void)s_idx;
+    if (threadIdx.x == 0) {
+        A.cnt[AC_NVIOL] = 0;
+        A.cnt[AC_NCHG] = 0;
+        A.cnt[AC_NREL] = released;
+        A.scal[AS_HARDRES] = hres;
+    }
+}
+
+// Dual round tail (oracle: face_dual).  Input: tN = Ah' y.  z = q - Ah'y; sign conditions of the LP dual that y violates
+// become active: the dual working set D shrinks in place (row leaves H / variable joins F / slack becomes basic).
+__global__ __launch_bounds__(1024) void k_face_dual_finish(AsPtrs A, AsSets D, double tol_m) {
+    __shared__ double sh[16];
+    const double td = tol_m * A.scale_q;
+    double nviol = 0.0;
+    for (int64_t j = threadIdx.x; j < A.n; j += 1024) {
+        const double z = A.q[j] - A.tN[j];
+        A.z[j] = z;
+        const int b = D.bst[j];
+        if (b != 0 && A.ub[j] > A.lb[j] && ((b < 0 && z < -td) || (b > 0 && z > td))) { D.bst[j] = 0; nviol += 1.0; }
+    }
+    for (int64_t i = threadIdx.x; i < A.M; i += 1024) {
+        const int rt = A.rtype[i];
+        if (A.hpos[i] >= 0 && rt != 0 && rt * A.y[i] < -td) { D.rowst[i] = 0; nviol += 1.0; }
+    }
+    __syncthreads();
+    for (int64_t k = threadIdx.x; k < A.ns; k += 1024) {
+        const double zs = A.w[k] - A.scoef[k] * A.y[A.srow[k]];
+        if (D.sst[k] == 0 && zs < -td) { D.sst[k] = 1; nviol += 1.0; }
+    }
+    __syncthreads();
+    for (int64_t k = threadIdx.x; k < A.ns; k += 1024)
+        if (D.sst[k] == 1) D.rowst[A.srow[k]] = 1;
+    nviol = blk_reduce_sum(nviol, sh);
+    if (threadIdx.x == 0) A.cnt[AC_NVIOL] = (int)nviol;
+}
+
+// LP optimality measures of a (p, s, y) triple with separate primal / dual working sets (oracle: face_polish tail).
+// Inputs: act (with slacks), z, y, s are current.  pr uses only feasibility; du is measured on the dual working set.
+__global__ __launch_bounds__(1024) void k_face_kkt(AsPtrs A, AsSets D) {
+    __shared__ double sh[16];
+    double pr = 0.0, du = 0.0;
+    for (int64_t i = threadIdx.x; i < A.M; i += 1024) {
+        const int rt = A.rtype[i];
+        const double a = A.act[i];
+        double viol = rt == 0 ? fabs(a - A.r[i]) : fmax(0.0, rt * (A.r[i] - a));
+        pr = fmax(pr, viol / (1.0 + fabs(A.r[i])));
+        const double y = A.y[i];
+        double dr = D.rowst[i] == 0 ? fabs(y) : (rt == 1 ? fmax(-y, 0.0) : (rt == -1 ? fmax(y, 0.0) : 0.0));
+        du = fmax(du, dr);
+    }
+    for (int64_t j = threadIdx.x; j < A.n; j += 1024) {
+        const double pj = A.p[j], z = A.z[j];
+        pr = fmax(pr, fmax(A.lb[j] - pj, 0.0));
+        pr = fmax(pr, fmax(pj - A.ub[j], 0.0));
+        if (A.ub[j] <= A.lb[j]) continue;
+        const int b = D.bst[j];
+        du = fmax(du, b < 0 ? fmax(-z, 0.0) : (b > 0 ? fmax(z, 0.0) : fabs(z)));
+    }
+    for (int64_t k = threadIdx.x; k < A.ns; k += 1024) {
+        pr = fmax(pr, fmax(A.slo[k] - A.s[k], 0.0) / (1.0 + fabs(A.slo[k])));
+        const double zs = A.w[k] - A.scoef[k] * A.y[A.srow[k]];
+        du = fmax(du, D.sst[k] == 0 ? fmax(-zs, 0.0) : fabs(zs));
+    }
+    pr = blk_reduce_max(pr, sh);
+    du = blk_reduce_max(du, sh);
+    if (threadIdx.x == 0) {
+        A.scal[AS_PR] = pr;
+        A.scal[AS_DU] = du / A.scale_q;
+    }
+}
+
+// copy of a working set
+__global__ __launch_bounds__(256) void k_as_copy_sets(AsSets dst, AsSets src, int64_t M, int64_t n, int64_t ns) {
+    int64_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < M) dst.rowst[t] = src.rowst[t];
+    if (t < n) dst.bst[t] = src.bst[t];
+    if (t < ns) dst.sst[t] = src.sst[t];
+}

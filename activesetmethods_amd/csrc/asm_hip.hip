@@ -8,6 +8,7 @@
 // algebra between them runs on the host and exchanges vectors through pinned staging buffers.
 #include "asm_kernels.hip.h"
 #include "asm_ipm_kernels.hip.h"
+#include "asm_as_kernels.hip.h"
 #include "../../include/asm_hip.h"
 
 #include <algorithm>
@@ -40,6 +41,9 @@ const double RED_TAU = 100.0, RED_MIN_FRAC = 0.1;
 const int PCG_MAXIT = 20;       // conjugate-gradient steps per Newton solve (preconditioner = the Cholesky factor)
 const double PCG_KAPPA = 1e-3;  // Newton-system residual tolerance relative to the current primal residual
 const double IPM_RHO_P = 1e-8;   // primal proximal regularisation of the Newton system
+// canonical pair of a non-unique optimum (oracle/lp_solver.py: FACE_*)
+const int FACE_BULK = 6, FACE_STEPS = 80;
+const double FACE_TOL_M = 1e-9;
 
 struct HipError : std::runtime_error {
     explicit HipError(const std::string& s) : std::runtime_error(s) {}
@@ -137,6 +141,10 @@ struct asm_handle {
     double nz_fraction = 1.0;       // executed share of the (tile pair, k-chunk) products of the Schur build
     double* d_ipm = nullptr;        // arena of the device-resident interior-point state
     int* d_ipm_i = nullptr;
+    double* d_as = nullptr;         // arena of the device-resident active-set machinery (asm_as_kernels.hip.h)
+    int* d_as_i = nullptr;
+    int* h_ascnt = nullptr;         // pinned read-back of its counters / scalars
+    double* h_asscal = nullptr;
     int64_t nsp = 0;
     double* h_scal = nullptr;       // pinned scalar read-back
     int* d_idx = nullptr;
@@ -975,190 +983,238 @@ struct Solver {
         }
     }
 
-    // ---------------------------------------------------------------- active-set machinery
-    void identify(ActiveSet& as) {
-        const int64_t n = lp.n, M = lp.M, ns = lp.ns;
-        as.rowst.assign(M, 0); as.bst.assign(n, 0); as.sst.assign(ns, 0);
-        double sq = lp.scale_q;
-        for (int64_t j = 0; j < n; ++j) {
-            if (!ip.free_[j]) { as.bst[j] = -1; continue; }
-            double width = lp.ub[j] - lp.lb[j];
-            if ((ip.tL[j] / width) < (ip.muL[j] / sq)) as.bst[j] = -1;
-            if ((ip.tU[j] / width) < (ip.muU[j] / sq)) as.bst[j] = 1;
-        }
-        for (int64_t i = 0; i < M; ++i) {
-            if (lp.rtype[i] == 0) as.rowst[i] = 1;
-            else as.rowst[i] = ((ip.g[i] / (1.0 + std::fabs(lp.r[i]))) < (ip.pi[i] / sq)) ? 1 : 0;
-        }
-        for (int64_t k = 0; k < ns; ++k) {
-            as.sst[k] = ((ip.ts[k] / (1.0 + std::fabs(lp.slo[k]))) >= (ip.mus[k] / sq)) ? 1 : 0;
-            if (as.sst[k]) as.rowst[lp.srow[k]] = 1;
-        }
-        as.valid = true;
-    }
-
+    // ---------------------------------------------------------------- active-set machinery (device resident)
+    // The working sets, index lists and every O(M+n) vector of the equality-constrained solves live in HBM
+    // (asm_as_kernels.hip.h); the host reads back one block of counters / scalars after the set-up kernel (the size of the
+    // gathered Schur system fixes the launch grids) and one after the tail kernel of a solve.
     struct EqpOut {
         vec p, s, y, act, z;   // act = Ah p + E s ; z = q - Ah' y
     };
+    AsPtrs A;
+    AsSets S_[6];              // 0..2: rotation of the correction loop; 3: partition of the iterate; 4: primal working set; 5: dual
+    double *d_pref = nullptr, *d_zero = nullptr;
+    double *d_p0 = nullptr, *d_s0 = nullptr, *d_y0 = nullptr, *d_act0 = nullptr, *d_z0 = nullptr;      // projection of the iterate
+    double *d_pa = nullptr, *d_sa = nullptr, *d_acta = nullptr;                                          // anchor of the primal method
+    double *d_pf = nullptr, *d_sf = nullptr, *d_actf = nullptr;                                          // least-norm point
+    int final_sets = 0;
+    int as_nH = 0, as_nF = 0;
 
-    // equality-constrained solve on the active set (oracle: eqp)
-    void eqp(const ActiveSet& as, const vec& p_ref, const vec& y_ref, EqpOut& o) {
+    void as_bind() {
+        const int64_t ln = h->ldn, lm = h->Mp, ls = h->nsp;
+        double* a = h->d_as;
+        auto N = [&]() { double* r_ = a; a += ln; return r_; };
+        auto Mv = [&]() { double* r_ = a; a += lm; return r_; };
+        auto Sv = [&]() { double* r_ = a; a += ls; return r_; };
+        A.q = P.q; A.lb = P.lb; A.ub = P.ub; A.r = P.r; A.w = P.w; A.slo = P.slo; A.scoef = P.scoef;
+        A.rtype = P.rtype; A.srow = P.srow; A.rs0 = P.rs0; A.rs1 = P.rs1;
+        A.n = lp.n; A.M = lp.M; A.ns = lp.ns; A.scale_q = lp.scale_q;
+        A.Fmask = N(); A.p = N(); A.z = N(); A.pB = N(); A.pF = N(); A.cF = N(); A.rd = N(); A.tN = N(); A.xfull = N(); A.nu = N();
+        d_pref = N(); d_zero = N(); d_p0 = N(); d_z0 = N(); d_pa = N(); d_pf = N();
+        A.Hmask = Mv(); A.sl = Mv(); A.y = Mv(); A.act = Mv(); A.t = Mv(); A.bH = Mv(); A.v = Mv(); A.u = Mv(); A.yH = Mv();
+        A.yfull = Mv(); A.uacc = Mv(); A.ax = Mv();
+        d_y0 = Mv(); d_act0 = Mv(); d_acta = Mv(); d_actf = Mv();
+        A.s = Sv(); d_s0 = Sv(); d_sa = Sv(); d_sf = Sv();
+        A.scal = a;
+        int* ia = h->d_as_i;
+        auto Ni = [&]() { int* r_ = ia; ia += ln; return r_; };
+        auto Mi = [&]() { int* r_ = ia; ia += lm; return r_; };
+        auto Si = [&]() { int* r_ = ia; ia += ls; return r_; };
+        for (int k = 0; k < 6; ++k) { S_[k].rowst = Mi(); S_[k].bst = Ni(); S_[k].sst = Si(); }
+        A.ksoft = Mi(); A.Hidx = Mi(); A.hpos = Mi(); A.Fidx = Ni(); A.fpos = Ni();
+        A.cnt = ia;
+    }
+    // per LP: reference point of the unique-optimum polish (0 clipped into the box), slack offsets of the rows
+    void as_begin_lp() {
+        as_bind();
+        hipLaunchKernelGGL(k_as_sl, dim3((unsigned)((lp.M + 255) / 256 + 1)), dim3(256), 0, h->stream, A);
+        hipLaunchKernelGGL(k_as_clip0, dim3((unsigned)((lp.n + 255) / 256)), dim3(256), 0, h->stream, A.lb, A.ub, (const double*)nullptr, d_zero, lp.n);
+    }
+    void as_read() {
+        HIPCHK(hipMemcpyAsync(h->h_ascnt, A.cnt, AC_COUNT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(h->h_asscal, A.scal, AS_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    void as_copy_sets(int dst, int src) {
+        hipLaunchKernelGGL(k_as_copy_sets, dim3(grid_all()), dim3(256), 0, h->stream, S_[dst], S_[src], lp.M, lp.n, lp.ns);
+    }
+    void as_upload_sets(const ActiveSet& as, int dst) {
+        std::vector<int> buf((size_t)(lp.M + lp.n + lp.ns));
+        for (int64_t i = 0; i < lp.M; ++i) buf[i] = as.rowst[i];
+        for (int64_t j = 0; j < lp.n; ++j) buf[lp.M + j] = as.bst[j];
+        for (int64_t k = 0; k < lp.ns; ++k) buf[lp.M + lp.n + k] = as.sst[k];
+        if (lp.M) HIPCHK(hipMemcpyAsync(S_[dst].rowst, buf.data(), lp.M * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(S_[dst].bst, buf.data() + lp.M, lp.n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        if (lp.ns) HIPCHK(hipMemcpyAsync(S_[dst].sst, buf.data() + lp.M + lp.n, lp.ns * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    void dcopy(double* dst, const double* src, int64_t cnt) {
+        if (cnt > 0) HIPCHK(hipMemcpyAsync(dst, src, cnt * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    }
+    // final answer of the LP (device -> host): p, s, y, z, act and the working set `final_sets`
+    void as_download(EqpOut& o, ActiveSet& as) {
         const int64_t n = lp.n, M = lp.M, ns = lp.ns;
-        o.p.resize(n); o.s = lp.slo; o.y.assign(M, 0.0);
-        std::vector<char> soft(M, 0);
-        for (int64_t j = 0; j < n; ++j) o.p[j] = as.bst[j] < 0 ? lp.lb[j] : (as.bst[j] > 0 ? lp.ub[j] : p_ref[j]);
-        bool any_soft = false;
-        for (int64_t k = 0; k < ns; ++k)
-            if (as.sst[k] == 1) {
-                int i = lp.srow[k];
-                if (!soft[i]) { soft[i] = 1; o.y[i] = lp.w[k] * lp.scoef[k]; any_soft = true; }
-            }
-        std::vector<int> H;
-        for (int64_t i = 0; i < M; ++i) if (as.rowst[i] == 1 && !soft[i]) H.push_back((int)i);
-        int64_t nF = 0;
-        for (int64_t j = 0; j < n; ++j) nF += as.bst[j] == 0;
-        const int Ms = (int)H.size();
-        if (Ms > 0 && nF > 0) {
-            vec pB(n), t(M), sl(M, 0.0), bH(Ms), cF(n, 0.0), mask(n), tN;
-            for (int64_t j = 0; j < n; ++j) { pB[j] = as.bst[j] == 0 ? 0.0 : o.p[j]; mask[j] = as.bst[j] == 0 ? 1.0 : 0.0; }
-            dev.gemv_n(h->d_Ah, pB.data(), t.data());
-            for (int64_t k = 0; k < ns; ++k) sl[lp.srow[k]] += lp.scoef[k] * lp.slo[k];
-            for (int a = 0; a < Ms; ++a) bH[a] = lp.r[H[a]] - t[H[a]] - sl[H[a]];
-            if (any_soft) {
-                vec ys(M);
-                for (int64_t i = 0; i < M; ++i) ys[i] = soft[i] ? o.y[i] : 0.0;
-                atv(ys, tN);
-                for (int64_t j = 0; j < n; ++j) cF[j] = as.bst[j] == 0 ? lp.q[j] - tN[j] : 0.0;
-            } else {
-                for (int64_t j = 0; j < n; ++j) cF[j] = as.bst[j] == 0 ? lp.q[j] : 0.0;
-            }
-            dev.syrk(H.data(), Ms, mask.data(), nullptr);
-            dev.diag_prepare(Ms, 1, 0.0, 0.0);
-            dev.chol(Ms, 1e-10);
-            vec pF(n), yH(Ms), v(Ms), u(Ms), yfull(M), rd(n);
-            for (int64_t j = 0; j < n; ++j) pF[j] = as.bst[j] == 0 ? p_ref[j] : 0.0;
-            for (int a = 0; a < Ms; ++a) yH[a] = y_ref[H[a]];
-            for (int it = 0; it < 4; ++it) {
-                dev.gemv_n(h->d_Ah, pF.data(), t.data());                       // AHF pF
-                for (int a = 0; a < Ms; ++a) v[a] = bH[a] - t[H[a]];
-                dev.chol_solve(v.data(), u.data(), Ms);
-                std::fill(yfull.begin(), yfull.end(), 0.0);
-                for (int a = 0; a < Ms; ++a) yfull[H[a]] = u[a];
-                atv(yfull, tN);                                                 // AHF' u
-                for (int64_t j = 0; j < n; ++j) if (as.bst[j] == 0) pF[j] += tN[j];
-                std::fill(yfull.begin(), yfull.end(), 0.0);
-                for (int a = 0; a < Ms; ++a) yfull[H[a]] = yH[a];
-                atv(yfull, tN);                                                 // AHF' yH
-                for (int64_t j = 0; j < n; ++j) rd[j] = as.bst[j] == 0 ? cF[j] - tN[j] : 0.0;
-                dev.gemv_n(h->d_Ah, rd.data(), t.data());                       // AHF rd
-                for (int a = 0; a < Ms; ++a) v[a] = t[H[a]];
-                dev.chol_solve(v.data(), u.data(), Ms);
-                for (int a = 0; a < Ms; ++a) yH[a] += u[a];
-            }
-            for (int64_t j = 0; j < n; ++j) if (as.bst[j] == 0) o.p[j] = pF[j];
-            for (int a = 0; a < Ms; ++a) o.y[H[a]] = yH[a];
-        } else if (Ms > 0) {
-            for (int a = 0; a < Ms; ++a) o.y[H[a]] = y_ref[H[a]];
+        down(o.p, A.p, n); down(o.z, A.z, n); down(o.y, A.y, M); down(o.act, A.act, M); down(o.s, A.s, ns);
+        std::vector<int> buf((size_t)(M + n + ns));
+        if (M) HIPCHK(hipMemcpyAsync(buf.data(), S_[final_sets].rowst, M * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(buf.data() + M, S_[final_sets].bst, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        if (ns) HIPCHK(hipMemcpyAsync(buf.data() + M + n, S_[final_sets].sst, ns * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        as.rowst.resize(M); as.bst.resize(n); as.sst.resize(ns);
+        for (int64_t i = 0; i < M; ++i) as.rowst[i] = (int8_t)buf[i];
+        for (int64_t j = 0; j < n; ++j) as.bst[j] = (int8_t)buf[M + j];
+        for (int64_t k = 0; k < ns; ++k) as.sst[k] = (int8_t)buf[M + n + k];
+        as.valid = true;
+    }
+    void identify_dev(int dst) {
+        hipLaunchKernelGGL(k_as_identify, dim3(grid_all()), dim3(256), 0, h->stream, P, S_[dst]);
+    }
+
+    // Equality-constrained solve on the working set `cur` (oracle: eqp / _face_primal_solve / face_dual's solve).
+    //   mode 0: both projections from (p_ref, y_ref), 4 refinement sweeps              (eqp)
+    //   mode 1: primal least-norm point only (p_ref = 0), 3 sweeps, the multipliers of that problem accumulated in uacc
+    //   mode 2: basic least-squares multipliers only (y_ref = 0), 4 sweeps
+    // Leaves t = Ah p and tN = Ah' y (mode 1: tN = Ah' u_full) for the tail kernel.
+    void as_solve(const AsSets& cur, const double* p_ref, const double* y_ref, int mode) {
+        const unsigned gA = grid_all(), gM = (unsigned)((lp.M + 255) / 256 + 1), gN = (unsigned)((lp.n + 255) / 256);
+        hipLaunchKernelGGL(k_as_setup, dim3(1), dim3(1024), 0, h->stream, A, cur, p_ref, h->ldn, h->Mp);
+        HIPCHK(hipMemcpyAsync(h->h_ascnt, A.cnt, AC_COUNT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        const int nH = h->h_ascnt[AC_NH], nF = h->h_ascnt[AC_NF];
+        const bool any_soft = h->h_ascnt[AC_ANYSOFT] != 0;
+        as_nH = nH; as_nF = nF;
+        if (nH > 0) {
+            dev.gemv_n_dev(h->d_Ah, A.pB, A.t);
+            if (any_soft) dev.gemv_t_dev(h->d_Ah, A.y, A.tN);
+            hipLaunchKernelGGL(k_as_rhs, dim3(gA), dim3(256), 0, h->stream, A, y_ref);
         }
-        // basic slack values from their tight row, then the final activities / reduced costs
-        rowact(o.p, o.s, o.act);
-        bool chg = false;
-        std::vector<char> done(M, 0);
-        for (int64_t k = 0; k < ns; ++k)
-            if (as.sst[k] == 1) {
-                int i = lp.srow[k];
-                if (!done[i]) {
-                    done[i] = 1;
-                    double snew = lp.slo[k] + (lp.r[i] - o.act[i]) / lp.scoef[k];
-                    o.act[i] += lp.scoef[k] * (snew - o.s[k]);
-                    o.s[k] = snew;
-                    chg = true;
+        if (nH > 0 && nF > 0) {
+            dev.syrk_gathered_dev(A.Hidx, nH, A.Fmask, nullptr);
+            dev.diag_prepare(nH, 1, 0.0, 0.0);
+            dev.chol(nH, 1e-10);
+            const int sweeps = mode == 1 ? 3 : 4;
+            const unsigned gH = (unsigned)((nH + 255) / 256);
+            for (int it = 0; it < sweeps; ++it) {
+                if (mode != 2) {
+                    dev.gemv_n_dev(h->d_Ah, A.pF, A.t);                                                  // A_HF pF
+                    hipLaunchKernelGGL(k_as_res_p, dim3(gH), dim3(256), 0, h->stream, A);
+                    dev.chol_solve_dev(A.v, A.u, nH);
+                    hipLaunchKernelGGL(k_as_scatter_h, dim3(gM), dim3(256), 0, h->stream, A, (const double*)A.u, mode == 1 ? 1 : 0);
+                    dev.gemv_t_dev(h->d_Ah, A.yfull, A.tN);                                              // A_HF' u
+                    hipLaunchKernelGGL(k_as_add_f, dim3(gN), dim3(256), 0, h->stream, A);
+                }
+                if (mode != 1) {
+                    hipLaunchKernelGGL(k_as_scatter_h, dim3(gM), dim3(256), 0, h->stream, A, (const double*)A.yH, 0);
+                    dev.gemv_t_dev(h->d_Ah, A.yfull, A.tN);                                              // A_HF' yH
+                    hipLaunchKernelGGL(k_as_rd, dim3(gN), dim3(256), 0, h->stream, A);
+                    dev.gemv_n_dev(h->d_Ah, A.rd, A.t);                                                  // A_HF rd
+                    hipLaunchKernelGGL(k_as_gather_h, dim3(gH), dim3(256), 0, h->stream, A);
+                    dev.chol_solve_dev(A.v, A.u, nH);
+                    hipLaunchKernelGGL(k_as_add_yh, dim3(gH), dim3(256), 0, h->stream, A);
                 }
             }
-        (void)chg;
-        vec aty;
-        atv(o.y, aty);
-        o.z.resize(n);
-        for (int64_t j = 0; j < n; ++j) o.z[j] = lp.q[j] - aty[j];
+        }
+        if (nH > 0) hipLaunchKernelGGL(k_as_merge, dim3(gA), dim3(256), 0, h->stream, A, mode != 1 ? 1 : 0);
+        dev.gemv_n_dev(h->d_Ah, A.p, A.t);
+        if (mode == 1) {
+            hipLaunchKernelGGL(k_as_scatter_h, dim3(gM), dim3(256), 0, h->stream, A, (const double*)A.uacc, 0);
+            dev.gemv_t_dev(h->d_Ah, A.yfull, A.tN);
+        } else {
+            dev.gemv_t_dev(h->d_Ah, A.y, A.tN);
+        }
         h->stats.eqp += 1;
     }
 
-    void kkt_measures(const ActiveSet& as, const EqpOut& o, double& pr, double& du) {
-        const int64_t n = lp.n, M = lp.M, ns = lp.ns;
-        pr = 0.0; du = 0.0;
-        for (int64_t i = 0; i < M; ++i) {
-            double viol = lp.rtype[i] == 0 ? std::fabs(o.act[i] - lp.r[i]) : std::max(0.0, lp.rtype[i] * (lp.r[i] - o.act[i]));
-            pr = std::max(pr, viol / (1.0 + std::fabs(lp.r[i])));
-            double y = o.y[i], dr;
-            if (as.rowst[i] == 0) dr = std::fabs(y);
-            else dr = lp.rtype[i] == 1 ? std::max(-y, 0.0) : (lp.rtype[i] == -1 ? std::max(y, 0.0) : 0.0);
-            du = std::max(du, dr);
-        }
-        for (int64_t j = 0; j < n; ++j) {
-            pr = std::max(pr, std::max(lp.lb[j] - o.p[j], 0.0));
-            pr = std::max(pr, std::max(o.p[j] - lp.ub[j], 0.0));
-            if (lp.ub[j] <= lp.lb[j]) continue;
-            double z = o.z[j];
-            double dz = as.bst[j] < 0 ? std::max(-z, 0.0) : (as.bst[j] > 0 ? std::max(z, 0.0) : std::fabs(z));
-            du = std::max(du, dz);
-        }
-        for (int64_t k = 0; k < ns; ++k) {
-            pr = std::max(pr, std::max(lp.slo[k] - o.s[k], 0.0) / (1.0 + std::fabs(lp.slo[k])));
-            double zs = lp.w[k] - lp.scoef[k] * o.y[lp.srow[k]];
-            du = std::max(du, as.sst[k] == 0 ? std::max(-zs, 0.0) : std::fabs(zs));
-        }
-        du /= lp.scale_q;
-    }
-
-    int64_t correct(const ActiveSet& as, const EqpOut& o, ActiveSet& nx) {
-        const int64_t n = lp.n, M = lp.M, ns = lp.ns;
-        nx = as;
-        double td = TOL_D * lp.scale_q;
-        int64_t nchg = 0;
-        for (int64_t i = 0; i < M; ++i) {
-            if (lp.rtype[i] == 0) continue;
-            double viol = lp.rtype[i] * (lp.r[i] - o.act[i]) / (1.0 + std::fabs(lp.r[i]));
-            if (as.rowst[i] == 1 && lp.rtype[i] * o.y[i] < -td) { nx.rowst[i] = 0; ++nchg; }
-            else if (as.rowst[i] == 0 && viol > TOL_P) { nx.rowst[i] = 1; ++nchg; }
-        }
-        for (int64_t j = 0; j < n; ++j) {
-            bool fixed = lp.ub[j] <= lp.lb[j];
-            double z = o.z[j];
-            if (!fixed && ((as.bst[j] < 0 && z < -td) || (as.bst[j] > 0 && z > td))) { nx.bst[j] = 0; ++nchg; }
-            else if (as.bst[j] == 0 && o.p[j] < lp.lb[j] - TOL_P) { nx.bst[j] = -1; ++nchg; }
-            else if (as.bst[j] == 0 && o.p[j] > lp.ub[j] + TOL_P) { nx.bst[j] = 1; ++nchg; }
-        }
-        for (int64_t k = 0; k < ns; ++k) {
-            double zs = lp.w[k] - lp.scoef[k] * o.y[lp.srow[k]];
-            if (as.sst[k] == 0 && zs < -td) { nx.sst[k] = 1; ++nchg; }
-            else if (as.sst[k] == 1 && o.s[k] < lp.slo[k] - TOL_P * (1.0 + std::fabs(lp.slo[k]))) { nx.sst[k] = 0; ++nchg; }
-        }
-        for (int64_t k = 0; k < ns; ++k) if (nx.sst[k] == 1) nx.rowst[lp.srow[k]] = 1;
-        return nchg;
-    }
-
-    static bool same(const ActiveSet& a, const ActiveSet& b) { return a.rowst == b.rowst && a.bst == b.bst && a.sst == b.sst; }
-
-    bool eqp_loop(ActiveSet as, const vec& p_ref, const vec& y_ref, int rounds, EqpOut& o, ActiveSet& out_as) {
-        ActiveSet prev;
+    // oracle: eqp_loop - solve, LP optimality test, bulk correction of the working set, at most `rounds` corrections.
+    // Starts from the sets in S_[0]; on return `final_sets` is the buffer holding the last working set.
+    bool eqp_loop(const double* p_ref, const double* y_ref, int rounds) {
+        int cur = 0, nx = 1, prev = 2;
         bool have_prev = false;
         for (int k = 0; k <= rounds; ++k) {
-            eqp(as, p_ref, y_ref, o);
-            double pr, du;
-            kkt_measures(as, o, pr, du);
+            as_solve(S_[cur], p_ref, y_ref, 0);
+            hipLaunchKernelGGL(k_as_finish, dim3(1), dim3(1024), 0, h->stream, A, S_[cur], S_[nx], S_[prev], have_prev ? 1 : 0, TOL_P, TOL_D);
+            as_read();
+            const double pr = h->h_asscal[AS_PR], du = h->h_asscal[AS_DU];
             h->stats.kkt_pr = pr;
             h->stats.kkt_du = du;
-            if (pr <= TOL_P && du <= TOL_D) { out_as = as; return true; }
+            final_sets = cur;
+            if (pr <= TOL_P && du <= TOL_D) return true;
             if (k == rounds) break;
-            ActiveSet nx;
-            int64_t nchg = correct(as, o, nx);
-            if (nchg == 0 || (have_prev && same(nx, prev))) break;
-            prev = as; have_prev = true;
-            as = nx;
+            if (h->h_ascnt[AC_NCHG] == 0 || (have_prev && h->h_ascnt[AC_NDIFF] == 0)) break;
+            const int old_prev = prev;
+            prev = cur; cur = nx; nx = old_prev;
+            have_prev = true;
+            final_sets = cur;
         }
-        out_as = as;
         return false;
     }
+
+    // oracle: face_polish - canonical pair of a non-unique optimum on the partition in S_[3].
+    // Returns 2 ('face': least-norm point + basic multipliers), 1 ('ref': projection of the iterate), 0 (partition not optimal).
+    int face_polish() {
+        const int64_t n = lp.n, M = lp.M, ns = lp.ns;
+        hipLaunchKernelGGL(k_as_clip0, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, A.lb, A.ub, (const double*)P.p, d_pref, n);
+        as_solve(S_[3], d_pref, P.y, 0);
+        hipLaunchKernelGGL(k_as_finish, dim3(1), dim3(1024), 0, h->stream, A, S_[3], S_[1], S_[2], 0, TOL_P, TOL_D);
+        as_read();
+        h->stats.kkt_pr = h->h_asscal[AS_PR];
+        h->stats.kkt_du = h->h_asscal[AS_DU];
+        if (!(h->h_asscal[AS_PR] <= TOL_P && h->h_asscal[AS_DU] <= TOL_D)) return 0;
+        dcopy(d_p0, A.p, n); dcopy(d_s0, A.s, ns); dcopy(d_y0, A.y, M); dcopy(d_act0, A.act, M); dcopy(d_z0, A.z, n);
+        // ---- primal: bulk rounds
+        bool okp = false;
+        as_copy_sets(4, 3);
+        for (int r = 0; r < FACE_BULK; ++r) {
+            as_solve(S_[4], nullptr, nullptr, 1);
+            hipLaunchKernelGGL(k_face_primal_finish, dim3(1), dim3(1024), 0, h->stream, A, S_[4], S_[3], TOL_P, FACE_TOL_M);
+            as_read();
+            if (h->verbose) std::fprintf(stderr, "[asm] face primal bulk %d: nH %d nF %d viol %d rel %d hres %.2e\n", r, as_nH, as_nF, h->h_ascnt[AC_NVIOL], h->h_ascnt[AC_NREL], h->h_asscal[AS_HARDRES]);
+            if (h->h_asscal[AS_HARDRES] > TOL_P) break;            // over-determined working set
+            if (h->h_ascnt[AC_NVIOL] > 0) continue;
+            if (h->h_ascnt[AC_NREL] == 0) { okp = true; break; }
+        }
+        // ---- primal: anchored method from the projection of the iterate
+        if (!okp) {
+            as_copy_sets(4, 3);
+            dcopy(d_pa, d_p0, n); dcopy(d_sa, d_s0, ns); dcopy(d_acta, d_act0, M);
+            for (int st = 0; st < FACE_STEPS; ++st) {
+                as_solve(S_[4], nullptr, nullptr, 1);
+                hipLaunchKernelGGL(k_face_anchor_step, dim3(1), dim3(1024), 0, h->stream, A, S_[4], S_[3], d_pa, d_sa, d_acta, TOL_P, FACE_TOL_M);
+                as_read();
+                if (h->verbose) std::fprintf(stderr, "[asm] face primal anchored %d: nH %d nF %d viol %d added %d released %d hres %.2e\n", st, as_nH, as_nF, h->h_ascnt[AC_NVIOL], h->h_ascnt[AC_NCHG], h->h_ascnt[AC_NREL], h->h_asscal[AS_HARDRES]);
+                if (h->h_asscal[AS_HARDRES] > TOL_P) break;
+                if (h->h_ascnt[AC_NVIOL] > 0) {
+                    if (h->h_ascnt[AC_NCHG] == 0) break;           // nothing blocks: numerical trouble
+                    continue;
+                }
+                if (h->h_ascnt[AC_NREL] == 0) { okp = true; break; }
+            }
+        }
+        bool okd = false;
+        if (okp) {
+            dcopy(d_pf, A.p, n); dcopy(d_sf, A.s, ns); dcopy(d_actf, A.act, M);
+            as_copy_sets(5, 3);
+            for (int r = 0; r < FACE_BULK; ++r) {
+                as_solve(S_[5], nullptr, nullptr, 2);
+                hipLaunchKernelGGL(k_face_dual_finish, dim3(1), dim3(1024), 0, h->stream, A, S_[5], FACE_TOL_M);
+                as_read();
+                if (h->verbose) std::fprintf(stderr, "[asm] face dual %d: nH %d nF %d viol %d\n", r, as_nH, as_nF, h->h_ascnt[AC_NVIOL]);
+                if (h->h_ascnt[AC_NVIOL] == 0) { okd = true; break; }
+            }
+        }
+        if (okp && okd) {
+            dcopy(A.p, d_pf, n); dcopy(A.s, d_sf, ns); dcopy(A.act, d_actf, M);
+            hipLaunchKernelGGL(k_face_kkt, dim3(1), dim3(1024), 0, h->stream, A, S_[5]);
+            as_read();
+            h->stats.kkt_pr = h->h_asscal[AS_PR];
+            h->stats.kkt_du = h->h_asscal[AS_DU];
+            if (h->verbose) std::fprintf(stderr, "[asm] face kkt pr %.2e du %.2e\n", h->h_asscal[AS_PR], h->h_asscal[AS_DU]);
+            if (h->h_asscal[AS_PR] <= TOL_P && h->h_asscal[AS_DU] <= TOL_D) { final_sets = 4; return 2; }
+        }
+        dcopy(A.p, d_p0, n); dcopy(A.s, d_s0, ns); dcopy(A.y, d_y0, M); dcopy(A.act, d_act0, M); dcopy(A.z, d_z0, n);
+        final_sets = 3;
+        return 1;
+    }
+
 
     // oracle: phase1_infeasible - elastic LP over the same rows/box; its optimal multipliers are a Farkas
     // certificate of the original LP, verified rigorously before INFEASIBLE is reported.
@@ -1186,24 +1242,25 @@ struct Solver {
     // oracle: solve_scaled
     double t_warm = 0, t_ipm = 0, t_polish = 0;
     static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-    int solve_scaled(const ActiveSet* warm, SolveHint& hint, EqpOut& o, ActiveSet& out_as) {
-        int st = solve_scaled_impl(warm, hint, o, out_as);
-        if (h->verbose) std::fprintf(stderr, "[asm] phases: warm %.2f ms, ipm %.2f ms (%d its), polish %.2f ms\n", t_warm, t_ipm, ip.iters, t_polish);
+    int solve_scaled(const ActiveSet* warm, SolveHint& hint) {
+        int st = solve_scaled_impl(warm, hint);
+        if (h->verbose) std::fprintf(stderr, "[asm] phases: warm %.2f ms, ipm %.2f ms (%d its), polish %.2f ms, path %d\n", t_warm, t_ipm, ip.iters, t_polish, h->stats.path);
         return st;
     }
-    int solve_scaled_impl(const ActiveSet* warm, SolveHint& hint, EqpOut& o, ActiveSet& out_as) {
+    int solve_scaled_impl(const ActiveSet* warm, SolveHint& hint) {
         const int64_t n = lp.n, M = lp.M, ns = lp.ns;
-        vec zero_p(n), zero_y(M, 0.0);
-        for (int64_t j = 0; j < n; ++j) zero_p[j] = std::min(std::max(0.0, lp.lb[j]), lp.ub[j]);
         h->stats.path = -1;
         h->stats.polished = 1;
+        ipm_upload_lp();
+        as_begin_lp();
         if (warm && warm->valid && (int64_t)warm->rowst.size() == M && (int64_t)warm->bst.size() == n && (int64_t)warm->sst.size() == ns) {
             // attempt when the last two LPs ended on the same sets or the back-off has run out (oracle: solve_scaled)
             if (!hint.stable && hint.warm_skip > 0) {
                 hint.warm_skip -= 1;
             } else {
                 double t0 = now_ms();
-                bool okw = eqp_loop(*warm, zero_p, zero_y, 1, o, out_as);
+                as_upload_sets(*warm, 0);
+                bool okw = eqp_loop(d_zero, nullptr, 1);
                 t_warm += now_ms() - t0;
                 if (okw) { hint.warm_fail = 0; hint.warm_skip = 0; h->stats.path = 0; return ASM_OPTIMAL; }
                 hint.warm_fail = std::min(hint.warm_fail + 1, 3);
@@ -1215,7 +1272,6 @@ struct Solver {
         ipm_init();
         const double tols[3] = {1e-8, 1e-10, 1e-12};
         const int more[3] = {IPM_MAXIT, 6, 6};
-        ActiveSet sets0;
         bool have_sets = false;
         for (int stage = 0; stage < 3; ++stage) {
             double t0 = now_ms();
@@ -1229,50 +1285,48 @@ struct Solver {
                 // the IPM is only the identifier: a jammed / slow run that is already close is still handed to
                 // the active-set solve, whose LP optimality test decides (oracle: solve_scaled)
                 if (ip.pinf <= 1e-3 && ip.dinf <= 1e-3 && ip.gap <= 1e-4) {
-                    ipm_download();
-                    identify(sets0);
+                    identify_dev(3);
                     have_sets = true;
-                    if (eqp_loop(sets0, zero_p, zero_y, 3, o, out_as)) { h->stats.path = 8; return ASM_OPTIMAL; }
+                    as_copy_sets(0, 3);
+                    if (eqp_loop(d_zero, nullptr, 3)) { h->stats.path = 8; return ASM_OPTIMAL; }
                 }
                 if (lp.ns == 0 && phase1_infeasible()) { h->stats.path = 7; return ASM_INFEASIBLE; }
                 break;
             }
             if (prefer_ref && stage + 1 < 3) continue;      // straight on to the last stage
             double t1 = now_ms();
-            ipm_download();
-            identify(sets0);
+            identify_dev(3);
             have_sets = true;
             if (prefer_ref) break;
-            bool okp = eqp_loop(sets0, zero_p, zero_y, 2, o, out_as);
+            as_copy_sets(0, 3);
+            bool okp = eqp_loop(d_zero, nullptr, 2);
             t_polish += now_ms() - t1;
             if (okp) { h->stats.path = 1 + stage; return ASM_OPTIMAL; }
         }
         if (have_sets) {
             double t1 = now_ms();
-            vec pc(n);
-            for (int64_t j = 0; j < n; ++j) pc[j] = std::min(std::max(ip.p[j], lp.lb[j]), lp.ub[j]);
-            bool okr = eqp_loop(sets0, pc, ip.y, 2, o, out_as);
+            // non-unique optimum: canonical (least-norm) pair of the optimal faces the partition describes (oracle: face_polish)
+            const int how = face_polish();
             t_polish += now_ms() - t1;
-            if (okr) { hint.prefer_ref = true; h->stats.path = 4; return ASM_OPTIMAL; }
+            if (how == 2) { hint.prefer_ref = true; h->stats.path = 4; return ASM_OPTIMAL; }
+            if (how == 1) { hint.prefer_ref = true; h->stats.path = 9; return ASM_OPTIMAL; }
+            // the partition is not optimal as it stands: bulk corrections from the iterate's projection
+            as_copy_sets(0, 3);
+            bool okr = eqp_loop(d_pref, P.y, 2);
+            if (okr) { hint.prefer_ref = true; h->stats.path = 9; return ASM_OPTIMAL; }
             hint.prefer_ref = false;
             if (prefer_ref) {                               // the least-norm polish has not been tried on this LP yet
-                if (eqp_loop(sets0, zero_p, zero_y, 2, o, out_as)) { h->stats.path = 3; return ASM_OPTIMAL; }
+                as_copy_sets(0, 3);
+                if (eqp_loop(d_zero, nullptr, 2)) { h->stats.path = 3; return ASM_OPTIMAL; }
             }
         }
+        // no active-set solve passed the LP optimality test: the interior iterate is not returned as a solution
+        // (status OTHER; the SLP caller stops with a warning, slp_line_search.jl:127-133)
         h->stats.path = 5;
         h->stats.polished = 0;
-        ipm_download();
-        if (!have_sets) identify(sets0);
-        out_as = sets0;
-        o.p.resize(n); o.s.resize(ns); o.y = ip.y;
-        for (int64_t j = 0; j < n; ++j) o.p[j] = std::min(std::max(ip.p[j], lp.lb[j]), lp.ub[j]);
-        for (int64_t k = 0; k < ns; ++k) o.s[k] = std::max(ip.s[k], lp.slo[k]);
-        vec aty;
-        atv(o.y, aty);
-        o.z.resize(n);
-        for (int64_t j = 0; j < n; ++j) o.z[j] = lp.q[j] - aty[j];
-        return std::max(std::max(ip.pinf, ip.dinf), ip.gap) <= 1e-6 ? ASM_OPTIMAL : ASM_OTHER;
+        return ASM_OTHER;
     }
+
 };
 
 // =====================================================================================================
@@ -1306,6 +1360,10 @@ void free_device(asm_handle* h) {
     h->sp_ok = h->spv_Ah_valid = h->spv_J_valid = false; h->sp_nnz = 0;
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     h->d_ipm = nullptr; h->d_ipm_i = nullptr; h->h_scal = nullptr;
+    F(h->d_as); F(h->d_as_i);
+    if (h->h_ascnt) (void)hipHostFree(h->h_ascnt);
+    if (h->h_asscal) (void)hipHostFree(h->h_asscal);
+    h->d_as = nullptr; h->d_as_i = nullptr; h->h_ascnt = nullptr; h->h_asscal = nullptr;
     if (h->h_pin) (void)hipHostFree(h->h_pin);
     h->d_perm = h->d_ustart = h->d_uoff = h->d_adjoff = nullptr;
     h->d_dE = h->d_J = h->d_Ah = h->d_S = h->d_c = h->d_rho = h->d_theta = h->d_diag = h->d_diag0 = nullptr;
@@ -1481,6 +1539,13 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
         }
         HIPCHK(hipMemcpy(h->d_ipm_i, iv.data(), iv.size() * sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(hipHostMalloc((void**)&h->h_scal, 64 * sizeof(double)));
+        const int64_t nas = 16 * h->ldn + 16 * h->Mp + 4 * h->nsp + 64, nasi = 6 * (h->Mp + h->ldn + h->nsp) + 3 * h->Mp + 2 * h->ldn + 64;
+        dmalloc(&h->d_as, nas);
+        HIPCHK(hipMemsetAsync(h->d_as, 0, nas * sizeof(double), h->stream));
+        dmalloc(&h->d_as_i, nasi);
+        HIPCHK(hipMemsetAsync(h->d_as_i, 0, nasi * sizeof(int), h->stream));
+        HIPCHK(hipHostMalloc((void**)&h->h_ascnt, 64 * sizeof(int)));
+        HIPCHK(hipHostMalloc((void**)&h->h_asscal, 64 * sizeof(double)));
     }
     h->pin_len = std::max(std::max(h->ldn, h->Mp), h->nsp);
     HIPCHK(hipHostMalloc((void**)&h->h_pin, 2 * h->pin_len * sizeof(double)));
@@ -1583,15 +1648,16 @@ void do_solve(asm_handle* h, double delta, int feasibility, double* p_out, doubl
 
     Solver::EqpOut o;
     ActiveSet as;
-    int st = sv.solve_scaled(&h->warm[fr ? 1 : 0], h->hint[fr ? 1 : 0], o, as);
+    int st = sv.solve_scaled(&h->warm[fr ? 1 : 0], h->hint[fr ? 1 : 0]);
     *status = st;
+    if (st == ASM_OPTIMAL) sv.as_download(o, as);
 
     for (int64_t j = 0; j < n; ++j) { p_out[j] = 0.0; mult_x_U[j] = 0.0; mult_x_L[j] = 0.0; }
     for (int64_t i = 0; i < m; ++i) { lambda[i] = 0.0; p_slack[2 * i] = 0.0; p_slack[2 * i + 1] = h->nslack[i] == 2 ? 0.0 : std::nan(""); }
     if (st == ASM_OPTIMAL) {
         {
             const ActiveSet& prev = h->warm[fr ? 1 : 0];
-            h->hint[fr ? 1 : 0].stable = prev.valid && Solver::same(prev, as);
+            h->hint[fr ? 1 : 0].stable = prev.valid && prev.rowst == as.rowst && prev.bst == as.bst && prev.sst == as.sst;
         }
         h->warm[fr ? 1 : 0] = as;
         h->last = as;

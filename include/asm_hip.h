@@ -82,7 +82,9 @@ int asm_sublp_reset_warm(asm_handle* h);
 
 /* Statistics of the last solve / accumulated device-kernel timing. */
 typedef struct {
-    int32_t path;          /* 0 warm, 1 ipm stage0+polish, 2 stage1, 3 stage2, 4 ipm+ref, 5 unpolished, 6 infeasible (IPM duals), 7 infeasible (phase-1 duals), 8 jammed ipm + polish */
+    int32_t path;          /* 0 warm, 1 ipm stage0+polish, 2 stage1, 3 stage2, 4 ipm+face (non-unique optimum: least-norm point of the optimal
+                            * face + basic multipliers), 5 unpolished (status OTHER), 6 infeasible (IPM duals), 7 infeasible (phase-1 duals),
+                            * 8 jammed ipm + polish, 9 ipm+ref (non-unique optimum, projection of the iterate: fallback of 4) */
     int32_t polished;
     int32_t ipm_iters;
     int32_t nfact;         /* Cholesky factorisations */

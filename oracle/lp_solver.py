@@ -587,6 +587,258 @@ def eqp_loop(lp, sets, p_ref, y_ref, rounds, stats):
     return False, p, s, y, sets
 
 
+# ----------------------------------------------------------------------------- canonical point of a non-unique optimum
+# An LP whose optimum is not unique (almost every restoration LP `min sum of slacks`) has a whole face of optimal points
+# and, when the optimal point is degenerate, a whole face of optimal multipliers.  A simplex code returns some vertex of
+# each; which one is an artefact of its pivoting rules.  This solver returns the LEAST-NORM point of each face (scaled
+# units): the solution of a strictly convex problem, hence unique - independent of the interior-point iterate that
+# identified the faces and of the order in which an implementation builds its working set.
+FACE_BULK = 6        # bulk rounds (all violated constraints join at once) before the anchored method takes over
+FACE_STEPS = 80      # anchored feasible-direction steps (each adds the blocking constraint of a ratio test)
+FACE_TOL_M = 1e-9    # sign tolerance of the least-norm problems' own multipliers (scaled units)
+
+
+def _soft_rows(lp, sst):
+    """Rows that carry a basic slack (the first one per row counts, as in `eqp`), their known multiplier, that slack."""
+    soft = np.zeros(lp.M, bool)
+    ysoft = np.zeros(lp.M)
+    ksoft = np.full(lp.M, -1, np.int64)
+    for k in np.nonzero(sst == 1)[0]:
+        i = lp.srow[k]
+        if not soft[i]:
+            soft[i] = True
+            ysoft[i] = lp.w[k] * lp.scoef[k]
+            ksoft[i] = k
+    return soft, ysoft, ksoft
+
+
+def _face_primal_solve(lp, W, sl, stats):
+    """Least-norm point of the affine hull of the working set W = (rowst, bst, sst): p = A_HF'(A_HF A_HF')^-1 b_H with three
+    refinement sweeps, basic slacks from their rows.  Returns p, s, act, the multipliers of this problem (u on the hard rows,
+    nu = p - A'u on the bounds), the hard-row mask and the largest hard-row residual (non-zero = W is over-determined)."""
+    rowst, bst, sst = W
+    A, M = lp.A, lp.M
+    F = np.nonzero(bst == 0)[0]
+    p = np.where(bst < 0, lp.lb, np.where(bst > 0, lp.ub, 0.0))
+    s = lp.slo.copy()
+    soft, _, ksoft = _soft_rows(lp, sst)
+    hard = (rowst == 1) & ~soft
+    H = np.nonzero(hard)[0]
+    u = np.zeros(M)
+    if len(H) > 0 and len(F) > 0:
+        AHF = A[np.ix_(H, F)]
+        bH = lp.r[H] - A[H] @ p - sl[H]
+        S = AHF @ AHF.T
+        idx = np.arange(len(H))
+        Lc = chol_guard(S, S[idx, idx].copy(), 1e-10)
+        stats['nfact'] += 1
+        pF = np.zeros(len(F))
+        uH = np.zeros(len(H))
+        for _r in range(3):
+            du = chol_solve(Lc, bH - AHF @ pF)
+            uH += du
+            pF = pF + AHF.T @ du
+        p[F] = pF
+        u[H] = uH
+    stats['eqp'] += 1
+    act = lp.A @ p + sl
+    isoft = np.nonzero(soft)[0]
+    ks = ksoft[isoft]
+    s[ks] = lp.slo[ks] + (lp.r[isoft] - act[isoft]) / lp.scoef[ks]
+    act[isoft] = lp.r[isoft]
+    nu = p - A.T @ u
+    rden = 1.0 + np.abs(lp.r)
+    hres = float((np.abs(act - lp.r)[hard] / rden[hard]).max(initial=0.0))
+    return p, s, act, u, nu, hard, hres
+
+
+def _primal_margins(lp, W, p, s, act):
+    """Signed margins (>= 0 feasible) of the face's inequalities that are NOT in the working set W."""
+    rowst, bst, sst = W
+    rden = 1.0 + np.abs(lp.r)
+    g_row = np.where((lp.rtype != 0) & (rowst == 0), lp.rtype * (act - lp.r) / rden, np.inf)
+    g_lo = np.where(bst == 0, p - lp.lb, np.inf)
+    g_up = np.where(bst == 0, lp.ub - p, np.inf)
+    g_s = np.where(sst == 1, (s - lp.slo) / (1.0 + np.abs(lp.slo)), np.inf)
+    return g_row, g_lo, g_up, g_s
+
+
+def face_primal(lp, part, anchor, stats):
+    """Least-norm point of the primal optimal face described by the strict-complementarity partition `part` (the constraints
+    it calls active hold on the whole face - "mandatory" -, every other constraint of the LP is an inequality of the face):
+        min 1/2 |p|^2   s.t.  (p, s) in the face.
+    Active-set method on the working set W (starts at the mandatory set); a solve is the Schur solve of `eqp` with p_ref = 0.
+      bulk rounds  : every violated inequality joins W at once; once feasible, non-mandatory members whose multiplier of THIS
+                     problem has the wrong sign leave.  Fast when the face is large; a bulk add can over-determine W (the hard
+                     rows then no longer hold) - then, or after FACE_BULK rounds,
+      anchored     : the classical primal method from the feasible `anchor` = (p, s) (the projection of the interior-point
+                     iterate onto the mandatory set): step towards the least-norm point of aff(W) until the first inequality
+                     blocks, add it, repeat; at a feasible least-norm point release the most wrong-signed member.  Every W it
+                     visits is consistent by construction and the face dimension drops with every step.
+    Whatever the route, the point returned satisfies the optimality conditions of the strictly convex problem, so it is THE
+    least-norm point.  Returns (ok, p, s, working set)."""
+    man_row, man_b, man_s0 = part[0] == 1, part[1], part[2] == 0
+    M, ns = lp.M, lp.ns
+    ineq = lp.rtype != 0
+    fixed = lp.ub <= lp.lb
+    sl = np.zeros(M)
+    if ns:
+        np.add.at(sl, lp.srow, lp.scoef * lp.slo)
+
+    def wrong_signs(W, u, nu, hard):
+        rowst, bst, sst = W
+        r_row = np.where(hard & ~man_row & ineq, np.maximum(-lp.rtype * u, 0.0), 0.0)
+        r_s = np.where((sst == 0) & ~man_s0 & hard[lp.srow], np.maximum(lp.scoef * u[lp.srow], 0.0), 0.0) if ns else np.zeros(0)
+        r_lo = np.where((bst < 0) & (man_b == 0) & ~fixed, np.maximum(-nu, 0.0), 0.0)
+        r_up = np.where((bst > 0) & (man_b == 0) & ~fixed, np.maximum(nu, 0.0), 0.0)
+        return r_row, r_s, r_lo, r_up
+
+    # ---- bulk rounds
+    W = tuple(a.copy() for a in part)
+    for _ in range(FACE_BULK):
+        p, s, act, u, nu, hard, hres = _face_primal_solve(lp, W, sl, stats)
+        if hres > TOL_P:
+            break                                         # over-determined working set
+        rowst, bst, sst = W
+        g_row, g_lo, g_up, g_s = _primal_margins(lp, W, p, s, act)
+        v_row, v_lo, v_up, v_s = g_row < -TOL_P, g_lo < -TOL_P, g_up < -TOL_P, g_s < -TOL_P
+        if v_row.any() or v_lo.any() or v_up.any() or v_s.any():
+            rowst[v_row] = 1
+            bst[v_lo] = -1
+            bst[v_up] = 1
+            sst[v_s] = 0
+            continue
+        r_row, r_s, r_lo, r_up = wrong_signs(W, u, nu, hard)
+        if max(r_row.max(initial=0.0), r_s.max(initial=0.0), r_lo.max(initial=0.0), r_up.max(initial=0.0)) <= FACE_TOL_M:
+            return True, p, s, W
+        rowst[r_row > FACE_TOL_M] = 0
+        sst[r_s > FACE_TOL_M] = 1
+        bst[(r_lo > FACE_TOL_M) | (r_up > FACE_TOL_M)] = 0
+        rowst[lp.srow[sst == 1]] = 1
+    # ---- anchored method
+    pa, sa = anchor
+    acta = lp.A @ pa
+    if ns:
+        np.add.at(acta, lp.srow, lp.scoef * sa)
+    W = tuple(a.copy() for a in part)
+    for _ in range(FACE_STEPS):
+        rowst, bst, sst = W
+        p, s, act, u, nu, hard, hres = _face_primal_solve(lp, W, sl, stats)
+        if hres > TOL_P:
+            return False, pa, sa, W
+        gw = _primal_margins(lp, W, p, s, act)
+        if min(g.min(initial=np.inf) for g in gw) >= -TOL_P:
+            r_row, r_s, r_lo, r_up = wrong_signs(W, u, nu, hard)
+            worst = max(r_row.max(initial=0.0), r_s.max(initial=0.0), r_lo.max(initial=0.0), r_up.max(initial=0.0))
+            if worst <= FACE_TOL_M:
+                return True, p, s, W
+            # release the most wrong-signed member (lowest index among equals; rows, then slacks, then bounds)
+            if r_row.max(initial=0.0) == worst:
+                rowst[int(np.argmax(r_row))] = 0
+            elif r_s.max(initial=0.0) == worst:
+                sst[int(np.argmax(r_s))] = 1
+            elif r_lo.max(initial=0.0) == worst:
+                bst[int(np.argmax(r_lo))] = 0
+            else:
+                bst[int(np.argmax(r_up))] = 0
+            rowst[lp.srow[sst == 1]] = 1
+            pa, sa, acta = p, s, act
+            continue
+        ga = _primal_margins(lp, W, pa, sa, acta)
+        # first blocking inequality on the segment anchor -> least-norm point (only inequalities violated at its end can block)
+        alpha = 1.0
+        for g0, g1 in zip(ga, gw):
+            m = g1 < -TOL_P
+            if m.any():
+                alpha = min(alpha, float((np.maximum(g0[m], 0.0) / (np.maximum(g0[m], 0.0) - g1[m])).min()))
+        pa = pa + alpha * (p - pa)
+        sa = sa + alpha * (s - sa)
+        acta = acta + alpha * (act - acta)
+        gn = _primal_margins(lp, W, pa, sa, acta)
+        blk = [(g1 < -TOL_P) & (g2 <= TOL_P * 1e-3) for g1, g2 in zip(gw, gn)]
+        if not any(b.any() for b in blk):
+            return False, pa, sa, W
+        rowst[blk[0]] = 1
+        bst[blk[1]] = -1
+        bst[blk[2]] = 1
+        sst[blk[3]] = 0
+    return False, pa, sa, W
+
+
+def face_dual(lp, part, stats):
+    """Multipliers for the canonical primal point: the BASIC least-squares solution of the dual equalities on the partition,
+        a_j'y = q_j for the variables the partition calls free, y_i = 0 on the rows it calls inactive, y_i = w_k scoef_k on
+        rows with a basic slack,
+    from the row Gram matrix A_HF A_HF' with the pivot guard in index order (an active row that is linearly dependent on
+    lower-indexed active rows carries 0 - a least-index rule; when the active rows are independent the multipliers are unique
+    anyway).  Sign conditions of the LP dual that this solution violates become active (the row leaves H / the variable joins
+    F / the slack becomes basic: the dual working set D only shrinks), at most FACE_BULK rounds.  The equalities are solved
+    in the least-squares sense, so a partition that is off by less than the dual tolerance does not break the solve.
+    Returns (ok, y, dual working set)."""
+    A, M, n, ns = lp.A, lp.M, lp.n, lp.ns
+    sq = max(1.0, np.abs(lp.q).max(initial=0.0), np.abs(lp.w).max(initial=0.0))
+    td = FACE_TOL_M * sq
+    fixed = lp.ub <= lp.lb
+    D = tuple(a.copy() for a in part)
+    y = np.zeros(M)
+    for _ in range(FACE_BULK):
+        rowst, bst, sst = D
+        F = np.nonzero(bst == 0)[0]
+        soft, ysoft, _ = _soft_rows(lp, sst)
+        hard = (rowst == 1) & ~soft
+        H = np.nonzero(hard)[0]
+        y = ysoft.copy()
+        if len(H) > 0 and len(F) > 0:
+            AHF = A[np.ix_(H, F)]
+            cF = lp.q[F] - A[:, F].T @ ysoft
+            S = AHF @ AHF.T
+            idx = np.arange(len(H))
+            Lc = chol_guard(S, S[idx, idx].copy(), 1e-10)
+            stats['nfact'] += 1
+            yH = np.zeros(len(H))
+            for _r in range(4):
+                yH = yH + chol_solve(Lc, AHF @ (cF - AHF.T @ yH))
+            y[H] = yH
+        stats['eqp'] += 1
+        z = lp.q - A.T @ y
+        b_row = hard & (lp.rtype != 0) & (lp.rtype * y < -td)
+        b_lo = (bst < 0) & ~fixed & (z < -td)
+        b_up = (bst > 0) & ~fixed & (z > td)
+        b_s = (sst == 0) & (lp.w - lp.scoef * y[lp.srow] < -td) if ns else np.zeros(0, bool)
+        if not (b_row.any() or b_lo.any() or b_up.any() or b_s.any()):
+            return True, y, D
+        rowst[b_row] = 0
+        bst[b_lo | b_up] = 0
+        if ns:
+            sst[b_s] = 1
+            rowst[lp.srow[sst == 1]] = 1
+    return False, y, D
+
+
+def face_polish(lp, part, p_ref, y_ref, stats):
+    """Canonical optimal pair of an LP whose optimum is not unique: the least-norm point of the primal optimal face
+    (`face_primal`) with the basic multipliers of `face_dual`, both on the strict-complementarity partition `part` of the
+    interior-point iterate (p_ref, y_ref).  The pair is complementary by construction (the dual support lies inside the
+    partition's active set, which the primal working set contains) and is accepted only if it passes the LP optimality test.
+    Returns (how, p, s, y, sets): 'face' = canonical pair; 'ref' = the projection of the iterate onto the partition (optimal,
+    but it inherits the iterate's rounding history - returned when an active-set loop runs out of steps); None = the partition
+    does not describe an optimal face (the caller continues)."""
+    p0, s0, y0, nf = eqp(lp, part, p_ref, y_ref)
+    stats['nfact'] += nf
+    stats['eqp'] += 1
+    pr, du = kkt_measures(lp, p0, s0, y0, part)
+    if not (pr <= TOL_P and du <= TOL_D):
+        return None, p0, s0, y0, part
+    okp, p, s, sets_p = face_primal(lp, part, (p0, s0), stats)
+    okd, y, sets_d = face_dual(lp, part, stats) if okp else (False, y0, part)
+    if okp and okd:
+        pr, _ = kkt_measures(lp, p, s, y, sets_p)
+        _, du = kkt_measures(lp, p, s, y, sets_d)
+        if pr <= TOL_P and du <= TOL_D:
+            return 'face', p, s, y, sets_p
+    return 'ref', p0, s0, y0, part
+
+
 IPM_STAGES = ((1e-8, IPM_MAXIT), (1e-10, 6), (1e-12, 6))
 
 
@@ -684,6 +936,13 @@ def solve_scaled(lp, warm=None, stats=None, hint=None):
             stats['path'] = 'ipm%d+ln' % stage
             return OPTIMAL, p, s, y, sets
     if sets0 is not None:
+        # non-unique optimum: canonical (least-norm) pair of the optimal faces the partition describes
+        how, p, s, y, sets = face_polish(lp, sets0, np.clip(ip.p, lp.lb, lp.ub), ip.y, stats)
+        if how is not None:
+            hint['prefer_ref'] = True
+            stats['path'] = 'ipm+' + how
+            return OPTIMAL, p, s, y, sets
+        # the partition is not optimal as it stands: bulk corrections from the iterate's projection
         ok, p, s, y, sets = eqp_loop(lp, sets0, np.clip(ip.p, lp.lb, lp.ub), ip.y, 2, stats)
         if ok:
             hint['prefer_ref'] = True
@@ -699,9 +958,9 @@ def solve_scaled(lp, warm=None, stats=None, hint=None):
     stats['polished'] = 0
     if sets0 is None:
         sets0 = identify(lp, ip)
-    pinf, dinf, gap = ip.log[-1][1:]
-    st = OPTIMAL if max(pinf, dinf, gap) <= 1e-6 else OTHER
-    return st, np.clip(ip.p, lp.lb, lp.ub), np.maximum(ip.s, lp.slo), ip.y, sets0
+    # no active-set solve passed the LP optimality test: the interior iterate is not a solution in the sense the caller
+    # expects from `MOI.optimize!` (subproblem.jl:490-529) -> status OTHER, never OPTIMAL
+    return OTHER, np.clip(ip.p, lp.lb, lp.ub), np.maximum(ip.s, lp.slo), ip.y, sets0
 
 
 def solve_lp(lp, warm=None, hint=None):

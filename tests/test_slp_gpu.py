@@ -121,10 +121,9 @@ def test_acopf_case118_sized_lp_parity():
 
 def test_acopf_restoration_lp_with_non_unique_optimum():
     """Trust-Region sub-LP of the case118-sized grid at x0: INFEASIBLE, then the restoration LP `min sum(slacks)`, whose
-    optimum is not unique (the least-norm polish fails at every stage, the polish from the interior-point iterate
-    succeeds: path 'ipm+ref').  The optimal point is then not pinned by the LP - the reference's simplex would return yet
-    another vertex - so the bars are: same path and iteration counts as the oracle, same optimal value (unique), the
-    step within 1e-6 (both follow the same central path), and the path decision carried to the next call."""
+    optimum is not unique (the optimal face has ~170 dimensions, ~60 of the active rows are linearly dependent).  The solver
+    returns the canonical pair - the least-norm point of the optimal face and the basic multipliers - which is determined by
+    the LP alone (path 'ipm+face'): same path, counts, working sets as the oracle and the 1e-10 bar on step and multipliers."""
     from activesetmethods_amd import acopf
     from tests.util import oracle_solve, hip_solve
     pr = acopf.acopf_problem(acopf.synthetic_case("case118", 1), "case118")
@@ -139,14 +138,35 @@ def test_acopf_restoration_lp_with_non_unique_optimum():
         opt, h_out = hip_solve(sp, True, opt)
         st, so = opt.last_stats(), o_out[6]['stats']
         assert o_out[5] == h_out[5] == 1
-        assert so['path'] == 'ipm+ref' and st['path'] == 4
+        assert so['path'] == 'ipm+face' and st['path'] == 4
         assert st['ipm_iters'] == so['ipm_iters'] and st['eqp'] == so['eqp']
+        rows, bnd, sl = opt.active_set()
+        for a, b in zip((rows, bnd, sl), o_out[6]['sets']):
+            assert np.array_equal(a, b)
         obj_o = sum(sum(v) for v in o_out[4].values()); obj_h = sum(sum(v) for v in h_out[4].values())
-        assert abs(obj_h - obj_o) <= 1e-8 * max(1.0, abs(obj_o))
-        assert rel_err(h_out[0], o_out[0]) < 1e-6
+        assert abs(obj_h - obj_o) <= 1e-10 * max(1.0, abs(obj_o))
+        for k in range(4):
+            assert rel_err(h_out[k], o_out[k]) < 1e-10, k
         assert qp.hint[True].get('prefer_ref') is True
-    assert so['eqp'] <= 4                                                  # second call went straight to that polish
     opt.close()
+
+
+def test_restoration_sequence_does_not_drift():
+    """An SLP run that passes through a sequence of restoration LPs (non-unique optima): because every LP answer is the
+    canonical pair, HIP and oracle stay together - per LP identical status / path / working sets and the 1e-9 trace bar, and
+    the iterates x agree to 1e-9 after the whole sequence (with the projection of the interior iterate this drifted from
+    4e-7 to 6e-2 over ten LPs)."""
+    from activesetmethods_amd import acopf
+    pr = acopf.acopf_problem(acopf.synthetic_case("case118", 1), "case118")
+    mh, sh = _hip_run(pr, algorithm="Trust Region", max_iter=12)
+    mo, so = _oracle_run(pr, algorithm="Trust Region", max_iter=12)
+    assert len(sh.trace) == len(so.trace) and sum(1 for r in so.trace if r['fr']) >= 10
+    names = {0: 'warm', 1: 'ipm0+ln', 2: 'ipm1+ln', 3: 'ipm2+ln', 4: 'ipm+face', 5: 'ipm-unpolished', 6: 'ipm-infeasible', 7: 'phase1-infeasible',
+             8: 'ipm~+ln', 9: 'ipm+ref'}
+    assert [names[r['stats']['path']] for r in sh.trace] == [r['stats']['path'] for r in so.trace]
+    assert all(r['stats']['path'] != 'ipm+ref' for r in so.trace)
+    _compare_traces(so, sh)
+    assert rel_err(mh.x, mo.x) < 1e-9
 
 
 def test_scenario_batch_on_one_gpu():
