@@ -307,7 +307,7 @@ __global__ __launch_bounds__(1024) void k_as_finish(AsPtrs A, AsSets cur, AsSets
 // Primal round tail.  Inputs: t = Ah p, tN = Ah' u_full (u = multipliers of the least-norm problem on the hard rows).
 // Violated inequalities of the face join the working set W (in place); when none is violated, non-mandatory members of W
 // with a wrong-sign multiplier leave; when nothing changes the hard rows must hold (AS_HARDRES).
-__global__ __launch_bounds__(1024) void k_face_primal_finish(AsPtrs A, AsSets W, AsSets part, double tol_p, double tol_m) {
+__global__ __launch_bounds__(1024) void k_face_primal_finish(AsPtrs A, AsSets W, AsSets part, double tol_p, double tol_m, int check_only) {
     __shared__ double sh[16];
     __shared__ int s_viol;
     double nviol = 0.0, nrel = 0.0, hres = 0.0;
@@ -338,6 +338,14 @@ __global__ __launch_bounds__(1024) void k_face_primal_finish(AsPtrs A, AsSets W,
     hres = blk_reduce_max(hres, sh);
     if (threadIdx.x == 0) s_viol = nviol > 0.0;
     __syncthreads();
+    if (check_only) {
+        if (threadIdx.x == 0) {
+            A.cnt[AC_NVIOL] = (int)nviol;
+            A.cnt[AC_NREL] = 0;
+            A.scal[AS_HARDRES] = hres;
+        }
+        return;
+    }
     if (s_viol) {
         // ---- grow
         for (int64_t i = threadIdx.x; i < A.M; i += 1024) {
@@ -382,158 +390,148 @@ __global__ __launch_bounds__(1024) void k_face_primal_finish(AsPtrs A, AsSets W,
     }
 }
 
-// Anchored (feasible-direction) step of the primal least-norm problem (oracle: face_primal, second stage).
-// Inputs: the least-norm point of aff(W) in (p, s, act) with its multipliers (uacc on the hard rows, tN = Ah' u_full), the
-// feasible anchor (pa, sa, acta).  If the point is feasible: the most wrong-signed non-mandatory member of W leaves (rows,
-// then slacks, then lower, then upper bounds; lowest index among equals) and the point becomes the anchor - or, when every
-// sign is right, the method is done (AC_NREL = 0, AC_NVIOL = 0).  Otherwise the anchor moves towards the point until the
-// first inequality blocks; every inequality tight there joins W (AC_NCHG = their number).  One workgroup.
-__device__ __forceinline__ double as_ratio(double g0, double g1, double tol) {
-    if (!(g1 < -tol)) return 2.0;
-    double a = fmax(g0, 0.0);
+// ---- anchored method in the null space of the mandatory set (oracle: _face_primal_anchored) -------------------------------
+// p = p0 + sum_c u_c z_c   (Zbuf row c = z_c, an n-vector supported on the partition's free columns)
+__global__ __launch_bounds__(256) void k_face_ns_combine(const double* __restrict__ p0, const double* __restrict__ Zbuf, int64_t ldz,
+                                                         const double* __restrict__ u, int k, double* __restrict__ p, int64_t n) {
+    int64_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    double acc = p0[j];
+    for (int c = 0; c < k; ++c) acc = fma(u[c], Zbuf[(int64_t)c * ldz + j], acc);
+    p[j] = acc;
+}
+// One step at the candidate p (A.p, with t = Ah p): basic slacks and activities on the working set W, feasibility; if some
+// inequality of the face is violated, the anchor (pa, sa, acta) moves towards the candidate until the first one blocks and
+// that one is marked in W and reported (AC_NCHG = family: 0 row, 1 slack bound, 2 lower, 3 upper; AC_NDIFF = its index;
+// ties: family order, then lowest index).  AC_NVIOL = number of violated inequalities (0: the candidate is feasible).
+__device__ __forceinline__ double as_ratio(double g0, double g1) {
+    const double a = fmax(g0, 0.0);
     return a / (a - g1);
 }
-__global__ __launch_bounds__(1024) void k_face_anchor_step(AsPtrs A, AsSets W, AsSets part, double* __restrict__ pa, double* __restrict__ sa,
-                                                           double* __restrict__ acta, double tol_p, double tol_m) {
+__global__ __launch_bounds__(1024) void k_face_ns_step(AsPtrs A, AsSets W, double* __restrict__ pa, double* __restrict__ sa,
+                                                       double* __restrict__ acta, double tol_p) {
     __shared__ double sh[16];
-    __shared__ double s_val;
-    __shared__ int s_idx[16];
     const int64_t M = A.M, n = A.n, ns = A.ns;
-    // ---- basic slack values and activities of the candidate (t = Ah p)
+    double nviol = 0.0, alpha = 2.0, hres = 0.0;
     for (int64_t i = threadIdx.x; i < M; i += 1024) {
+        int ks = -1;
+        if (ns) {
+            const int k0 = A.rs0[i], k1 = A.rs1[i];
+            if (k0 >= 0 && W.sst[k0] == 1) ks = k0;
+            else if (k1 >= 0 && W.sst[k1] == 1) ks = k1;
+        }
+        A.ksoft[i] = ks;
         double a = A.t[i] + A.sl[i];
-        const int ks = A.ksoft[i];
         if (ks >= 0) {
             const double snew = A.slo[ks] + (A.r[i] - a) / A.scoef[ks];
             a += A.scoef[ks] * (snew - A.slo[ks]);
             A.s[ks] = snew;
         }
         A.act[i] = a;
-    }
-    __syncthreads();
-    // ---- margins of the candidate and the step length to the first blocking inequality
-    double nviol = 0.0, alpha = 1.0, hres = 0.0;
-    for (int64_t i = threadIdx.x; i < M; i += 1024) {
         const int rt = A.rtype[i];
         const double den = 1.0 + fabs(A.r[i]);
-        if (A.hpos[i] >= 0) hres = fmax(hres, fabs(A.act[i] - A.r[i]) / den);
-        if (rt == 0 || W.rowst[i] != 0) continue;
-        const double g1 = rt * (A.act[i] - A.r[i]) / den, g0 = rt * (acta[i] - A.r[i]) / den;
-        if (g1 < -tol_p) { nviol += 1.0; alpha = fmin(alpha, as_ratio(g0, g1, tol_p)); }
+        if (W.rowst[i] == 1 && ks < 0) hres = fmax(hres, fabs(a - A.r[i]) / den);
+        if (rt != 0 && W.rowst[i] == 0) {
+            const double g1 = rt * (a - A.r[i]) / den;
+            if (g1 < -tol_p) { nviol += 1.0; alpha = fmin(alpha, as_ratio(rt * (acta[i] - A.r[i]) / den, g1)); }
+        }
     }
     for (int64_t j = threadIdx.x; j < n; j += 1024) {
-        A.nu[j] = A.p[j] - A.tN[j];
         if (W.bst[j] != 0) continue;
-        double g1 = A.p[j] - A.lb[j], g0 = pa[j] - A.lb[j];
-        if (g1 < -tol_p) { nviol += 1.0; alpha = fmin(alpha, as_ratio(g0, g1, tol_p)); }
-        g1 = A.ub[j] - A.p[j]; g0 = A.ub[j] - pa[j];
-        if (g1 < -tol_p) { nviol += 1.0; alpha = fmin(alpha, as_ratio(g0, g1, tol_p)); }
+        double g1 = A.p[j] - A.lb[j];
+        if (g1 < -tol_p) { nviol += 1.0; alpha = fmin(alpha, as_ratio(pa[j] - A.lb[j], g1)); }
+        g1 = A.ub[j] - A.p[j];
+        if (g1 < -tol_p) { nviol += 1.0; alpha = fmin(alpha, as_ratio(A.ub[j] - pa[j], g1)); }
     }
+    __syncthreads();                                  // s[] of the basic slacks is complete
     for (int64_t k = threadIdx.x; k < ns; k += 1024) {
-        if (W.sst[k] != 1) continue;
+        if (W.sst[k] != 1) { A.s[k] = A.slo[k]; continue; }
         const double den = 1.0 + fabs(A.slo[k]);
-        const double g1 = (A.s[k] - A.slo[k]) / den, g0 = (sa[k] - A.slo[k]) / den;
-        if (g1 < -tol_p) { nviol += 1.0; alpha = fmin(alpha, as_ratio(g0, g1, tol_p)); }
+        const double g1 = (A.s[k] - A.slo[k]) / den;
+        if (g1 < -tol_p) { nviol += 1.0; alpha = fmin(alpha, as_ratio((sa[k] - A.slo[k]) / den, g1)); }
     }
     nviol = blk_reduce_sum(nviol, sh);
     alpha = blk_reduce_min(alpha, sh);
     hres = blk_reduce_max(hres, sh);
-    if (nviol > 0.0) {
-        // ---- move the anchor, add what blocks there
-        double nadd = 0.0;
-        for (int64_t i = threadIdx.x; i < M; i += 1024) {
-            const double an = acta[i] + alpha * (A.act[i] - acta[i]);
-            acta[i] = an;
-            const int rt = A.rtype[i];
-            if (rt == 0 || W.rowst[i] != 0) continue;
-            const double den = 1.0 + fabs(A.r[i]);
-            if (rt * (A.act[i] - A.r[i]) / den < -tol_p && rt * (an - A.r[i]) / den <= tol_p * 1e-3) { W.rowst[i] = 1; nadd += 1.0; }
-        }
-        for (int64_t j = threadIdx.x; j < n; j += 1024) {
-            const double pn = pa[j] + alpha * (A.p[j] - pa[j]);
-            pa[j] = pn;
-            if (W.bst[j] != 0) continue;
-            if (A.p[j] - A.lb[j] < -tol_p && pn - A.lb[j] <= tol_p * 1e-3) { W.bst[j] = -1; nadd += 1.0; }
-            else if (A.ub[j] - A.p[j] < -tol_p && A.ub[j] - pn <= tol_p * 1e-3) { W.bst[j] = 1; nadd += 1.0; }
-        }
-        for (int64_t k = threadIdx.x; k < ns; k += 1024) {
-            const double sn = sa[k] + alpha * (A.s[k] - sa[k]);
-            sa[k] = sn;
-            if (W.sst[k] != 1) continue;
-            const double den = 1.0 + fabs(A.slo[k]);
-            if ((A.s[k] - A.slo[k]) / den < -tol_p && (sn - A.slo[k]) / den <= tol_p * 1e-3) { W.sst[k] = 0; nadd += 1.0; }
-        }
-        nadd = blk_reduce_sum(nadd, sh);
-        if (threadIdx.x == 0) {
-            A.cnt[AC_NVIOL] = (int)nviol;
-            A.cnt[AC_NCHG] = (int)nadd;
-            A.cnt[AC_NREL] = 0;
-            A.scal[AS_HARDRES] = hres;
-        }
+    if (nviol == 0.0) {
+        if (threadIdx.x == 0) { A.cnt[AC_NVIOL] = 0; A.scal[AS_HARDRES] = hres; }
         return;
     }
-    // ---- feasible: worst wrong-signed non-mandatory member
-    double worst = 0.0;
+    // the blocking inequality: smallest ratio, then family order (rows, slacks, lower, upper), then lowest index
+    double code = 1e300;                              // family * 2^40 + index, exact in a double
+    const double F40 = 1099511627776.0;
     for (int64_t i = threadIdx.x; i < M; i += 1024) {
-        const int rt = A.rtype[i], pos = A.hpos[i];
-        if (pos >= 0 && part.rowst[i] != 1 && rt != 0) worst = fmax(worst, -rt * A.uacc[pos]);
+        const int rt = A.rtype[i];
+        if (rt == 0 || W.rowst[i] != 0) continue;
+        const double den = 1.0 + fabs(A.r[i]);
+        const double g1 = rt * (A.act[i] - A.r[i]) / den;
+        if (g1 < -tol_p && as_ratio(rt * (acta[i] - A.r[i]) / den, g1) == alpha) code = fmin(code, (double)i);
     }
     for (int64_t k = threadIdx.x; k < ns; k += 1024) {
-        const int pos = A.hpos[A.srow[k]];
-        if (W.sst[k] == 0 && part.sst[k] != 0 && pos >= 0) worst = fmax(worst, A.scoef[k] * A.uacc[pos]);
+        if (W.sst[k] != 1) continue;
+        const double den = 1.0 + fabs(A.slo[k]);
+        const double g1 = (A.s[k] - A.slo[k]) / den;
+        if (g1 < -tol_p && as_ratio((sa[k] - A.slo[k]) / den, g1) == alpha) code = fmin(code, F40 + (double)k);
     }
     for (int64_t j = threadIdx.x; j < n; j += 1024) {
-        const int b = W.bst[j];
-        if (b == 0 || part.bst[j] != 0 || A.ub[j] <= A.lb[j]) continue;
-        worst = fmax(worst, b < 0 ? -A.nu[j] : A.nu[j]);
+        if (W.bst[j] != 0) continue;
+        double g1 = A.p[j] - A.lb[j];
+        if (g1 < -tol_p && as_ratio(pa[j] - A.lb[j], g1) == alpha) code = fmin(code, 2.0 * F40 + (double)j);
+        g1 = A.ub[j] - A.p[j];
+        if (g1 < -tol_p && as_ratio(A.ub[j] - pa[j], g1) == alpha) code = fmin(code, 3.0 * F40 + (double)j);
     }
-    worst = blk_reduce_max(worst, sh);
-    int released = 0;
-    if (worst > tol_m) {
-        // lowest index holding the worst value, family by family (rows, slacks, lower bounds, upper bounds)
-        for (int fam = 0; fam < 4 && !released; ++fam) {
-            double best = 1e300;                                     // smallest index as a double (exact below 2^53)
-            if (fam == 0) {
-                for (int64_t i = threadIdx.x; i < M; i += 1024) {
-                    const int rt = A.rtype[i], pos = A.hpos[i];
-                    if (pos >= 0 && part.rowst[i] != 1 && rt != 0 && -rt * A.uacc[pos] == worst) best = fmin(best, (double)i);
-                }
-            } else if (fam == 1) {
-                for (int64_t k = threadIdx.x; k < ns; k += 1024) {
-                    const int pos = A.hpos[A.srow[k]];
-                    if (W.sst[k] == 0 && part.sst[k] != 0 && pos >= 0 && A.scoef[k] * A.uacc[pos] == worst) best = fmin(best, (double)k);
-                }
-            } else {
-                for (int64_t j = threadIdx.x; j < n; j += 1024) {
-                    const int b = W.bst[j];
-                    if (b == 0 || part.bst[j] != 0 || A.ub[j] <= A.lb[j]) continue;
-                    if (fam == 2 && b < 0 && -A.nu[j] == worst) best = fmin(best, (double)j);
-                    if (fam == 3 && b > 0 && A.nu[j] == worst) best = fmin(best, (double)j);
-                }
-            }
-            best = blk_reduce_min(best, sh);
-            if (best < 1e299) {
-                released = 1;
-                if (threadIdx.x == 0) {
-                    const int64_t e = (int64_t)best;
-                    if (fam == 0) W.rowst[e] = 0;
-                    else if (fam == 1) { W.sst[e] = 1; W.rowst[A.srow[e]] = 1; }
-                    else W.bst[e] = 0;
-                }
-            }
-        }
-        // the feasible point becomes the anchor
-        for (int64_t i = threadIdx.x; i < M; i += 1024) acta[i] = A.act[i];
-        for (int64_t j = threadIdx.x; j < n; j += 1024) pa[j] = A.p[j];
-        for (int64_t k = threadIdx.x; k < ns; k += 1024) sa[k] = A.s[k];
-    }
-    (void)s_val; (void)s_idx;
+    code = blk_reduce_min(code, sh);
+    const int fam = (int)(code / F40);
+    const int64_t e = (int64_t)(code - (double)fam * F40);
+    const double al = fmin(alpha, 1.0);
+    for (int64_t i = threadIdx.x; i < M; i += 1024) acta[i] += al * (A.act[i] - acta[i]);
+    for (int64_t j = threadIdx.x; j < n; j += 1024) pa[j] += al * (A.p[j] - pa[j]);
+    for (int64_t k = threadIdx.x; k < ns; k += 1024) sa[k] += al * (A.s[k] - sa[k]);
     if (threadIdx.x == 0) {
-        A.cnt[AC_NVIOL] = 0;
-        A.cnt[AC_NCHG] = 0;
-        A.cnt[AC_NREL] = released;
+        if (fam == 0) W.rowst[e] = 1;
+        else if (fam == 1) W.sst[e] = 0;
+        else if (fam == 2) W.bst[e] = -1;
+        else W.bst[e] = 1;
+        A.cnt[AC_NVIOL] = (int)nviol;
+        A.cnt[AC_NCHG] = fam;
+        A.cnt[AC_NDIFF] = (int)e;
         A.scal[AS_HARDRES] = hres;
     }
+}
+// The blocking constraint as  c'p (>= | <=) b  on the free columns of the partition: rd = c, AS_EQRES = g = b - c'(p0 - pfix),
+// AS_PR = c'c.   t0 = Ah p0.
+__global__ __launch_bounds__(1024) void k_face_ns_col(AsPtrs A, const double* __restrict__ Ah, int64_t ld, int fam, int64_t e,
+                                                      const double* __restrict__ p0, const double* __restrict__ t0) {
+    __shared__ double sh[16];
+    double cc = 0.0;
+    const int64_t row = fam == 0 ? e : (fam == 1 ? (int64_t)A.srow[e] : -1);
+    for (int64_t j = threadIdx.x; j < A.n; j += 1024) {
+        double c = 0.0;
+        if (row >= 0) c = A.Fmask[j] * Ah[row * ld + j];
+        else if (j == e) c = 1.0;
+        A.rd[j] = c;
+        cc += c * c;
+    }
+    cc = blk_reduce_sum(cc, sh);
+    if (threadIdx.x == 0) {
+        double g;
+        if (row >= 0) g = A.r[row] - A.sl[row] - t0[row];
+        else g = (fam == 2 ? A.lb[e] : A.ub[e]) - p0[e];
+        A.scal[AS_EQRES] = g;
+        A.scal[AS_PR] = cc;
+    }
+}
+// z = rd - Fmask .* tN   (tN = N0' S0^-1 N0 c)
+__global__ __launch_bounds__(256) void k_face_ns_z(AsPtrs A, double* __restrict__ z) {
+    int64_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j < A.n) z[j] = A.rd[j] - A.Fmask[j] * A.tN[j];
+}
+// undo a mark of the working set (release of an added constraint)
+__global__ void k_face_ns_unmark(AsPtrs A, AsSets W, int fam, int64_t e) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (fam == 0) W.rowst[e] = 0;
+    else if (fam == 1) { W.sst[e] = 1; W.rowst[A.srow[e]] = 1; }
+    else W.bst[e] = 0;
 }
 
 // Dual round tail (oracle: face_dual).  Input: tN = Ah' y.  z = q - Ah'y; sign conditions of the LP dual that y violates

@@ -42,7 +42,7 @@ const int PCG_MAXIT = 20;       // conjugate-gradient steps per Newton solve (pr
 const double PCG_KAPPA = 1e-3;  // Newton-system residual tolerance relative to the current primal residual
 const double IPM_RHO_P = 1e-8;   // primal proximal regularisation of the Newton system
 // canonical pair of a non-unique optimum (oracle/lp_solver.py: FACE_*)
-const int FACE_BULK = 6, FACE_STEPS = 80;
+const int FACE_BULK = 6, FACE_STEPS = 400;
 const double FACE_TOL_M = 1e-9;
 
 struct HipError : std::runtime_error {
@@ -145,6 +145,7 @@ struct asm_handle {
     int* d_as_i = nullptr;
     int* h_ascnt = nullptr;         // pinned read-back of its counters / scalars
     double* h_asscal = nullptr;
+    double *d_Zbuf = nullptr, *d_nsu = nullptr, *d_nsdots = nullptr, *h_nsdots = nullptr;   // null-space active-set method (face_primal_anchored)
     int64_t nsp = 0;
     double* h_scal = nullptr;       // pinned scalar read-back
     int* d_idx = nullptr;
@@ -1148,6 +1149,138 @@ struct Solver {
         return false;
     }
 
+    // bordered Cholesky of the small matrix Z'Z (host)
+    struct SmallChol {
+        std::vector<vec> T, L;
+        bool factor_row(size_t k) {                 // row k of L from rows 0..k-1 and T[k]
+            vec l(k + 1, 0.0);
+            for (size_t a = 0; a < k; ++a) {
+                double v = T[k][a];
+                for (size_t b = 0; b < a; ++b) v -= l[b] * L[a][b];
+                l[a] = v / L[a][a];
+            }
+            double d2 = T[k][k];
+            for (size_t b = 0; b < k; ++b) d2 -= l[b] * l[b];
+            if (!(d2 > 1e-14 * T[k][k])) return false;
+            l[k] = std::sqrt(d2);
+            L.push_back(l);
+            return true;
+        }
+        bool append(const vec& trow) {              // trow: products with the members so far, then the diagonal entry
+            const size_t k = T.size();
+            for (size_t a = 0; a < k; ++a) T[a].push_back(trow[a]);
+            T.push_back(trow);
+            if (factor_row(k)) return true;
+            T.pop_back();
+            for (size_t a = 0; a < k; ++a) T[a].pop_back();
+            return false;
+        }
+        bool remove_swap(size_t j) {                // member j leaves, the last member takes its slot
+            const size_t last = T.size() - 1;
+            if (j != last) {
+                std::swap(T[j], T[last]);
+                for (auto& r_ : T) std::swap(r_[j], r_[last]);
+            }
+            T.pop_back();
+            for (auto& r_ : T) r_.pop_back();
+            L.clear();
+            for (size_t k = 0; k < T.size(); ++k)
+                if (!factor_row(k)) return false;
+            return true;
+        }
+        vec solve(const vec& g) const {
+            const size_t k = L.size();
+            vec x(g.begin(), g.begin() + k);
+            for (size_t a = 0; a < k; ++a) {
+                for (size_t b = 0; b < a; ++b) x[a] -= L[a][b] * x[b];
+                x[a] /= L[a][a];
+            }
+            for (size_t a = k; a-- > 0;) {
+                for (size_t b = a + 1; b < k; ++b) x[a] -= L[b][a] * x[b];
+                x[a] /= L[a][a];
+            }
+            return x;
+        }
+    };
+
+    bool face_primal_anchored() {
+        const int64_t n = lp.n, M = lp.M, ns = lp.ns, ldz = h->ldn;
+        const unsigned gM = (unsigned)((M + 255) / 256 + 1), gN = (unsigned)((n + 255) / 256);
+        as_copy_sets(4, 3);
+        as_solve(S_[4], nullptr, nullptr, 1);            // p0 = least-norm point of the partition; its factor, Hidx, Fmask stay
+        const int nH0 = as_nH;
+        double *p0 = d_pf, *t0 = d_actf;
+        dcopy(p0, A.p, n); dcopy(t0, A.t, M);
+        dcopy(d_pa, d_p0, n); dcopy(d_sa, d_s0, ns); dcopy(d_acta, d_act0, M);
+        std::vector<std::pair<int, int64_t>> members;
+        vec g, sign, u;
+        SmallChol sc;
+        for (int st = 0; st < FACE_STEPS; ++st) {
+            const int k = (int)members.size();
+            if (k > 0) {
+                HIPCHK(hipMemcpyAsync(h->d_nsu, u.data(), k * sizeof(double), hipMemcpyHostToDevice, h->stream));
+                hipLaunchKernelGGL(k_face_ns_combine, dim3(gN), dim3(256), 0, h->stream, (const double*)p0, (const double*)h->d_Zbuf, ldz,
+                                   (const double*)h->d_nsu, k, A.p, n);
+            } else {
+                dcopy(A.p, p0, n);
+            }
+            dev.gemv_n_dev(h->d_Ah, A.p, A.t);
+            hipLaunchKernelGGL(k_face_ns_step, dim3(1), dim3(1024), 0, h->stream, A, S_[4], d_pa, d_sa, d_acta, TOL_P);
+            as_read();                                    // (the host copy of u is no longer needed by the device after this)
+            const int nviol = h->h_ascnt[AC_NVIOL];
+            if (h->verbose && (st < 5 || st % 20 == 0 || nviol == 0))
+                std::fprintf(stderr, "[asm] face primal anchored %d: members %d viol %d hres %.2e\n", st, k, nviol, h->h_asscal[AS_HARDRES]);
+            if (h->h_asscal[AS_HARDRES] > TOL_P) return false;
+            if (nviol == 0) {
+                int jw = -1;
+                double worst = FACE_TOL_M;
+                for (int j = 0; j < k; ++j)
+                    if (-sign[j] * u[j] > worst) { worst = -sign[j] * u[j]; jw = j; }
+                if (jw < 0) return true;                  // feasible, every multiplier has the right sign: THE least-norm point
+                hipLaunchKernelGGL(k_face_ns_unmark, dim3(1), dim3(64), 0, h->stream, A, S_[4], members[jw].first, members[jw].second);
+                dcopy(d_pa, A.p, n); dcopy(d_sa, A.s, ns); dcopy(d_acta, A.act, M);
+                const int last = k - 1;
+                if (jw != last) {
+                    dcopy(h->d_Zbuf + (int64_t)jw * ldz, h->d_Zbuf + (int64_t)last * ldz, ldz);
+                    members[jw] = members[last]; g[jw] = g[last]; sign[jw] = sign[last];
+                }
+                members.pop_back(); g.pop_back(); sign.pop_back();
+                if (!sc.remove_swap((size_t)jw)) return false;
+                u = sc.solve(g);
+                continue;
+            }
+            const int fam = h->h_ascnt[AC_NCHG];
+            const int64_t e = h->h_ascnt[AC_NDIFF];
+            hipLaunchKernelGGL(k_face_ns_col, dim3(1), dim3(1024), 0, h->stream, A, (const double*)h->d_Ah, h->ldn, fam, e, (const double*)p0, (const double*)t0);
+            if (nH0 > 0) {
+                dev.gemv_n_dev(h->d_Ah, A.rd, A.t);
+                hipLaunchKernelGGL(k_as_gather_h, dim3((unsigned)((nH0 + 255) / 256)), dim3(256), 0, h->stream, A);
+                dev.chol_solve_dev(A.v, A.u, nH0);
+                hipLaunchKernelGGL(k_as_scatter_h, dim3(gM), dim3(256), 0, h->stream, A, (const double*)A.u, 0);
+                dev.gemv_t_dev(h->d_Ah, A.yfull, A.tN);
+            } else {
+                HIPCHK(hipMemsetAsync(A.tN, 0, h->ldn * sizeof(double), h->stream));
+            }
+            double* znew = h->d_Zbuf + (int64_t)k * ldz;
+            hipLaunchKernelGGL(k_face_ns_z, dim3(gN), dim3(256), 0, h->stream, A, znew);
+            hipLaunchKernelGGL(k_gemv_n, dim3((unsigned)((k + 1 + 3) / 4)), dim3(256), 0, h->stream, (const double*)h->d_Zbuf, ldz, (const double*)znew,
+                               h->d_nsdots, (int64_t)(k + 1), ldz);
+            HIPCHK(hipMemcpyAsync(h->h_nsdots, h->d_nsdots, (k + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(h->h_asscal, A.scal, AS_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            const double zz = h->h_nsdots[k], cc = h->h_asscal[AS_PR];
+            if (!(zz > 1e-10 * cc)) return false;        // dependent on the working set although it blocks
+            vec trow(h->h_nsdots, h->h_nsdots + k + 1);
+            if (!sc.append(trow)) return false;
+            members.emplace_back(fam, e);
+            g.push_back(h->h_asscal[AS_EQRES]);
+            sign.push_back(fam == 0 ? (double)lp.rtype[e] : (fam == 1 ? -lp.scoef[e] : (fam == 2 ? 1.0 : -1.0)));
+            u = sc.solve(g);
+            h->stats.eqp += 1;
+        }
+        return false;
+    }
+
     // oracle: face_polish - canonical pair of a non-unique optimum on the partition in S_[3].
     // Returns 2 ('face': least-norm point + basic multipliers), 1 ('ref': projection of the iterate), 0 (partition not optimal).
     int face_polish() {
@@ -1165,29 +1298,21 @@ struct Solver {
         as_copy_sets(4, 3);
         for (int r = 0; r < FACE_BULK; ++r) {
             as_solve(S_[4], nullptr, nullptr, 1);
-            hipLaunchKernelGGL(k_face_primal_finish, dim3(1), dim3(1024), 0, h->stream, A, S_[4], S_[3], TOL_P, FACE_TOL_M);
+            hipLaunchKernelGGL(k_face_primal_finish, dim3(1), dim3(1024), 0, h->stream, A, S_[4], S_[3], TOL_P, FACE_TOL_M, 0);
             as_read();
             if (h->verbose) std::fprintf(stderr, "[asm] face primal bulk %d: nH %d nF %d viol %d rel %d hres %.2e\n", r, as_nH, as_nF, h->h_ascnt[AC_NVIOL], h->h_ascnt[AC_NREL], h->h_asscal[AS_HARDRES]);
             if (h->h_asscal[AS_HARDRES] > TOL_P) break;            // over-determined working set
             if (h->h_ascnt[AC_NVIOL] > 0) continue;
             if (h->h_ascnt[AC_NREL] == 0) { okp = true; break; }
         }
-        // ---- primal: anchored method from the projection of the iterate
-        if (!okp) {
-            as_copy_sets(4, 3);
-            dcopy(d_pa, d_p0, n); dcopy(d_sa, d_s0, ns); dcopy(d_acta, d_act0, M);
-            for (int st = 0; st < FACE_STEPS; ++st) {
-                as_solve(S_[4], nullptr, nullptr, 1);
-                hipLaunchKernelGGL(k_face_anchor_step, dim3(1), dim3(1024), 0, h->stream, A, S_[4], S_[3], d_pa, d_sa, d_acta, TOL_P, FACE_TOL_M);
-                as_read();
-                if (h->verbose) std::fprintf(stderr, "[asm] face primal anchored %d: nH %d nF %d viol %d added %d released %d hres %.2e\n", st, as_nH, as_nF, h->h_ascnt[AC_NVIOL], h->h_ascnt[AC_NCHG], h->h_ascnt[AC_NREL], h->h_asscal[AS_HARDRES]);
-                if (h->h_asscal[AS_HARDRES] > TOL_P) break;
-                if (h->h_ascnt[AC_NVIOL] > 0) {
-                    if (h->h_ascnt[AC_NCHG] == 0) break;           // nothing blocks: numerical trouble
-                    continue;
-                }
-                if (h->h_ascnt[AC_NREL] == 0) { okp = true; break; }
-            }
+        // ---- primal: anchored method in the null space of the partition (oracle: _face_primal_anchored) - one factorisation,
+        // one solve with it per added constraint, the k x k matrix Z'Z of the added constraints on the host
+        if (!okp && face_primal_anchored()) {
+            // the answer is the least-norm point of the FINAL working set, computed like any other (fresh factorisation)
+            as_solve(S_[4], nullptr, nullptr, 1);
+            hipLaunchKernelGGL(k_face_primal_finish, dim3(1), dim3(1024), 0, h->stream, A, S_[4], S_[3], TOL_P, FACE_TOL_M, 1);
+            as_read();
+            okp = h->h_asscal[AS_HARDRES] <= TOL_P && h->h_ascnt[AC_NVIOL] == 0;
         }
         bool okd = false;
         if (okp) {
@@ -1364,6 +1489,9 @@ void free_device(asm_handle* h) {
     if (h->h_ascnt) (void)hipHostFree(h->h_ascnt);
     if (h->h_asscal) (void)hipHostFree(h->h_asscal);
     h->d_as = nullptr; h->d_as_i = nullptr; h->h_ascnt = nullptr; h->h_asscal = nullptr;
+    F(h->d_Zbuf); F(h->d_nsu); F(h->d_nsdots);
+    if (h->h_nsdots) (void)hipHostFree(h->h_nsdots);
+    h->d_Zbuf = h->d_nsu = h->d_nsdots = h->h_nsdots = nullptr;
     if (h->h_pin) (void)hipHostFree(h->h_pin);
     h->d_perm = h->d_ustart = h->d_uoff = h->d_adjoff = nullptr;
     h->d_dE = h->d_J = h->d_Ah = h->d_S = h->d_c = h->d_rho = h->d_theta = h->d_diag = h->d_diag0 = nullptr;
@@ -1546,6 +1674,11 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
         HIPCHK(hipMemsetAsync(h->d_as_i, 0, nasi * sizeof(int), h->stream));
         HIPCHK(hipHostMalloc((void**)&h->h_ascnt, 64 * sizeof(int)));
         HIPCHK(hipHostMalloc((void**)&h->h_asscal, 64 * sizeof(double)));
+        dmalloc(&h->d_Zbuf, (int64_t)(FACE_STEPS + 1) * h->ldn);
+        HIPCHK(hipMemsetAsync(h->d_Zbuf, 0, (int64_t)(FACE_STEPS + 1) * h->ldn * sizeof(double), h->stream));
+        dmalloc(&h->d_nsu, FACE_STEPS + 8);
+        dmalloc(&h->d_nsdots, FACE_STEPS + 8);
+        HIPCHK(hipHostMalloc((void**)&h->h_nsdots, (FACE_STEPS + 8) * sizeof(double)));
     }
     h->pin_len = std::max(std::max(h->ldn, h->Mp), h->nsp);
     HIPCHK(hipHostMalloc((void**)&h->h_pin, 2 * h->pin_len * sizeof(double)));

@@ -594,7 +594,7 @@ def eqp_loop(lp, sets, p_ref, y_ref, rounds, stats):
 # units): the solution of a strictly convex problem, hence unique - independent of the interior-point iterate that
 # identified the faces and of the order in which an implementation builds its working set.
 FACE_BULK = 6        # bulk rounds (all violated constraints join at once) before the anchored method takes over
-FACE_STEPS = 80      # anchored feasible-direction steps (each adds the blocking constraint of a ratio test)
+FACE_STEPS = 400     # anchored feasible-direction steps (each adds the blocking constraint of a ratio test: one solve)
 FACE_TOL_M = 1e-9    # sign tolerance of the least-norm problems' own multipliers (scaled units)
 
 
@@ -715,53 +715,138 @@ def face_primal(lp, part, anchor, stats):
         sst[r_s > FACE_TOL_M] = 1
         bst[(r_lo > FACE_TOL_M) | (r_up > FACE_TOL_M)] = 0
         rowst[lp.srow[sst == 1]] = 1
-    # ---- anchored method
+    # ---- anchored method in the null space of the mandatory set (one factorisation, one solve per added constraint)
+    return _face_primal_anchored(lp, part, anchor, sl, stats)
+
+
+def _face_primal_anchored(lp, part, anchor, sl, stats):
+    """Second stage of `face_primal`: the classical primal active-set method for  min 1/2 |p|^2  over the face, started at the
+    feasible `anchor`, written as a Schur-complement update so that the working set never has to be re-factored.
+    With N0 = the hard rows of the partition restricted to its free columns F0 and P = I - N0'(N0 N0')^-1 N0 the projector onto
+    their null space, every point of aff(W) for W = partition + added constraints {c_1..c_k} is
+        p = p0 + Z u,   z_j = P c_j,   (Z'Z) u = g,   g_j = b_j - c_j'p0,
+    p0 = least-norm point of the partition.  u are the multipliers of the added constraints in the least-norm problem (the
+    partition's own members are mandatory and never leave), so the release test reads them off directly.  A step: move the
+    anchor towards p until the first inequality blocks (ratio test), add it (one solve with the factor of N0 N0' for its z, one
+    bordering step of the k x k matrix Z'Z); at a feasible p release the most wrong-signed added constraint, or stop.  Every
+    working set visited holds at the anchor, hence is consistent; a blocking constraint whose z vanishes cannot occur for a
+    consistent set and ends the method (numerical trouble: the caller falls back)."""
+    rowst0, bst0, sst0 = part
+    A, M, n, ns = lp.A, lp.M, lp.n, lp.ns
+    W = tuple(a.copy() for a in part)
+    rowst, bst, sst = W
+    F0 = bst0 == 0
+    Fm = F0.astype(float)
+    soft0, _, ksoft0 = _soft_rows(lp, sst0)
+    hard0 = (rowst0 == 1) & ~soft0
+    H0 = np.nonzero(hard0)[0]
+    pfix = np.where(bst0 < 0, lp.lb, np.where(bst0 > 0, lp.ub, 0.0))
+    Lc = None
+    if len(H0) > 0 and F0.any():
+        N0 = A[np.ix_(H0, np.nonzero(F0)[0])]
+        S = N0 @ N0.T
+        idx = np.arange(len(H0))
+        Lc = chol_guard(S, S[idx, idx].copy(), 1e-10)
+        stats['nfact'] += 1
+
+    def project(c):
+        """P c for an n-vector supported on F0."""
+        if Lc is None:
+            return c.copy()
+        return c - Fm * (A[H0].T @ chol_solve(Lc, A[H0] @ c))
+
+    # p0: least-norm point of the partition (three sweeps, as in _face_primal_solve)
+    p0 = pfix.copy()
+    if Lc is not None:
+        bH = lp.r[H0] - A[H0] @ pfix - sl[H0]
+        pF = np.zeros(n)
+        for _r in range(3):
+            pF = pF + Fm * (A[H0].T @ chol_solve(Lc, bH - A[H0] @ pF))
+        p0 = pfix + pF
+    stats['eqp'] += 1
+    t0 = A @ p0
+    members = []          # (family, index): 0 row, 1 slack-bound (row becomes hard), 2 lower bound, 3 upper bound
+    Z = np.zeros((0, n))
+    g = np.zeros(0)
+    sign = np.zeros(0)    # +1: constraint c'p >= b (multiplier >= 0), -1: c'p <= b
     pa, sa = anchor
-    acta = lp.A @ pa
+    acta = A @ pa
     if ns:
         np.add.at(acta, lp.srow, lp.scoef * sa)
-    W = tuple(a.copy() for a in part)
+    rden = 1.0 + np.abs(lp.r)
+    u = np.zeros(0)
     for _ in range(FACE_STEPS):
-        rowst, bst, sst = W
-        p, s, act, u, nu, hard, hres = _face_primal_solve(lp, W, sl, stats)
-        if hres > TOL_P:
+        if len(members):
+            T = Z @ Z.T
+            u = np.linalg.solve(T, g)
+            p = p0 + Z.T @ u
+        else:
+            p = p0.copy()
+        # basic slacks / activities on the current working set
+        s = lp.slo.copy()
+        soft, _, ksoft = _soft_rows(lp, sst)
+        act = A @ p + sl
+        isoft = np.nonzero(soft)[0]
+        ks = ksoft[isoft]
+        s[ks] = lp.slo[ks] + (lp.r[isoft] - act[isoft]) / lp.scoef[ks]
+        act[isoft] = lp.r[isoft]
+        hard = (rowst == 1) & ~soft
+        if float((np.abs(act - lp.r)[hard] / rden[hard]).max(initial=0.0)) > TOL_P:
             return False, pa, sa, W
         gw = _primal_margins(lp, W, p, s, act)
-        if min(g.min(initial=np.inf) for g in gw) >= -TOL_P:
-            r_row, r_s, r_lo, r_up = wrong_signs(W, u, nu, hard)
-            worst = max(r_row.max(initial=0.0), r_s.max(initial=0.0), r_lo.max(initial=0.0), r_up.max(initial=0.0))
-            if worst <= FACE_TOL_M:
-                return True, p, s, W
-            # release the most wrong-signed member (lowest index among equals; rows, then slacks, then bounds)
-            if r_row.max(initial=0.0) == worst:
-                rowst[int(np.argmax(r_row))] = 0
-            elif r_s.max(initial=0.0) == worst:
-                sst[int(np.argmax(r_s))] = 1
-            elif r_lo.max(initial=0.0) == worst:
-                bst[int(np.argmax(r_lo))] = 0
+        if min(x.min(initial=np.inf) for x in gw) >= -TOL_P:
+            wrong = -sign * u
+            if wrong.max(initial=0.0) <= FACE_TOL_M:
+                # the answer is the least-norm point of the FINAL working set, computed like any other (fresh factorisation):
+                # it does not inherit the rounding of the null-space updates
+                p, s, act, _, _, _, hres = _face_primal_solve(lp, W, sl, stats)
+                ok = hres <= TOL_P and min(x.min(initial=np.inf) for x in _primal_margins(lp, W, p, s, act)) >= -TOL_P
+                return bool(ok), p, s, W
+            j = int(np.argmax(wrong))                       # most wrong-signed added constraint (first among equals) leaves
+            fam, e = members.pop(j)
+            Z = np.delete(Z, j, axis=0); g = np.delete(g, j); sign = np.delete(sign, j)
+            if fam == 0:
+                rowst[e] = 0
+            elif fam == 1:
+                sst[e] = 1
             else:
-                bst[int(np.argmax(r_up))] = 0
-            rowst[lp.srow[sst == 1]] = 1
+                bst[e] = 0
             pa, sa, acta = p, s, act
             continue
         ga = _primal_margins(lp, W, pa, sa, acta)
-        # first blocking inequality on the segment anchor -> least-norm point (only inequalities violated at its end can block)
-        alpha = 1.0
-        for g0, g1 in zip(ga, gw):
+        # first blocking inequality on the segment anchor -> p; ties: rows, then slacks, then lower, then upper bounds, lowest index
+        best = (2.0, 9, -1)
+        for fam, (g0, g1) in enumerate(zip((ga[0], ga[3], ga[1], ga[2]), (gw[0], gw[3], gw[1], gw[2]))):
             m = g1 < -TOL_P
             if m.any():
-                alpha = min(alpha, float((np.maximum(g0[m], 0.0) / (np.maximum(g0[m], 0.0) - g1[m])).min()))
+                a0 = np.where(m, np.maximum(g0, 0.0), 0.0)
+                ratio = np.where(m, a0 / np.where(m, a0 - g1, 1.0), 2.0)
+                e = int(np.argmin(ratio))
+                if (float(ratio[e]), fam, e) < best:
+                    best = (float(ratio[e]), fam, e)
+        alpha, fam, e = best
+        alpha = min(alpha, 1.0)
         pa = pa + alpha * (p - pa)
         sa = sa + alpha * (s - sa)
         acta = acta + alpha * (act - acta)
-        gn = _primal_margins(lp, W, pa, sa, acta)
-        blk = [(g1 < -TOL_P) & (g2 <= TOL_P * 1e-3) for g1, g2 in zip(gw, gn)]
-        if not any(b.any() for b in blk):
-            return False, pa, sa, W
-        rowst[blk[0]] = 1
-        bst[blk[1]] = -1
-        bst[blk[2]] = 1
-        sst[blk[3]] = 0
+        # the blocking constraint as  c'p (>= | <=) b  on the free columns of the partition
+        if fam == 0:
+            c = Fm * A[e]; bc = lp.r[e] - sl[e] - A[e] @ pfix; sg = float(lp.rtype[e]); rowst[e] = 1
+        elif fam == 1:
+            i = lp.srow[e]
+            c = Fm * A[i]; bc = lp.r[i] - sl[i] - A[i] @ pfix; sg = -float(lp.scoef[e]); sst[e] = 0
+        elif fam == 2:
+            c = np.zeros(n); c[e] = 1.0; bc = lp.lb[e]; sg = 1.0; bst[e] = -1
+        else:
+            c = np.zeros(n); c[e] = 1.0; bc = lp.ub[e]; sg = -1.0; bst[e] = 1
+        z = project(c)
+        if not (z @ z > 1e-10 * (c @ c)):
+            return False, pa, sa, W                          # dependent on the working set although it blocks
+        members.append((fam, e))
+        Z = np.vstack([Z, z])
+        g = np.append(g, bc - c @ (p0 - pfix))
+        sign = np.append(sign, sg)
+        stats['eqp'] += 1
     return False, pa, sa, W
 
 
