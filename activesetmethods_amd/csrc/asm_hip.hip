@@ -29,6 +29,7 @@ namespace {
 const double INF = std::numeric_limits<double>::infinity();
 const double TOL_P = 1e-9, TOL_D = 1e-6;
 const int IPM_MAXIT = 60;
+const double JAM_PINF = 1e-6;    // below this a stagnating primal residual is rounding-level, not a jam (oracle/lp_solver.py)
 const int IPM_MCC = 2;           // Gondzio centrality correctors per iteration (oracle/lp_solver.py)
 const double MCC_DELTA = 0.3, MCC_BMIN = 0.1, MCC_BMAX = 10.0, MCC_GAMMA = 0.1;
 const int CHOL_NBI = 256, CHOL_NBO = 1024;   // inner / outer panel widths of the three-level Cholesky
@@ -894,7 +895,7 @@ struct Solver {
             if (done >= max_more) return ip.status = ASM_OTHER;
             // jammed: complementarity collapsed but the primal residual no longer decreases (oracle: IPM.run)
             ip.pinf_hist.push_back(ip.pinf);
-            if (ip.iters >= 10 && ip.gap <= 1e-2 * ip.pinf && ip.pinf > 0.5 * ip.pinf_hist[ip.pinf_hist.size() - 4]) {
+            if (ip.iters >= 10 && ip.pinf > JAM_PINF && ip.gap <= 1e-2 * ip.pinf && ip.pinf > 0.5 * ip.pinf_hist[ip.pinf_hist.size() - 4]) {
                 ip.stalled = true;
                 return ip.status = ASM_OTHER;
             }
@@ -1418,11 +1419,18 @@ struct Solver {
                 if (lp.ns == 0 && phase1_infeasible()) { h->stats.path = 7; return ASM_INFEASIBLE; }
                 break;
             }
-            if (prefer_ref && stage + 1 < 3) continue;      // straight on to the last stage
             double t1 = now_ms();
             identify_dev(3);
             have_sets = true;
-            if (prefer_ref) break;
+            if (prefer_ref) {
+                // non-unique optimum expected: the canonical pair as soon as the partition passes the LP optimality test
+                // (oracle: solve_scaled)
+                const int how = face_polish();
+                t_polish += now_ms() - t1;
+                if (how == 2) { h->stats.path = 4; return ASM_OPTIMAL; }
+                if (how == 1) { h->stats.path = 9; return ASM_OPTIMAL; }
+                continue;
+            }
             as_copy_sets(0, 3);
             bool okp = eqp_loop(d_zero, nullptr, 2);
             t_polish += now_ms() - t1;
@@ -1431,7 +1439,7 @@ struct Solver {
         if (have_sets) {
             double t1 = now_ms();
             // non-unique optimum: canonical (least-norm) pair of the optimal faces the partition describes (oracle: face_polish)
-            const int how = face_polish();
+            const int how = prefer_ref ? 0 : face_polish();
             t_polish += now_ms() - t1;
             if (how == 2) { hint.prefer_ref = true; h->stats.path = 4; return ASM_OPTIMAL; }
             if (how == 1) { hint.prefer_ref = true; h->stats.path = 9; return ASM_OPTIMAL; }

@@ -37,6 +37,7 @@ TOL_P = 1e-9      # primal feasibility of the accepted vertex (scaled units)
 TOL_D = 1e-6      # dual feasibility of the accepted vertex (scaled units)
 IPM_TOL = 1e-8
 IPM_MAXIT = 60
+JAM_PINF = 1e-6       # a primal residual below this is rounding-level stagnation of a converging run, not a jam
 COL_MIN_M = 64        # column (Sherman-Morrison-Woodbury) form of the Newton system: smallest M, largest n/M, CG steps
 COL_MAX_RATIO = 0.8   # per solve beyond which the rest of the LP returns to the row form, pivot of fixed columns
 COL_MAX_CG = 6
@@ -254,7 +255,7 @@ class IPM:
             # jammed: complementarity has collapsed but the primal residual no longer decreases (the
             # signature of a slightly infeasible LP) -> give up, the caller runs the elastic phase-1 LP
             self.pinf_hist.append(pinf)
-            if self.iters >= 10 and gap <= 1e-2 * pinf and pinf > 0.5 * self.pinf_hist[-4]:
+            if self.iters >= 10 and pinf > JAM_PINF and gap <= 1e-2 * pinf and pinf > 0.5 * self.pinf_hist[-4]:
                 self.status = OTHER
                 self.stalled = True
                 return self.status
@@ -1011,18 +1012,23 @@ def solve_scaled(lp, warm=None, stats=None, hint=None):
                 stats['path'] = 'phase1-infeasible'
                 return INFEASIBLE, None, None, None, None
             break                                   # never reached 1e-8: no identification attempt
-        if prefer_ref and stage + 1 < len(IPM_STAGES):
-            continue                                # straight on to the last stage
         sets0 = identify(lp, ip)
         if prefer_ref:
-            break
+            # non-unique optimum expected: the canonical pair as soon as the partition passes the LP optimality test (its
+            # first step is that test - one solve when it fails); pushing the iterate further than needed only costs
+            # factorisations and, where a tolerance is out of reach, accuracy
+            how, p, s, y, sets = face_polish(lp, sets0, np.clip(ip.p, lp.lb, lp.ub), ip.y, stats)
+            if how is not None:
+                stats['path'] = 'ipm+' + how
+                return OPTIMAL, p, s, y, sets
+            continue
         ok, p, s, y, sets = eqp_loop(lp, sets0, zero_p, zero_y, 2, stats)
         if ok:
             stats['path'] = 'ipm%d+ln' % stage
             return OPTIMAL, p, s, y, sets
     if sets0 is not None:
         # non-unique optimum: canonical (least-norm) pair of the optimal faces the partition describes
-        how, p, s, y, sets = face_polish(lp, sets0, np.clip(ip.p, lp.lb, lp.ub), ip.y, stats)
+        how, p, s, y, sets = (None,) * 5 if prefer_ref else face_polish(lp, sets0, np.clip(ip.p, lp.lb, lp.ub), ip.y, stats)
         if how is not None:
             hint['prefer_ref'] = True
             stats['path'] = 'ipm+' + how
