@@ -43,7 +43,7 @@ const int PCG_MAXIT = 20;       // conjugate-gradient steps per Newton solve (pr
 const double PCG_KAPPA = 1e-3;  // Newton-system residual tolerance relative to the current primal residual
 const double IPM_RHO_P = 1e-8;   // primal proximal regularisation of the Newton system
 // canonical pair of a non-unique optimum (oracle/lp_solver.py: FACE_*)
-const int FACE_BULK = 6, FACE_STEPS = 400;
+const int FACE_BULK = 12, FACE_STEPS = 400;
 const double FACE_TOL_M = 1e-9;
 
 struct HipError : std::runtime_error {

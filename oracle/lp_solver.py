@@ -594,7 +594,7 @@ def eqp_loop(lp, sets, p_ref, y_ref, rounds, stats):
 # each; which one is an artefact of its pivoting rules.  This solver returns the LEAST-NORM point of each face (scaled
 # units): the solution of a strictly convex problem, hence unique - independent of the interior-point iterate that
 # identified the faces and of the order in which an implementation builds its working set.
-FACE_BULK = 6        # bulk rounds (all violated constraints join at once) before the anchored method takes over
+FACE_BULK = 12       # bulk rounds (all violated constraints join at once) before the anchored method takes over
 FACE_STEPS = 400     # anchored feasible-direction steps (each adds the blocking constraint of a ratio test: one solve)
 FACE_TOL_M = 1e-9    # sign tolerance of the least-norm problems' own multipliers (scaled units)
 

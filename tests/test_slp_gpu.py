@@ -216,3 +216,87 @@ def test_scenario_batch_on_one_gpu():
     assert np.array_equal(np.concatenate([s.x for s in slps2]), np.concatenate([s.x for s in slps]))
     for k in ("scenarios", "converged", "iterations", "lp_solves", "restoration_solves", "inf_pr", "inf_du"):
         assert stats2[k] == stats[k]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Regression: full SLP runs at case118 / case300 size.  Round 1 left a run on record (gpurun_out/fail.log) where a
+# case118-sized run ended with status -5 because an LP came back unpolished (path 5) / status OTHER: the interior-point
+# iteration was declared "jammed" at a primal residual of 1e-8 (rounding level) one iteration before convergence, and the
+# polish of the not-quite-converged iterate failed.  Every LP of these runs must now end in an active-set solve.
+@pytest.mark.parametrize("case,load,alg,expect", [
+    ("case118", 1.0, "Line Search", (0,)),
+    ("case118", 1.0, "Trust Region", (0, 6, -1)),
+    ("case300", 0.5, "Line Search", (0,)),
+    ("case300", 1.0, "Line Search", (0, 6, -1, 2)),
+])
+def test_slp_run_to_termination_every_lp_polished(case, load, alg, expect):
+    from activesetmethods_amd import acopf
+    pr = acopf.acopf_problem(acopf.synthetic_case(case, 1, load), case)
+    mh, sh = _hip_run(pr, algorithm=alg, max_iter=100)
+    bad = [(k, r['status'], r['stats']['path'], r['stats']['polished']) for k, r in enumerate(sh.trace)
+           if r['status'] not in (1, 2) or r['stats']['polished'] != 1 or r['stats']['path'] == 5]
+    assert not bad, bad
+    assert mh.status in expect, (mh.status, sh.iter, sh.lp_solves)       # never -5 (LP solver trouble, slp_line_search.jl:127-133)
+
+
+def test_case300_sized_lp_parity_normal_and_restoration():
+    """C5's size (n = 2382, m = 3889): one normal-phase LP (Line-Search radius) and the restoration LP after the INFEASIBLE
+    Trust-Region LP at the same point, HIP vs oracle: status, path, working sets, 1e-9 on step and multipliers."""
+    from activesetmethods_amd import acopf
+    from tests.util import oracle_solve, hip_solve
+    pr = acopf.acopf_problem(acopf.synthetic_case("case300", 1, 0.5), "case300")
+    x = pr.x0.copy()
+    base = dict(n=pr.n, m=pr.m, j_row=pr.j_row, j_col=pr.j_col, dE=pr.eval_jac_g(x, np.zeros(pr.nnz)), df=pr.eval_grad_f(x, np.zeros(pr.n)),
+                f=pr.eval_f(x), E=pr.eval_g(x, np.zeros(pr.m)), x_k=x, c_lb=pr.g_L, c_ub=pr.g_U, v_lb=pr.x_L, v_ub=pr.x_U)
+    names = {0: 'warm', 1: 'ipm0+ln', 2: 'ipm1+ln', 3: 'ipm2+ln', 4: 'ipm+face', 5: 'ipm-unpolished', 6: 'ipm-infeasible', 7: 'phase1-infeasible',
+             8: 'ipm~+ln', 9: 'ipm+ref'}
+    # normal phase, Line-Search radius
+    sp = dict(base, delta=1000.0)
+    qp, o_out = oracle_solve(sp)
+    opt, h_out = hip_solve(sp)
+    assert o_out[5] == h_out[5] == 1
+    assert names[opt.last_stats()['path']] == o_out[6]['stats']['path']
+    for a, b in zip(opt.active_set(), o_out[6]['sets']):
+        assert np.array_equal(a, b)
+    for k in range(4):
+        assert rel_err(h_out[k], o_out[k]) < 1e-9, k
+    opt.close()
+    # Trust-Region radius: INFEASIBLE, then the restoration LP (non-unique optimum)
+    sp = dict(base, delta=0.05)
+    qp, o_out = oracle_solve(sp)
+    opt, h_out = hip_solve(sp)
+    assert o_out[5] == h_out[5]
+    if o_out[5] == 2:
+        qp, o_out = oracle_solve(sp, True, qp)
+        opt, h_out = hip_solve(sp, True, opt)
+    assert o_out[5] == h_out[5] == 1
+    assert names[opt.last_stats()['path']] == o_out[6]['stats']['path']
+    for a, b in zip(opt.active_set(), o_out[6]['sets']):
+        assert np.array_equal(a, b)
+    for k in range(4):
+        assert rel_err(h_out[k], o_out[k]) < 1e-9, k
+    opt.close()
+
+
+def test_case300_scenario_batch_all_converge():
+    """BASELINE.json configs[4] at reduced count: 8 scenarios of the case300-sized grid (the C5 workload of bench.py: load
+    scale 0.5, loads x U(0.9,1.1) per scenario) through the batch path on one GPU, three in flight; every scenario must
+    converge (status 0) with every LP polished, and the merged statistics must say so."""
+    import activesetmethods_amd as A
+    from activesetmethods_amd import acopf, batch
+    base = acopf.synthetic_case("case300", 1, 0.5)
+
+    def make_model(sidx):
+        pr = acopf.acopf_problem(acopf.scenario_case(base, sidx), "case300-sized scenario %d" % sidx)
+        return A.Model.from_problem(pr, A.Parameters(algorithm="Line Search", max_iter=100))
+
+    def run(model):
+        slp = A.optimize(model)
+        slp.optimizer.close()
+        return slp
+
+    slps, stats = batch.solve_batch(make_model, 8, rank=0, world=1, run=run, concurrency=3)
+    assert stats["scenarios"] == 8 and stats["converged"] == 8, stats
+    assert all(s.ret == 0 for s in slps)
+    assert all(r['status'] in (1, 2) and r['stats']['polished'] == 1 for s in slps for r in s.trace)
+    assert stats["inf_pr"] <= 0.01 and stats["inf_du"] <= 0.01
