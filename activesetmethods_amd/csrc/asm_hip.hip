@@ -170,6 +170,9 @@ struct asm_handle {
     std::vector<hipEvent_t> event_pool;
     std::map<std::pair<int, int>, hipGraphExec_t> graphs;   // (kind, Ms) -> captured launch sequence
     bool use_graphs = false;
+    bool fused_panel = true;        // Cholesky inner panels as one dataflow launch (k_chol_panel) instead of three launches per 64-wide step
+    int panel_wgs = 240;            // its grid bound: every workgroup must be able to become resident
+    unsigned *d_pflags = nullptr, *d_ptmo = nullptr;
     bool timing = true;
     bool verbose = false;
 };
@@ -514,6 +517,15 @@ struct Dev {
     void chol_chain(int Ms, double thr, int K0, int K1) {
         for (int I0 = K0; I0 < K1; I0 += CHOL_NBI) {
             const int I1 = std::min(I0 + CHOL_NBI, K1);
+            if (h->fused_panel) {
+                // the <= 4 steps of this inner panel in one dataflow launch (k_chol_panel): row tiles are owned by workgroups,
+                // diagonal-block factors and the panel tiles other workgroups need travel through release / acquire flags
+                const int nrt = (Ms - I0 + ASM_NB - 1) / ASM_NB;
+                const int G = std::min(nrt, h->panel_wgs);
+                HIPCHK(hipMemsetAsync(h->d_pflags, 0, 32 * sizeof(unsigned), cur));
+                hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)G), dim3(256), 0, cur, h->d_S, h->Mp, I0, std::min(I1, Ms), Ms, (const double*)h->d_diag0, thr,
+                                   h->d_Linv, h->d_pflags, h->d_ptmo);
+            } else
             for (int k0 = I0; k0 < I1; k0 += ASM_NB) {
                 int nb = std::min(ASM_NB, Ms - k0);
                 hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, cur, h->d_S, h->Mp, k0, nb, h->d_diag0, thr, h->d_Linv);
@@ -1493,6 +1505,8 @@ void free_device(asm_handle* h) {
     h->sp_ok = h->spv_Ah_valid = h->spv_J_valid = false; h->sp_nnz = 0;
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     h->d_ipm = nullptr; h->d_ipm_i = nullptr; h->h_scal = nullptr;
+    F(h->d_pflags); F(h->d_ptmo);
+    h->d_pflags = h->d_ptmo = nullptr;
     F(h->d_as); F(h->d_as_i);
     if (h->h_ascnt) (void)hipHostFree(h->h_ascnt);
     if (h->h_asscal) (void)hipHostFree(h->h_asscal);
@@ -1507,6 +1521,13 @@ void free_device(asm_handle* h) {
     h->d_Linv = nullptr;
     h->d_idx = nullptr;
     h->h_pin = nullptr;
+}
+
+void check_panel_timeout(asm_handle* h) {
+    if (!h->fused_panel || !h->d_ptmo) return;
+    unsigned tmo = 0;
+    HIPCHK(hipMemcpy(&tmo, h->d_ptmo, sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (tmo != 0) throw HipError("k_chol_panel: a workgroup timed out waiting for a producer (grid not resident?)");
 }
 
 template <class T>
@@ -1622,6 +1643,9 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     dmalloc(&h->d_partial, (int64_t)ASM_TMAXCHUNKS * h->ldn);
     dmalloc(&h->d_idx, h->Mp);
     dmalloc(&h->d_Linv, (h->Mp / ASM_NB + 1) * ASM_NB * ASM_NB);
+    dmalloc(&h->d_pflags, 32);
+    dmalloc(&h->d_ptmo, 4);
+    HIPCHK(hipMemsetAsync(h->d_ptmo, 0, 4 * sizeof(unsigned), h->stream));
     h->wb = h->M > 1536 ? 1024 : 512;      // wide-block width of the triangular solves (k_wtrsv_*<WB>)
     if (h->M >= RED_MIN_M) {
         dmalloc(&h->d_idxI, h->Mp); dmalloc(&h->d_rdI, h->Mp); dmalloc(&h->d_rce, h->Mp); dmalloc(&h->d_rze, h->Mp); dmalloc(&h->d_sdiag, h->Mp);
@@ -1839,6 +1863,7 @@ void do_solve(asm_handle* h, double delta, int feasibility, double* p_out, doubl
         h->last = ActiveSet();
     }
     sv.dev.resolve_timing();
+    check_panel_timeout(h);
     h->stats.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
@@ -1889,6 +1914,12 @@ int asm_create(int device, asm_handle** out) {
     h->timing = !(tm && tm[0] == '0');
     const char* vb = std::getenv("ASM_HIP_VERBOSE");
     h->verbose = vb && vb[0] == '1';
+    const char* fp = std::getenv("ASM_HIP_FUSED_PANEL");
+    h->fused_panel = !(fp && fp[0] == '0');
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 16) h->panel_wgs = prop.multiProcessorCount - 16;
+    }
     const char* gr = std::getenv("ASM_HIP_GRAPHS");
     h->use_graphs = gr && gr[0] == '1';      // opt-in: no measured gain on this ROCm build, and rocprofv3 crashes on captured streams
     *out = h;
@@ -2078,6 +2109,7 @@ int asm_test_cholesky(asm_handle* h, const double* S, int64_t N, double* L_out) 
             for (int64_t j = i + 1; j < N; ++j) L_out[i * N + j] = 0.0;
         }
         d.resolve_timing();
+        check_panel_timeout(h);
     });
 }
 

@@ -341,13 +341,20 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
     return __hiloint2double(hi, lo);
 }
-__global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int64_t ldS, int k0, int nb,
-                                                    const double* __restrict__ diag0, double thr, double* __restrict__ Linv) {
-    __shared__ double D[ASM_NB * ASM_DP];
-    __shared__ double W[ASM_NB * ASM_DP];
-    __shared__ double T[4][16 * 17];
-    __shared__ double d0[ASM_NB], dinv[ASM_NB];
+// body shared by the stand-alone kernel and the fused panel kernel: D, W are ASM_NB x ASM_DP LDS buffers, T 4 x (16 x 17)
+typedef double potrf_T_t[16 * 17];
+template <bool SC1>
+__device__ __forceinline__ void potrf64_body(double* __restrict__ D, double* __restrict__ W, potrf_T_t* __restrict__ T, double* __restrict__ d0,
+                                             double* __restrict__ dinv, double* __restrict__ S, int64_t ldS, int k0, int nb,
+                                             const double* __restrict__ diag0, double thr, double* __restrict__ Linv) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#ifdef ASM_POTRF_PROF
+    long long stamp_[16]; int ns_ = 0;
+#define PSTAMP() do { if (tid == 0) stamp_[ns_++] = clock64(); } while (0)
+#else
+#define PSTAMP() do {} while (0)
+#endif
+    PSTAMP();
     for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
         int rr = e >> 6, c = e & 63;
         D[rr * ASM_DP + c] = (rr < nb && c <= rr) ? S[(int64_t)(k0 + rr) * ldS + k0 + c] : (rr == c ? 1.0 : 0.0);
@@ -355,49 +362,58 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int6
     }
     if (tid < ASM_NB) d0[tid] = tid < nb ? diag0[k0 + tid] : 1.0;
     __syncthreads();
+    PSTAMP();
+    // inverse of one finished 16x16 diagonal block of L (columns of the inverse by substitution; lane t < 16 owns column t)
+    auto diag_inverse = [&](int c0) {
+        const int t = lane & 15;
+        double x[16];
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            double sum = 0.0;
+#pragma unroll
+            for (int q = 0; q < rr; ++q) sum = fma(D[(c0 + rr) * ASM_DP + c0 + q], x[q], sum);
+            double rhs = (rr == t) ? 1.0 : 0.0;
+            x[rr] = (rr < t) ? 0.0 : (rhs - sum) * dinv[c0 + rr];
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) W[(c0 + rr) * ASM_DP + c0 + t] = x[rr];
+        }
+    };
     for (int sb = 0; sb < 4; ++sb) {
         const int c0 = sb * 16;
-        if (wv == 0) {                                   // (1) 16x16 diagonal sub-block, lane t < 16 owns row c0+t
-            const int t = lane & 15;
+        if (wv == 0) {
+            // (1) 16 columns of the factor over ALL remaining rows at once: lane r owns row c0 + r.  Lanes 0..15 hold the
+            //     diagonal sub-block; the same sixteen broadcast-and-update steps that factor it solve the rows below it
+            //     (x L11' = a is exactly the recurrence a[c] -= l * L11[c][j]), so the panel solve costs nothing extra.
+            const int row = c0 + lane;
+            const bool live = row < ASM_NB;
             double a[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) a[c] = D[(c0 + t) * ASM_DP + c0 + c];
+            for (int c = 0; c < 16; ++c) a[c] = live ? D[row * ASM_DP + c0 + c] : 0.0;
             double my_inv = 1.0;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 double d = readlane_f64(a[j], j);
                 if (!(d > thr * d0[c0 + j])) d = 1e256;
                 double inv = rsqrt(d);                   // one transcendental on the dependent chain instead of sqrt + division
-                double ljj = d * inv;
                 double l = a[j] * inv;
-                if (t == j) { l = ljj; my_inv = inv; }
+                if (lane == j) { l = d * inv; my_inv = inv; }
                 a[j] = l;
 #pragma unroll
                 for (int c = j + 1; c < 16; ++c) a[c] = fma(-l, readlane_f64(l, c), a[c]);
             }
-            if (lane < 16) {
+            if (live) {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) D[(c0 + t) * ASM_DP + c0 + c] = (c <= t) ? a[c] : 0.0;
-                dinv[c0 + t] = my_inv;
+                for (int c = 0; c < 16; ++c) D[row * ASM_DP + c0 + c] = (lane >= 16 || c <= lane) ? a[c] : 0.0;
+                if (lane < 16) dinv[c0 + lane] = my_inv;
             }
+        } else if (wv == 1 && sb > 0) {
+            diag_inverse(c0 - 16);                       // meanwhile: inverse of the previous (finished) diagonal sub-block
         }
         __syncthreads();
-        const int rows_below = ASM_NB - (c0 + 16);
-        if (tid < rows_below) {                          // (2) rows below: x L11' = d  (substitution, L11 broadcast from LDS)
-            const int r = c0 + 16 + tid;
-            double x[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                double v = D[r * ASM_DP + c0 + c];
-#pragma unroll
-                for (int q = 0; q < c; ++q) v = fma(-x[q], D[(c0 + c) * ASM_DP + c0 + q], v);
-                x[c] = v * dinv[c0 + c];
-            }
-#pragma unroll
-            for (int c = 0; c < 16; ++c) D[r * ASM_DP + c0 + c] = x[c];
-        }
-        __syncthreads();
-        {                                                // (3) rank-16 update of the remaining lower triangle, 16x16 tiles on
+        PSTAMP();
+        {                                                // (2) rank-16 update of the remaining lower triangle, 16x16 tiles on
             const int rb = c0 + 16;                      //     the matrix cores: A22[ti][tj] -= X[ti] X[tj]'  (tj <= ti)
             const int nt = (ASM_NB - rb) / 16;
             for (int t = wv; t < nt * (nt + 1) / 2; t += 4) {
@@ -423,24 +439,11 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int6
         int rr = e >> 6, c = e & 63;
         if (c <= rr && c < nb) S[(int64_t)(k0 + rr) * ldS + k0 + c] = D[rr * ASM_DP + c];
     }
-    // ---- inverse W = L^-1 by 16x16 blocks
-    {   // diagonal blocks: wavefront wv inverts block wv; lane t < 16 owns column t of the block inverse
-        const int c0 = wv * 16, t = lane & 15;
-        double x[16];
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-            double sum = 0.0;
-#pragma unroll
-            for (int q = 0; q < rr; ++q) sum = fma(D[(c0 + rr) * ASM_DP + c0 + q], x[q], sum);
-            double rhs = (rr == t) ? 1.0 : 0.0;
-            x[rr] = (rr < t) ? 0.0 : (rhs - sum) * dinv[c0 + rr];
-        }
-        if (lane < 16) {
-#pragma unroll
-            for (int rr = 0; rr < 16; ++rr) W[(c0 + rr) * ASM_DP + c0 + t] = x[rr];
-        }
-    }
+    PSTAMP();
+    // ---- inverse W = L^-1 by 16x16 blocks (diagonal blocks 0..2 were inverted beside the factorisation of their successors)
+    if (wv == 1) diag_inverse(48);
     __syncthreads();
+    PSTAMP();
     for (int dlev = 1; dlev < 4; ++dlev) {               // off-diagonal blocks (i, j = i - dlev), one wavefront per block,
         const int i = wv + dlev, j = wv;                 // 16x16x16 products on the matrix cores
         if (i < 4) {
@@ -471,8 +474,24 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int6
         }
         __syncthreads();
     }
+    PSTAMP();
     double* out = Linv + (int64_t)(k0 / ASM_NB) * ASM_NB * ASM_NB;
-    for (int e = tid; e < ASM_NB * ASM_NB; e += 256) out[e] = W[(e >> 6) * ASM_DP + (e & 63)];
+#ifdef ASM_POTRF_PROF
+    if (tid == 0 && k0 == 64) { stamp_[ns_++] = clock64(); printf("potrf stamps:"); for (int q = 1; q < ns_; ++q) printf(" %lld", stamp_[q] - stamp_[q - 1]); printf("\n"); }
+#endif
+    for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
+        const double v = W[(e >> 6) * ASM_DP + (e & 63)];
+        if (SC1) __hip_atomic_store(out + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // write-through: read by other workgroups of this launch
+        else out[e] = v;
+    }
+}
+__global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int64_t ldS, int k0, int nb,
+                                                    const double* __restrict__ diag0, double thr, double* __restrict__ Linv) {
+    __shared__ double D[ASM_NB * ASM_DP];
+    __shared__ double W[ASM_NB * ASM_DP];
+    __shared__ potrf_T_t T[4];
+    __shared__ double d0[ASM_NB], dinv[ASM_NB];
+    potrf64_body<false>(D, W, T, d0, dinv, S, ldS, k0, nb, diag0, thr, Linv);
 }
 
 // Panel solve through the explicit inverse:  S[i, k0:k1] <- S[i, k0:k1] * Linv11'  for the 64 rows of this tile, as one
@@ -558,6 +577,161 @@ __global__ __launch_bounds__(256) void k_panel_update64(double* __restrict__ S, 
             int row = r0 + w * 16 + (lane >> 4) + 4 * r, col = c0 + t * 16 + (lane & 15);
             if (row < Ms && col < c_end && col <= row) S[(int64_t)row * ldS + col] = acc[t][r];
         }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused inner panel of the Cholesky: the 64-wide steps of one inner panel [I0, I1) (<= 4 steps: diagonal-block
+// factorisation, panel solve, rank-64 update of the panel's remaining columns) in ONE launch, as a dataflow over
+// 64-row tiles instead of three dependent launches per step.  Row tile rt (rows I0 + 64 rt ...) belongs to workgroup
+// rt mod G for the whole launch, so a tile's own history needs no synchronisation; what crosses workgroups is published
+// with an agent-scope release and consumed behind a relaxed poll + ONE agent-scope acquire (cdna_hip_programming.md,
+// Guideline 16):
+//     flags[k]              the factor / inverse of diagonal block k (written by the owner of row tile k)
+//     flags[4 + 4 k + tj]   the solved panel tile X(tj, step k) of a later diagonal row tile tj (the right operand of the
+//                           rank-64 update of column tile tj)
+// The owner of row tile k+1 factors diagonal block k+1 as soon as that tile has its step-k update (look-ahead): the
+// critical path of a step is  panel solve + update of ONE tile + the 64 x 64 factorisation, everything else overlaps.
+// Every workgroup must be able to become resident (G <= #CUs); every spin is bounded (tmo[0] != 0 -> the host fails the
+// factorisation).  Flags are zeroed by a memset node ahead of every launch.
+// The payload is stored write-through (sc1: __hip_atomic_store relaxed / agent scope), so publishing needs no release fence
+// (which would write back every dirty line of the XCD's L2): every storing wavefront drains its stores, then one lane sets
+// the flag (Guideline 16, recipe R1).
+__device__ __forceinline__ void pnl_publish(unsigned* flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void pnl_wait(unsigned* flag, unsigned* tmo) {
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1u << 22)) {                       // bounded: a lost producer must not hang the GPU
+                __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+#define ASM_PNL_LDS (2 * ASM_NB * ASM_XP + 4 * 16 * 17 + 2 * ASM_NB)
+__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms,
+                                                    const double* __restrict__ diag0, double thr, double* __restrict__ Linv,
+                                                    unsigned* __restrict__ flags, unsigned* __restrict__ tmo) {
+    __shared__ __attribute__((aligned(16))) double sm[ASM_PNL_LDS];
+    double* B0 = sm;                                  // the tile being solved, then X
+    double* B1 = sm + ASM_NB * ASM_XP;                // block inverse, then the right operand X(tj)
+    potrf_T_t* Tt = reinterpret_cast<potrf_T_t*>(sm + 2 * ASM_NB * ASM_XP);
+    double* d0 = sm + 2 * ASM_NB * ASM_XP + 4 * 16 * 17;
+    double* dinv = d0 + ASM_NB;
+    const int G = gridDim.x, wg = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nsteps = (I1 - I0 + ASM_NB - 1) / ASM_NB;
+    const int nrt = (Ms - I0 + ASM_NB - 1) / ASM_NB;
+    if (wg == 0) {
+        potrf64_body<true>(B0, B1, Tt, d0, dinv, S, ldS, I0, min(ASM_NB, Ms - I0), diag0, thr, Linv);
+        pnl_publish(flags + 0);
+    }
+    for (int k = 0; k < nsteps; ++k) {
+        const int k0 = I0 + k * ASM_NB;
+        const int nb = min(ASM_NB, Ms - k0), k1 = k0 + nb;
+        if (k1 >= Ms) break;
+        bool waited = false;
+        // first row tile > k owned by this workgroup
+        int rt = wg;
+        while (rt <= k) rt += G;
+        for (; rt < nrt; rt += G) {
+            if (!waited) { pnl_wait(flags + k, tmo); waited = true; }
+            const int i0 = I0 + rt * ASM_NB;
+            const double* Lb = Linv + (int64_t)(k0 / ASM_NB) * ASM_NB * ASM_NB;
+            // ---- panel solve of the tile: X = S[tile, k0:k1] Linv'
+            __syncthreads();
+            for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
+                int rr = e >> 6, c = e & 63;
+                B1[rr * ASM_XP + c] = Lb[e];
+                int gi = i0 + rr;
+                B0[rr * ASM_XP + c] = (gi < Ms && c < nb) ? S[(int64_t)gi * ldS + k0 + c] : 0.0;
+            }
+            __syncthreads();
+            v4f64 acc[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+            for (int kk = 0; kk < ASM_NB; kk += 4) {
+                double af = B0[(w * 16 + (lane & 15)) * ASM_XP + kk + (lane >> 4)];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    double bf = B1[(t * 16 + (lane & 15)) * ASM_XP + kk + (lane >> 4)];
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc[t], 0, 0, 0);
+                }
+            }
+            __syncthreads();                          // every wavefront has read its rows of B0 and all of B1
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int row = w * 16 + (lane >> 4) + 4 * r, col = t * 16 + (lane & 15);
+                    int gi = i0 + row;
+                    B0[row * ASM_XP + col] = acc[t][r];
+                    if (gi < Ms && col < nb) {
+                        double* dst = S + (int64_t)gi * ldS + k0 + col;
+                        if (rt < nsteps) __hip_atomic_store(dst, acc[t][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // operand for others
+                        else *dst = acc[t][r];
+                    }
+                }
+            if (rt < nsteps) pnl_publish(flags + 4 + 4 * k + rt);      // a later diagonal row tile: its X is an operand for others
+            else __syncthreads();
+            // ---- rank-64 update of the panel's remaining column tiles tj = k+1 .. min(rt, nsteps-1)
+            const int tj_hi = min(rt, nsteps - 1);
+            for (int tj = k + 1; tj <= tj_hi; ++tj) {
+                const int c0 = I0 + tj * ASM_NB, c_end = min(c0 + ASM_NB, min(I1, Ms));
+                const double* Pb = B0;
+                if (tj != rt) {
+                    pnl_wait(flags + 4 + 4 * k + tj, tmo);
+                    for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
+                        int rr = e >> 6, c = e & 63;
+                        B1[rr * ASM_XP + c] = (c0 + rr < Ms && c < nb) ? S[(int64_t)(c0 + rr) * ldS + k0 + c] : 0.0;
+                    }
+                    __syncthreads();
+                    Pb = B1;
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int row = i0 + w * 16 + (lane >> 4) + 4 * r, col = c0 + t * 16 + (lane & 15);
+                        acc[t][r] = (row < Ms && col < c_end && col <= row) ? S[(int64_t)row * ldS + col] : 0.0;
+                    }
+#pragma unroll 4
+                for (int kk = 0; kk < ASM_NB; kk += 4) {
+                    double af = -B0[(w * 16 + (lane & 15)) * ASM_XP + kk + (lane >> 4)];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        double bf = Pb[(t * 16 + (lane & 15)) * ASM_XP + kk + (lane >> 4)];
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc[t], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int row = i0 + w * 16 + (lane >> 4) + 4 * r, col = c0 + t * 16 + (lane & 15);
+                        if (row < Ms && col < c_end && col <= row) S[(int64_t)row * ldS + col] = acc[t][r];
+                    }
+                __syncthreads();                      // B1 is reloaded for the next column tile
+            }
+            // ---- look-ahead: this tile is the next diagonal block and has all its updates now
+            if (rt == k + 1 && rt < nsteps) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                const int kn = I0 + rt * ASM_NB;
+                potrf64_body<true>(B0, B1, Tt, d0, dinv, S, ldS, kn, min(ASM_NB, Ms - kn), diag0, thr, Linv);
+                pnl_publish(flags + rt);
+            }
+        }
+    }
 }
 
 // out[i] = || A[i, :] ||_2   (one wavefront per row) - KT_residuals / compute_nu! (common.jl:41, slp.jl:58)

@@ -36,7 +36,7 @@ def test_syrk_matches_numpy(hip_lib, handle, M, K, Ms, tile):
     assert err < 1e-13          # f64 MFMA accumulation, K <= 1000
 
 
-@pytest.mark.parametrize("N", [1, 17, 64, 65, 200, 513, 1000])
+@pytest.mark.parametrize("N", [1, 17, 64, 65, 200, 513, 1000, 2500, 4700])
 def test_cholesky_and_solve(hip_lib, handle, N):
     rng = np.random.default_rng(N)
     B = rng.standard_normal((N, N + 5))
