@@ -173,7 +173,7 @@ struct asm_handle {
     bool fused_panel = true;        // Cholesky inner panels as one dataflow launch (k_chol_panel) instead of three launches per 64-wide step
     int panel_wgs = 240;            // its grid bound: every workgroup must be able to become resident
     unsigned *d_pflags = nullptr, *d_ptmo = nullptr;
-    bool timing = true;
+    int timing = 1;                 // HIP-event timing: 0 off, 1 the dominant kernel only (every k_syrk launch), 2 every kernel family
     bool verbose = false;
 };
 
@@ -201,7 +201,7 @@ struct Dev {
         h->kstats.flops[kind] += flops;
         h->kstats.bytes[kind] += bytes;
         h->kstats.calls[kind] += 1;
-        if (!h->timing) return -1;
+        if (h->timing < 2 && !(h->timing == 1 && kind == ASM_K_SYRK_KERNEL)) return -1;
         TimedRegion r;
         r.a = get_event();
         r.b = get_event();
@@ -383,6 +383,7 @@ struct Dev {
     }
     // fraction of (tile pair, chunk) products actually executed: keeps the flop accounting of the roofline honest
     double executed_fraction(const unsigned char* d_flags, int nt, int nch) {
+        if (h->timing == 0) return h->nz_valid ? h->nz_fraction : 1.0;      // only the flop accounting needs it: no read-back when timing is off
         std::vector<unsigned char> fl((size_t)nt * nch);
         HIPCHK(hipMemcpyAsync(fl.data(), d_flags, fl.size(), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -1009,7 +1010,7 @@ struct Solver {
     double *d_pref = nullptr, *d_zero = nullptr;
     double *d_p0 = nullptr, *d_s0 = nullptr, *d_y0 = nullptr, *d_act0 = nullptr, *d_z0 = nullptr;      // projection of the iterate
     double *d_pa = nullptr, *d_sa = nullptr, *d_acta = nullptr;                                          // anchor of the primal method
-    double *d_pf = nullptr, *d_sf = nullptr, *d_actf = nullptr;                                          // least-norm point
+    double *d_pf = nullptr, *d_sf = nullptr, *d_actf = nullptr, *d_yf = nullptr, *d_zf = nullptr;       // least-norm point (scratch) / multipliers
     int final_sets = 0;
     int as_nH = 0, as_nF = 0;
 
@@ -1023,10 +1024,10 @@ struct Solver {
         A.rtype = P.rtype; A.srow = P.srow; A.rs0 = P.rs0; A.rs1 = P.rs1;
         A.n = lp.n; A.M = lp.M; A.ns = lp.ns; A.scale_q = lp.scale_q;
         A.Fmask = N(); A.p = N(); A.z = N(); A.pB = N(); A.pF = N(); A.cF = N(); A.rd = N(); A.tN = N(); A.xfull = N(); A.nu = N();
-        d_pref = N(); d_zero = N(); d_p0 = N(); d_z0 = N(); d_pa = N(); d_pf = N();
+        d_pref = N(); d_zero = N(); d_p0 = N(); d_z0 = N(); d_pa = N(); d_pf = N(); d_zf = N();
         A.Hmask = Mv(); A.sl = Mv(); A.y = Mv(); A.act = Mv(); A.t = Mv(); A.bH = Mv(); A.v = Mv(); A.u = Mv(); A.yH = Mv();
         A.yfull = Mv(); A.uacc = Mv(); A.ax = Mv();
-        d_y0 = Mv(); d_act0 = Mv(); d_acta = Mv(); d_actf = Mv();
+        d_y0 = Mv(); d_act0 = Mv(); d_acta = Mv(); d_actf = Mv(); d_yf = Mv();
         A.s = Sv(); d_s0 = Sv(); d_sa = Sv(); d_sf = Sv();
         A.scal = a;
         int* ia = h->d_as_i;
@@ -1088,7 +1089,8 @@ struct Solver {
     //   mode 1: primal least-norm point only (p_ref = 0), 3 sweeps, the multipliers of that problem accumulated in uacc
     //   mode 2: basic least-squares multipliers only (y_ref = 0), 4 sweeps
     // Leaves t = Ah p and tN = Ah' y (mode 1: tN = Ah' u_full) for the tail kernel.
-    void as_solve(const AsSets& cur, const double* p_ref, const double* y_ref, int mode) {
+    bool part_factor = false;   // d_S holds the factor of the partition's Schur matrix (face_polish re-uses it for the rounds on the same sets)
+    void as_solve(const AsSets& cur, const double* p_ref, const double* y_ref, int mode, bool reuse_factor = false) {
         const unsigned gA = grid_all(), gM = (unsigned)((lp.M + 255) / 256 + 1), gN = (unsigned)((lp.n + 255) / 256);
         hipLaunchKernelGGL(k_as_setup, dim3(1), dim3(1024), 0, h->stream, A, cur, p_ref, h->ldn, h->Mp);
         HIPCHK(hipMemcpyAsync(h->h_ascnt, A.cnt, AC_COUNT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1102,9 +1104,12 @@ struct Solver {
             hipLaunchKernelGGL(k_as_rhs, dim3(gA), dim3(256), 0, h->stream, A, y_ref);
         }
         if (nH > 0 && nF > 0) {
-            dev.syrk_gathered_dev(A.Hidx, nH, A.Fmask, nullptr);
-            dev.diag_prepare(nH, 1, 0.0, 0.0);
-            dev.chol(nH, 1e-10);
+            if (!(reuse_factor && part_factor)) {
+                dev.syrk_gathered_dev(A.Hidx, nH, A.Fmask, nullptr);
+                dev.diag_prepare(nH, 1, 0.0, 0.0);
+                dev.chol(nH, 1e-10);
+                part_factor = false;
+            }
             const int sweeps = mode == 1 ? 3 : 4;
             const unsigned gH = (unsigned)((nH + 255) / 256);
             for (int it = 0; it < sweeps; ++it) {
@@ -1306,41 +1311,45 @@ struct Solver {
         h->stats.kkt_du = h->h_asscal[AS_DU];
         if (!(h->h_asscal[AS_PR] <= TOL_P && h->h_asscal[AS_DU] <= TOL_D)) return 0;
         dcopy(d_p0, A.p, n); dcopy(d_s0, A.s, ns); dcopy(d_y0, A.y, M); dcopy(d_act0, A.act, M); dcopy(d_z0, A.z, n);
+        part_factor = true;            // the factor in d_S belongs to the partition: the first dual / primal round below re-use it
+        // ---- dual: basic least-squares multipliers on the partition, sign repair (oracle: face_dual; independent of the primal
+        // stage, run first so that its round 0 and the primal round 0 share the factorisation of the projection above)
+        bool okd = false;
+        as_copy_sets(5, 3);
+        for (int r = 0; r < FACE_BULK; ++r) {
+            as_solve(S_[5], nullptr, nullptr, 2, r == 0);
+            hipLaunchKernelGGL(k_face_dual_finish, dim3(1), dim3(1024), 0, h->stream, A, S_[5], FACE_TOL_M);
+            as_read();
+            if (h->verbose) std::fprintf(stderr, "[asm] face dual %d: nH %d nF %d viol %d\n", r, as_nH, as_nF, h->h_ascnt[AC_NVIOL]);
+            if (h->h_ascnt[AC_NVIOL] == 0) { okd = true; break; }
+        }
+        if (okd) { dcopy(d_yf, A.y, M); dcopy(d_zf, A.z, n); }
         // ---- primal: bulk rounds
         bool okp = false;
-        as_copy_sets(4, 3);
-        for (int r = 0; r < FACE_BULK; ++r) {
-            as_solve(S_[4], nullptr, nullptr, 1);
-            hipLaunchKernelGGL(k_face_primal_finish, dim3(1), dim3(1024), 0, h->stream, A, S_[4], S_[3], TOL_P, FACE_TOL_M, 0);
-            as_read();
-            if (h->verbose) std::fprintf(stderr, "[asm] face primal bulk %d: nH %d nF %d viol %d rel %d hres %.2e\n", r, as_nH, as_nF, h->h_ascnt[AC_NVIOL], h->h_ascnt[AC_NREL], h->h_asscal[AS_HARDRES]);
-            if (h->h_asscal[AS_HARDRES] > TOL_P) break;            // over-determined working set
-            if (h->h_ascnt[AC_NVIOL] > 0) continue;
-            if (h->h_ascnt[AC_NREL] == 0) { okp = true; break; }
-        }
-        // ---- primal: anchored method in the null space of the partition (oracle: _face_primal_anchored) - one factorisation,
-        // one solve with it per added constraint, the k x k matrix Z'Z of the added constraints on the host
-        if (!okp && face_primal_anchored()) {
-            // the answer is the least-norm point of the FINAL working set, computed like any other (fresh factorisation)
-            as_solve(S_[4], nullptr, nullptr, 1);
-            hipLaunchKernelGGL(k_face_primal_finish, dim3(1), dim3(1024), 0, h->stream, A, S_[4], S_[3], TOL_P, FACE_TOL_M, 1);
-            as_read();
-            okp = h->h_asscal[AS_HARDRES] <= TOL_P && h->h_ascnt[AC_NVIOL] == 0;
-        }
-        bool okd = false;
-        if (okp) {
-            dcopy(d_pf, A.p, n); dcopy(d_sf, A.s, ns); dcopy(d_actf, A.act, M);
-            as_copy_sets(5, 3);
+        if (okd) {
+            as_copy_sets(4, 3);
             for (int r = 0; r < FACE_BULK; ++r) {
-                as_solve(S_[5], nullptr, nullptr, 2);
-                hipLaunchKernelGGL(k_face_dual_finish, dim3(1), dim3(1024), 0, h->stream, A, S_[5], FACE_TOL_M);
+                as_solve(S_[4], nullptr, nullptr, 1, r == 0);
+                hipLaunchKernelGGL(k_face_primal_finish, dim3(1), dim3(1024), 0, h->stream, A, S_[4], S_[3], TOL_P, FACE_TOL_M, 0);
                 as_read();
-                if (h->verbose) std::fprintf(stderr, "[asm] face dual %d: nH %d nF %d viol %d\n", r, as_nH, as_nF, h->h_ascnt[AC_NVIOL]);
-                if (h->h_ascnt[AC_NVIOL] == 0) { okd = true; break; }
+                if (h->verbose) std::fprintf(stderr, "[asm] face primal bulk %d: nH %d nF %d viol %d rel %d hres %.2e\n", r, as_nH, as_nF, h->h_ascnt[AC_NVIOL], h->h_ascnt[AC_NREL], h->h_asscal[AS_HARDRES]);
+                if (h->h_asscal[AS_HARDRES] > TOL_P) break;            // over-determined working set
+                if (h->h_ascnt[AC_NVIOL] > 0) continue;
+                if (h->h_ascnt[AC_NREL] == 0) { okp = true; break; }
+            }
+            // ---- primal: anchored method in the null space of the partition (oracle: _face_primal_anchored) - one factorisation,
+            // one solve with it per added constraint, the k x k matrix Z'Z of the added constraints on the host
+            if (!okp && face_primal_anchored()) {
+                // the answer is the least-norm point of the FINAL working set, computed like any other (fresh factorisation)
+                as_solve(S_[4], nullptr, nullptr, 1);
+                hipLaunchKernelGGL(k_face_primal_finish, dim3(1), dim3(1024), 0, h->stream, A, S_[4], S_[3], TOL_P, FACE_TOL_M, 1);
+                as_read();
+                okp = h->h_asscal[AS_HARDRES] <= TOL_P && h->h_ascnt[AC_NVIOL] == 0;
             }
         }
+        part_factor = false;
         if (okp && okd) {
-            dcopy(A.p, d_pf, n); dcopy(A.s, d_sf, ns); dcopy(A.act, d_actf, M);
+            dcopy(A.y, d_yf, M); dcopy(A.z, d_zf, n);      // (p, s, act) are the primal stage's last solve; y, z come from the dual stage
             hipLaunchKernelGGL(k_face_kkt, dim3(1), dim3(1024), 0, h->stream, A, S_[5]);
             as_read();
             h->stats.kkt_pr = h->h_asscal[AS_PR];
@@ -1699,7 +1708,7 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
         }
         HIPCHK(hipMemcpy(h->d_ipm_i, iv.data(), iv.size() * sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(hipHostMalloc((void**)&h->h_scal, 64 * sizeof(double)));
-        const int64_t nas = 16 * h->ldn + 16 * h->Mp + 4 * h->nsp + 64, nasi = 6 * (h->Mp + h->ldn + h->nsp) + 3 * h->Mp + 2 * h->ldn + 64;
+        const int64_t nas = 17 * h->ldn + 17 * h->Mp + 4 * h->nsp + 64, nasi = 6 * (h->Mp + h->ldn + h->nsp) + 3 * h->Mp + 2 * h->ldn + 64;
         dmalloc(&h->d_as, nas);
         HIPCHK(hipMemsetAsync(h->d_as, 0, nas * sizeof(double), h->stream));
         dmalloc(&h->d_as_i, nasi);
@@ -1911,7 +1920,7 @@ int asm_create(int device, asm_handle** out) {
     std::memset(&h->kstats, 0, sizeof(h->kstats));
     std::memset(&h->stats, 0, sizeof(h->stats));
     const char* tm = std::getenv("ASM_HIP_TIMING");
-    h->timing = !(tm && tm[0] == '0');
+    h->timing = (tm && tm[0] >= '0' && tm[0] <= '2') ? tm[0] - '0' : 1;
     const char* vb = std::getenv("ASM_HIP_VERBOSE");
     h->verbose = vb && vb[0] == '1';
     const char* fp = std::getenv("ASM_HIP_FUSED_PANEL");

@@ -67,7 +67,7 @@ WORKLOADS = {
     # name: (description, default algorithm, default steps, default warmup)
     "c4": dict(desc="ACOPF case1354pegase-sized synthetic grid (1354 bus / 260 gen / 1991 branch; BASELINE.json configs[3], "
                     "the case the metric is quoted on; real case file not shipped with the reference), n=11192 m=18637",
-               algorithm="Line Search", steps=3, warmup=1),
+               algorithm="Line Search", steps=20, warmup=2),
     "c5": dict(desc="batch of scenario ACOPF, case300-sized synthetic grid (300 bus / 69 gen / 411 branch), load_scale 0.5, loads x U(0.9,1.1) per "
                     "scenario (BASELINE.json configs[4] has 512 scenarios over 8 GPUs = 64 per GPU; --scenarios-per-gpu sets the share), "
                     "n=2382 m=3889; one step = one complete scenario solve",
@@ -165,6 +165,7 @@ def run_steps(pr, algorithm, device, n_steps, state):
         done += slp.lp_solves - before
         if slp.lp_solves < target:                      # the SLP run terminated: restart from x0
             state["restarts"] = state.get("restarts", 0) + 1
+            state.setdefault("terminations", []).append(int(slp.ret))
             state["slp"] = None
     return done
 
@@ -177,26 +178,39 @@ def _cores():
         return HOST_THREADS
 
 
-def highs_baseline(lp):
-    """Independent third-party CPU LP code on the identical first sub-LP: SciPy's HiGHS dual simplex on
-    the sparse form, cold start, one thread.  Not the reference's GLPK (absent here) - an orientation figure only."""
+def highs_sequence(pr, timed, budget_s):
+    """Independent third-party CPU LP code on the SEQUENCE of sub-LPs the timed GPU steps solved: for every
+    timed step, in order, the LP is rebuilt at that step's iterate (oracle/sparse_lp.py: the sparse statement of
+    subproblem.jl:229-484, normal or restoration phase as the step had it) and solved by SciPy's HiGHS dual simplex, cold
+    start, one thread, until the time budget is spent.  This is the natural CPU method for these LPs (a sparse simplex, as
+    the reference's GLPK) - but not GLPK itself (absent here) and without GLPK's retained-basis warm start (linprog has none)."""
     try:
-        import numpy as np, scipy.sparse as sp
-        from scipy.optimize import linprog
-        A = sp.csr_matrix(lp.A)
-        eq, ge, le = lp.rtype == 0, lp.rtype == 1, lp.rtype == -1
-        A_ub = sp.vstack([-A[ge], A[le]]).tocsr()
-        b_ub = np.concatenate([-lp.r[ge], lp.r[le]])
-        t0 = time.perf_counter()
-        res = linprog(lp.q, A_ub=A_ub, b_ub=b_ub, A_eq=A[eq], b_eq=lp.r[eq], bounds=np.c_[lp.lb, lp.ub], method="highs-ds")
-        dt = time.perf_counter() - t0
-        return dict(lp_solves_per_s=1.0 / dt, seconds=dt, status=int(res.status), simplex_iterations=int(res.nit),
-                    note="scipy.optimize.linprog(method='highs-ds') on the first normal-phase sub-LP of the workload (sparse, cold start, 1 thread)")
+        import numpy as np
+        from oracle import sparse_lp
+        t_tot, n_done, n_fr, mism, its = 0.0, 0, 0, 0, 0
+        for rec in timed:
+            if t_tot >= budget_s:
+                break
+            x = np.asarray(rec["x"], float)
+            lp = sparse_lp.build(pr.n, pr.m, pr.j_row, pr.j_col, pr.eval_jac_g(x, np.zeros(pr.nnz)), pr.eval_grad_f(x, np.zeros(pr.n)),
+                                 pr.eval_g(x, np.zeros(pr.m)), pr.g_L, pr.g_U, pr.x_L, pr.x_U, x, rec["delta"], rec["fr"])
+            st, obj, p, dt, nit = sparse_lp.solve_highs(lp)
+            t_tot += dt
+            n_done += 1
+            n_fr += 1 if rec["fr"] else 0
+            its += nit
+            mism += 1 if st != rec["status"] else 0
+        if n_done == 0:
+            return dict(error="no timed step")
+        return dict(value=n_done / t_tot, unit="iter/s", cores=1, lp_solved=n_done, restoration_lps=n_fr, seconds=t_tot,
+                    simplex_iterations=its, status_mismatches_vs_gpu=mism,
+                    note="scipy.optimize.linprog(method='highs-ds') on the sub-LPs of the first %d timed steps (their iterates, radius and phase), "
+                         "sparse, cold start, 1 thread; LP solve time only" % n_done)
     except Exception as e:                                   # SciPy missing or HiGHS failure: report, do not fail the bench
         return dict(error=repr(e))
 
 
-def cpu_baseline(pr, algorithm, budget_s, mix):
+def cpu_baseline(pr, algorithm, budget_s, mix, timed):
     """Oracle (NumPy restatement of the same path) on a bounded sample of the same workload.
     Small NLPs: whole SLP iterations from x0.  Large NLPs (one LP would take minutes on the host): single
     interior-point iterations of the oracle are timed in both forms of the Newton system and priced with the mix of
@@ -224,8 +238,9 @@ def cpu_baseline(pr, algorithm, budget_s, mix):
         qp = QpModel(QpData(pr.eval_grad_f(x, np.zeros(pr.n)), pr.eval_f(x), A, pr.eval_g(x, np.zeros(pr.m)), pr.g_L, pr.g_U, pr.x_L, pr.x_U, st),
                      pr.j_row, pr.j_col)
         return dict(value=steps / t_total, unit="iter/s", cores=cores, kind="port",
-                    sample="oracle SLP (%s) from x0, first %d SLP iterations of the same NLP, %.1f s" % (algorithm, steps, t_total),
-                    highs=highs_baseline(qp.build_lp(x, 1000.0 if algorithm == "Line Search" else 0.4, False)))
+                    sample="oracle (NumPy restatement of the same dense algorithm) SLP (%s) from x0, first %d SLP iterations of the same NLP, %.1f s"
+                           % (algorithm, steps, t_total),
+                    highs_sequence=highs_sequence(pr, timed, budget_s))
     # large NLPs: one oracle LP takes many minutes.  Time single interior-point iterations of the oracle in the two forms the
     # solver uses - the M x M row form on the first (normal-phase) sub-LP, the n x n column form on the restoration LP at
     # the same point - and price the GPU run's own mix of iterations with them (active-set solves by their cubic size ratio).
@@ -260,12 +275,12 @@ def cpu_baseline(pr, algorithm, budget_s, mix):
     eqp_cost = t_row * 0.2                      # an active-set factorisation has ~0.58 M rows: 0.58^3
     step_s = t_setup + (mix["row_iters"] * t_row + mix["col_iters"] * t_col + mix["eqp"] * eqp_cost) / max(mix["steps"], 1)
     return dict(value=1.0 / step_s, unit="iter/s", cores=cores, kind="port",
-                sample="oracle: assembly+formulation+scaling of the first sub-LP (%.1f s), %d row-form interior-point iterations of it (%.1f s each) and "
+                sample="oracle (NumPy restatement of the same dense algorithm): assembly+formulation+scaling of the first sub-LP (%.1f s), %d row-form interior-point iterations of it (%.1f s each) and "
                        "%d column-form iterations of the restoration LP at the same point (%.1f s each), priced with the GPU run's own mix per SLP "
                        "step: %.1f row-form + %.1f column-form iterations + %.1f active-set solves (0.2 row-form iterations each)"
                        % (t_setup, n_row, t_row, n_col, t_col, mix["row_iters"] / max(mix["steps"], 1), mix["col_iters"] / max(mix["steps"], 1),
                           mix["eqp"] / max(mix["steps"], 1)),
-                highs=highs_baseline(lp))
+                highs_sequence=highs_sequence(pr, timed, budget_s))
 
 
 def launch_ranks(n, argv, script=None):
@@ -313,6 +328,8 @@ def main():
     ap.add_argument("--max-iter", type=int, default=100, help="workload c5: SLP iteration cap per scenario")
     ap.add_argument("--concurrency", type=int, default=3, help="workload c5: scenarios in flight per GPU (one handle / HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-breakdown", action="store_true",
+                    help="time every kernel family with HIP events (adds kernels_ms; default: only the dominant kernel, k_syrk, is timed)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
@@ -328,6 +345,9 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # HIP-event timing inside the library: 1 = the dominant kernel only (two events per k_syrk launch, on the stream it is
+    # launched on), 2 = every kernel family (perturbs the latency-bound small workloads)
+    os.environ.setdefault("ASM_HIP_TIMING", "2" if args.kernel_breakdown else "1")
     if args.workload == "c5":
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # one hardware queue per concurrent scenario stream (ROCm default: 4)
     import torch
@@ -375,25 +395,19 @@ def main():
 
     ks = opt.kernel_stats()
     trace = state.get("trace_all", [])
-    # dominant kernel: single-kernel families only (chol/trsv/syrk are multi-launch regions that contain them)
-    single = {k: v for k, v in ks.items() if k in ("assemble", "scale", "gemv", "syrk_kernel")}
-    dom = max(single, key=lambda k: single[k]["ms"])
-    d = ks[dom]
-    if dom == "syrk_kernel":
-        dom = "k_syrk<T> (f64 MFMA rank-K update: Schur builds + Cholesky trailing updates)"
-        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-        roof = dict(bound="mfma", kernel=dom, regions_tflops={k: (ks[k]["flops"] / (ks[k]["ms"] * 1e-3) / 1e12 if ks[k]["ms"] > 0 else 0.0)
-                                                              for k in ("syrk", "chol")}, achieved=ach, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=ach / FP64_MFMA_PEAK_TFLOPS, traffic=None,
-                    avg_launch_ms=d["ms"] / max(d["calls"], 1), launches=d["calls"])
-    else:
-        ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
-        roof = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                    traffic=None, avg_launch_ms=d["ms"] / max(d["calls"], 1), launches=d["calls"])
+    # roofline of the dominant kernel: k_syrk<T> (Schur builds + Cholesky trailing updates), every launch timed with HIP events
+    d = ks["syrk_kernel"]
+    ach = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+    roof = dict(bound="mfma", kernel="k_syrk<T> (f64 MFMA rank-K update: Schur builds + Cholesky trailing updates)", achieved=ach,
+                peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP64_MFMA_PEAK_TFLOPS, traffic=None,
+                avg_launch_ms=d["ms"] / max(d["calls"], 1), launches=d["calls"],
+                share_of_step_time=d["ms"] / (1e3 * elapsed) if elapsed > 0 else None)
+    if args.kernel_breakdown:
+        roof["regions_tflops"] = {k: (ks[k]["flops"] / (ks[k]["ms"] * 1e-3) / 1e12 if ks[k]["ms"] > 0 else 0.0) for k in ("syrk", "chol")}
 
     nfact = ks["chol"]["calls"]
     # HBM bytes per launch of the dominant kernel from the committed PMC passes (cannot be collected inside bench)
-    tpath = os.path.join(ROOT, "profiles", "r01_%s_pmc_traffic.json" % args.workload)
+    tpath = os.path.join(ROOT, "profiles", "r02_%s_pmc_traffic.json" % args.workload)
     if roof["bound"] == "mfma" and os.path.exists(tpath):
         tj = json.load(open(tpath))
         roof["traffic"] = tj["traffic_bytes_per_launch"]
@@ -409,16 +423,28 @@ def main():
                        "parallelism": "replicas x%d" % world, "restarts": state.get("restarts", 0),
                        "factorisations_per_step": nfact / max(args.steps, 1)},
             "roofline": roof,
-            "kernels_ms": {k: round(v["ms"], 3) for k, v in ks.items()},
         }
+        if args.kernel_breakdown:
+            out["kernels_ms"] = {k: round(v["ms"], 3) for k, v in ks.items()}
+        timed = trace[-args.steps:] if trace else []
+        names = {0: "warm", 1: "ipm0+ln", 2: "ipm1+ln", 3: "ipm2+ln", 4: "ipm+face", 5: "ipm-unpolished", 6: "ipm-infeasible",
+                 7: "phase1-infeasible", 8: "ipm~+ln", 9: "ipm+ref"}
+        hist = {}
+        for r in timed:
+            key = names.get(r["stats"]["path"], str(r["stats"]["path"])) + ("/fr" if r["fr"] else "")
+            hist[key] = hist.get(key, 0) + 1
+        out["lp_outcomes"] = {"paths": hist, "unpolished": sum(1 for r in timed if r["stats"]["polished"] != 1),
+                              "status_other": sum(1 for r in timed if r["status"] not in (1, 2)),
+                              "restoration_lps": sum(1 for r in timed if r["fr"]),
+                              "slp_status_last": int(state["slp"].ret) if state.get("slp") is not None else None,
+                              "slp_terminations": state.get("terminations", [])}
         if not args.no_cpu_baseline and world == 1:
-            timed = trace[-args.steps:] if trace else []
             mix = dict(steps=args.steps, col_iters=sum(r["stats"].get("col_iters", 0) for r in timed),
                        row_iters=sum(r["stats"]["ipm_iters"] - r["stats"].get("col_iters", 0) for r in timed),
                        eqp=sum(r["stats"]["eqp"] for r in timed))
             if not timed:
                 mix = dict(steps=args.steps, col_iters=0, row_iters=nfact, eqp=0)
-            out["cpu_baseline"] = cpu_baseline(pr, args.algorithm, args.cpu_seconds, mix)
+            out["cpu_baseline"] = cpu_baseline(pr, args.algorithm, args.cpu_seconds, mix, timed)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

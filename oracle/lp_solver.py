@@ -915,8 +915,8 @@ def face_polish(lp, part, p_ref, y_ref, stats):
     pr, du = kkt_measures(lp, p0, s0, y0, part)
     if not (pr <= TOL_P and du <= TOL_D):
         return None, p0, s0, y0, part
-    okp, p, s, sets_p = face_primal(lp, part, (p0, s0), stats)
-    okd, y, sets_d = face_dual(lp, part, stats) if okp else (False, y0, part)
+    okd, y, sets_d = face_dual(lp, part, stats)                 # (independent of the primal stage; first, so that an implementation
+    okp, p, s, sets_p = face_primal(lp, part, (p0, s0), stats) if okd else (False, p0, s0, part)   # can share the partition's factor)
     if okp and okd:
         pr, _ = kkt_measures(lp, p, s, y, sets_p)
         _, du = kkt_measures(lp, p, s, y, sets_d)

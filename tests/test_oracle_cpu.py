@@ -206,3 +206,27 @@ def test_newton_system_forms_agree():
     assert all(np.array_equal(x, y) for x, y in zip(a[6]['sets'], b[6]['sets']))
     assert np.abs(a[0] - b[0]).max() < 1e-9 and np.abs(a[1] - b[1]).max() < 1e-8
     assert a[6]['stats']['red_iters'] > 0, a[6]['stats']
+
+
+@pytest.mark.parametrize("seed,infeasible", [(11, False), (12, True), (13, True)])
+def test_sparse_lp_statement_agrees_with_oracle_and_highs(seed, infeasible):
+    """oracle/sparse_lp.py (the sparse statement handed to HiGHS by bench.py's cpu_baseline) poses the same LP as the
+    oracle's dense build_lp: same status, same optimal value in the normal and the restoration phase - HiGHS (an
+    independent LP code) and the oracle's own solver agree on it."""
+    from oracle import sparse_lp
+    from tests.util import random_subproblem, oracle_solve
+    sp = random_subproblem(seed, 40, 30, 0.3, 0.2, 3, infeasible=infeasible)
+    qp, out = oracle_solve(sp)
+    lp = sparse_lp.build(sp['n'], sp['m'], sp['j_row'], sp['j_col'], sp['dE'], sp['df'], sp['E'], sp['c_lb'], sp['c_ub'], sp['v_lb'], sp['v_ub'],
+                         sp['x_k'], sp['delta'], False)
+    st, obj, p, _, _ = sparse_lp.solve_highs(lp)
+    assert st == out[5]
+    if st == 1:
+        assert abs(obj - sp['df'] @ out[0]) <= 1e-9 * max(1.0, abs(obj))
+    else:
+        qp, out = oracle_solve(sp, True, qp)
+        lp = sparse_lp.build(sp['n'], sp['m'], sp['j_row'], sp['j_col'], sp['dE'], sp['df'], sp['E'], sp['c_lb'], sp['c_ub'], sp['v_lb'], sp['v_ub'],
+                             sp['x_k'], sp['delta'], True)
+        st, obj, p, _, _ = sparse_lp.solve_highs(lp)
+        assert st == out[5] == 1
+        assert abs(obj - sum(sum(v) for v in out[4].values())) <= 1e-8 * max(1.0, abs(obj))
