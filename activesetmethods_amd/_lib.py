@@ -41,6 +41,13 @@ PROTOTYPES = {
     "asm_kernel_stats_reset": (C.c_int, [_P]),
     "asm_kt_residuals": (C.c_int, [_P, _D, _D, _D, _D, _D]),
     "asm_jac_row_norms": (C.c_int, [_P, _D]),
+    "asm_eval_setup": (C.c_int, [_P, C.c_int64, _I64, _I64, _D, _I64, _I64, _I64, _D, _D, _I64, _I64, _I64, _D, _I64, C.c_double, C.c_int,
+                                 C.c_int64, C.c_int64, _I64, C.c_int64, _D, C.c_int64]),
+    "asm_eval_functions": (C.c_int, [_P, _D, _D, _D, _D]),
+    "asm_eval_constraints": (C.c_int, [_P, _D, _D, _D]),
+    "asm_eval_jacobian_values": (C.c_int, [_P, _D]),
+    "asm_slp_norms": (C.c_int, [_P, _D, _D, _D, _D]),
+    "asm_slp_merit": (C.c_int, [_P, C.c_int, C.c_double, _D, _D, _D, C.c_int, C.c_double, _D]),
     "asm_test_syrk": (C.c_int, [_P, _D, C.c_int64, C.c_int64, _I32, C.c_int64, _D, _D, _D, C.c_int]),
     "asm_test_cholesky": (C.c_int, [_P, _D, C.c_int64, _D]),
     "asm_test_chol_solve": (C.c_int, [_P, _D, C.c_int64, _D, _D]),

@@ -318,6 +318,77 @@ class AcopfModel:
         return v
 
 
+def function_model(case):
+    """The same polar ACOPF as a FunctionModel (moi_evaluator.py), i.e. the way the reference receives it: affine and quadratic
+    scalar functions in the wrapper's six lists (angle differences linear <= / >=; reference angle, dc-line loss and the nodal
+    balances of buses without shunt linear ==; thermal limits quadratic <=; balances of buses with a shunt quadratic ==) and
+    Ohm's law as the NLP block (src/MOI_wrapper.jl:683-689).  Rows and pattern come out in the wrapper's order, which is a
+    permutation of `AcopfModel`'s; the NLP block carries the parameters of its device kernel (csrc/asm_eval_kernels.hip.h)."""
+    from .moi_evaluator import FunctionModel, ScalarFunction, NlpBlock
+    mdl = AcopfModel(case)
+    c = case
+    V = lambda idx: int(idx) + 1                       # 1-based variable index
+    fm = FunctionModel(mdl.n, mdl.x_L, mdl.x_U)
+    fm.start = {j + 1: float(v) for j, v in enumerate(mdl.x0)}          # init_opf.jl midpoint start as VariablePrimalStart
+    f, t = c["f_bus"], c["t_bus"]
+    for l in range(mdl.nl):
+        fm.add_constraint(ScalarFunction(0.0, [(1.0, V(mdl.va[f[l]])), (-1.0, V(mdl.va[t[l]]))]), "le", c["angmax"][l])
+    for l in range(mdl.nl):
+        fm.add_constraint(ScalarFunction(0.0, [(1.0, V(mdl.va[f[l]])), (-1.0, V(mdl.va[t[l]]))]), "ge", c["angmin"][l])
+    for b in c["ref"]:
+        fm.add_constraint(ScalarFunction(0.0, [(1.0, V(mdl.va[b]))]), "eq", 0.0)
+    for k in range(mdl.nd):
+        fm.add_constraint(ScalarFunction(0.0, [(1.0 - c["dc_loss1"][k], V(mdl.pdf[k])), (1.0, V(mdl.pdt[k]))]), "eq", c["dc_loss0"][k])
+    for l in mdl.lim:
+        fm.add_constraint(ScalarFunction(0.0, [], [(2.0, V(mdl.pf[l]), V(mdl.pf[l])), (2.0, V(mdl.qf[l]), V(mdl.qf[l]))]), "le", c["rate_a"][l] ** 2)
+    for l in mdl.lim:
+        fm.add_constraint(ScalarFunction(0.0, [], [(2.0, V(mdl.pt[l]), V(mdl.pt[l])), (2.0, V(mdl.qt[l]), V(mdl.qt[l]))]), "le", c["rate_a"][l] ** 2)
+    gens_at = [[] for _ in range(mdl.nb)]
+    for g, b in enumerate(c["gen_bus"]):
+        gens_at[b].append(g)
+    fr_at = [[] for _ in range(mdl.nb)]; to_at = [[] for _ in range(mdl.nb)]
+    for l in range(mdl.nl):
+        fr_at[f[l]].append(l); to_at[t[l]].append(l)
+    dcf_at = [[] for _ in range(mdl.nb)]; dct_at = [[] for _ in range(mdl.nb)]
+    for k in range(mdl.nd):
+        dcf_at[c["dc_f"][k]].append(k); dct_at[c["dc_t"][k]].append(k)
+    for (gv, fv, tv, dfv, dtv, shunt, rhs) in ((mdl.pg, mdl.pf, mdl.pt, mdl.pdf, mdl.pdt, -2.0 * c["gs"], c["pd"]),
+                                               (mdl.qg, mdl.qf, mdl.qt, mdl.qdf, mdl.qdt, 2.0 * c["bs"], c["qd"])):
+        for b in range(mdl.nb):
+            aff = [(1.0, V(gv[g])) for g in gens_at[b]] + [(-1.0, V(fv[l])) for l in fr_at[b]] + [(-1.0, V(tv[l])) for l in to_at[b]]
+            aff += [(-1.0, V(dfv[k])) for k in dcf_at[b]] + [(-1.0, V(dtv[k])) for k in dct_at[b]]
+            quad = [(float(shunt[b]), V(mdl.vm[b]), V(mdl.vm[b]))] if (c["gs"][b] != 0 or c["bs"][b] != 0) else []
+            fm.add_constraint(ScalarFunction(0.0, aff, quad), "eq", rhs[b])
+    fm.objective = ScalarFunction(float(np.sum(c["cost0"])), [(float(c["cost1"][g]), V(mdl.pg[g])) for g in range(mdl.ng)],
+                                  [(2.0 * float(c["cost2"][g]), V(mdl.pg[g]), V(mdl.pg[g])) for g in range(mdl.ng) if c["cost2"][g] != 0.0])
+    # ---- NLP block: Ohm's law, rows pfr | qfr | pto | qto, pattern in 4 groups x 5 sub-blocks of n_branch
+    nl = mdl.nl
+    rows, cols = [], []
+    for g, pv in enumerate((mdl.pf, mdl.qf, mdl.pt, mdl.qt)):
+        r = np.arange(g * nl, (g + 1) * nl) + 1
+        for cc in (pv, mdl.vm[f], mdl.vm[t], mdl.va[f], mdl.va[t]):
+            rows.append(r); cols.append(np.asarray(cc) + 1)
+    r0 = mdl.r_pfr[0]
+    j0 = len(mdl.j_row) - 20 * nl
+
+    def eval_g(x, out):
+        full = mdl.eval_g(x, np.zeros(mdl.m))
+        out[:] = full[r0:]
+        return out
+
+    def eval_jac_g(x, out):
+        full = mdl.eval_jac_g(x, np.zeros(len(mdl.j_row)))
+        out[:] = full[j0:]
+        return out
+    ipar = np.concatenate([[nl, mdl.va[0], mdl.vm[0], mdl.pf[0] if nl else 0, mdl.pt[0] if nl else 0, mdl.qf[0] if nl else 0, mdl.qt[0] if nl else 0],
+                           f, t]).astype(np.int64)
+    dpar = np.concatenate([mdl.k_ff_p, mdl.k_ff_q, mdl.k_tt_p, mdl.k_tt_q, mdl.a_f, mdl.b_f, mdl.a_t, mdl.b_t]).astype(np.float64)
+    fm.nlp = NlpBlock(np.zeros(4 * nl), np.zeros(4 * nl), np.concatenate(rows), np.concatenate(cols), eval_g, eval_jac_g,
+                      device=("acopf_ohm", ipar, dpar))
+    fm.acopf_model = mdl
+    return fm
+
+
 def acopf_problem(case, name="acopf"):
     mdl = AcopfModel(case)
     pr = Problem(name, mdl.n, mdl.m, mdl.x_L, mdl.x_U, mdl.g_L, mdl.g_U, mdl.j_row, mdl.j_col, mdl.x0,

@@ -1,0 +1,213 @@
+// Device-side evaluation of the functions the SLP hot path consumes (eval_functions!, src/algorithms/slp.jl:186-191):
+//   * the affine / quadratic evaluator of the MOI wrapper (src/MOI_wrapper.jl:776-944) on a flattened function store -
+//     term by term in the reference's order, with explicit round-to-nearest multiplies and adds (no fused multiply-add),
+//     so that values, gradient and Jacobian entries are BIT-IDENTICAL to the host restatement
+//     (activesetmethods_amd/moi_evaluator.py);
+//   * two NLP-block kernels: Ohm's-law rows of the polar ACOPF model (test/opf.jl:6-10) and the dense quadratic rows of the
+//     synthetic NLP of BASELINE.json configs[1];
+//   * the per-iteration reductions of the SLP callers (KT_residuals, norm_violations, norm_complementarity: common.jl:35-98;
+//     compute_phi, compute_derivative: slp.jl:79-147) on the evaluation results already in HBM.
+// Jacobian values are written straight into the handle's `dE` buffer in j_str order: they never cross PCIe.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct FnStore {
+    int64_t n_rows, n;
+    const int64_t *aff_ptr, *aff_var, *quad_ptr, *q_v1, *q_v2, *jac_off, *g_ptr, *g_kind, *g_other;
+    const double *aff_coef, *q_coef, *constant, *g_coef;
+    double objective_scale;
+};
+
+// eval_function (MOI_wrapper.jl:780-807) of row r
+// (`#pragma clang fp contract(off)` + plain operators: hipcc would otherwise fuse a * b + c into one fma - one rounding instead
+// of the reference's two; the __dmul_rn / __dadd_rn spellings do not prevent that, their bodies are inlined with contraction on)
+__device__ __forceinline__ double fn_value(const FnStore& F, int64_t r, const double* __restrict__ x) {
+#pragma clang fp contract(off)
+    double v = F.constant[r];
+    for (int64_t k = F.aff_ptr[r]; k < F.aff_ptr[r + 1]; ++k) { const double t = F.aff_coef[k] * x[F.aff_var[k]]; v = v + t; }
+    for (int64_t k = F.quad_ptr[r]; k < F.quad_ptr[r + 1]; ++k) {
+        const int64_t a = F.q_v1[k], b = F.q_v2[k];
+        const double c = F.q_coef[k];
+        const double t = a == b ? ((0.5 * c) * x[a]) * x[b] : (c * x[a]) * x[b];
+        v = v + t;
+    }
+    return v;
+}
+// eval_constraint + eval_constraint_jacobian of the affine / quadratic rows (MOI_wrapper.jl:875-944): one thread per row
+__global__ __launch_bounds__(256) void k_fn_rows(FnStore F, const double* __restrict__ x, double* __restrict__ E, double* __restrict__ dE,
+                                                 int write_jac) {
+#pragma clang fp contract(off)
+    int64_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= F.n_rows) return;
+    E[r] = fn_value(F, r, x);
+    if (!write_jac) return;
+    int64_t o = F.jac_off[r];
+    for (int64_t k = F.aff_ptr[r]; k < F.aff_ptr[r + 1]; ++k) dE[o++] = F.aff_coef[k];
+    for (int64_t k = F.quad_ptr[r]; k < F.quad_ptr[r + 1]; ++k) {
+        const int64_t a = F.q_v1[k], b = F.q_v2[k];
+        const double c = F.q_coef[k];
+        dE[o++] = c * x[b];
+        if (a != b) dE[o++] = c * x[a];
+    }
+}
+// eval_objective (one thread: the sum is sequential in the reference) and its sense scale (MOI_wrapper.jl:1046-1049)
+__global__ void k_fn_objective(FnStore F, const double* __restrict__ x, double* __restrict__ f_out) {
+#pragma clang fp contract(off)
+    if (threadIdx.x == 0 && blockIdx.x == 0) f_out[0] = F.objective_scale * fn_value(F, F.n_rows, x);
+}
+// fill_gradient! (MOI_wrapper.jl:827-850): one thread per variable sums its contributions in term order
+__global__ __launch_bounds__(256) void k_fn_gradient(FnStore F, const double* __restrict__ x, double* __restrict__ df) {
+#pragma clang fp contract(off)
+    int64_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= F.n) return;
+    double g = 0.0;
+    for (int64_t k = F.g_ptr[j]; k < F.g_ptr[j + 1]; ++k)
+        { const double t = F.g_kind[k] == 0 ? F.g_coef[k] : F.g_coef[k] * x[F.g_other[k]]; g = g + t; }
+    df[j] = g * F.objective_scale;
+}
+
+// ---- NLP block 1: Ohm's law of the polar ACOPF (activesetmethods_amd/acopf.py: _flows, eval_g, eval_jac_g).
+// ipar: [nl, va0, vm0, pf0, pt0, qf0, qt0, then f_bus[nl], t_bus[nl]] ; dpar: 10 coefficient arrays of length nl
+// (k_ff_p, k_ff_q, k_tt_p, k_tt_q, a_f, b_f, a_t, b_t).  Rows: pfr, qfr, pto, qto (nl each) from row r0; Jacobian values from
+// j0 in 4 groups x 5 sub-blocks of nl (d/d flow variable, vm_f, vm_t, va_f, va_t).
+__global__ __launch_bounds__(256) void k_nlp_acopf_ohm(const int64_t* __restrict__ ipar, const double* __restrict__ dpar,
+                                                       const double* __restrict__ x, double* __restrict__ E, double* __restrict__ dE,
+                                                       int64_t r0, int64_t j0, int write_jac) {
+    const int64_t nl = ipar[0];
+    int64_t l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= nl) return;
+    const int64_t va0 = ipar[1], vm0 = ipar[2], pf0 = ipar[3], pt0 = ipar[4], qf0 = ipar[5], qt0 = ipar[6];
+    const int64_t fb = ipar[7 + l], tb = ipar[7 + nl + l];
+    const double kffp = dpar[l], kffq = dpar[nl + l], kttp = dpar[2 * nl + l], kttq = dpar[3 * nl + l];
+    const double af = dpar[4 * nl + l], bf = dpar[5 * nl + l], at = dpar[6 * nl + l], bt = dpar[7 * nl + l];
+    const double vf = x[vm0 + fb], vt = x[vm0 + tb];
+    const double d = x[va0 + fb] - x[va0 + tb];
+    const double cs = cos(d), sn = sin(d);
+    const double vv = vf * vt;
+    const double pfr = kffp * vf * vf + af * vv * cs + bf * vv * sn;
+    const double qfr = kffq * vf * vf - bf * vv * cs + af * vv * sn;
+    const double pto = kttp * vt * vt + at * vv * cs - bt * vv * sn;
+    const double qto = kttq * vt * vt - bt * vv * cs - at * vv * sn;
+    E[r0 + l] = x[pf0 + l] - pfr;
+    E[r0 + nl + l] = x[qf0 + l] - qfr;
+    E[r0 + 2 * nl + l] = x[pt0 + l] - pto;
+    E[r0 + 3 * nl + l] = x[qt0 + l] - qto;
+    if (!write_jac) return;
+    const double dvf[4] = {2 * kffp * vf + af * vt * cs + bf * vt * sn, 2 * kffq * vf - bf * vt * cs + af * vt * sn,
+                           at * vt * cs - bt * vt * sn, -bt * vt * cs - at * vt * sn};
+    const double dvt[4] = {af * vf * cs + bf * vf * sn, -bf * vf * cs + af * vf * sn, 2 * kttp * vt + at * vf * cs - bt * vf * sn,
+                           2 * kttq * vt - bt * vf * cs - at * vf * sn};
+    const double dth[4] = {-af * vv * sn + bf * vv * cs, bf * vv * sn + af * vv * cs, -at * vv * sn - bt * vv * cs, bt * vv * sn - at * vv * cs};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        double* o = dE + j0 + (int64_t)g * 5 * nl + l;
+        o[0] = 1.0;
+        o[nl] = -dvf[g];
+        o[2 * nl] = -dvt[g];
+        o[3 * nl] = -dth[g];
+        o[4 * nl] = dth[g];
+    }
+}
+// ---- NLP block 2: dense quadratic rows  g_i = sum_j A_ij x_j + 1/2 Q_ij x_j^2 ,  J_ij = A_ij + Q_ij x_j  (row-major pattern).
+// dpar: A (m x n) then Q (m x n); one wavefront per row.
+__global__ __launch_bounds__(256) void k_nlp_dense_quadratic(const double* __restrict__ dpar, int64_t mrows, int64_t n, const double* __restrict__ x,
+                                                             double* __restrict__ E, double* __restrict__ dE, int64_t r0, int64_t j0, int write_jac) {
+    int64_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= mrows) return;
+    const int lane = threadIdx.x & 63;
+    const double* Ar = dpar + i * n;
+    const double* Qr = dpar + mrows * n + i * n;
+    double acc = 0.0;
+    for (int64_t j = lane; j < n; j += 64) {
+        const double xj = x[j], a = Ar[j], q = Qr[j];
+        acc += a * xj + 0.5 * q * xj * xj;
+        if (write_jac) dE[j0 + i * n + j] = a + q * xj;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) E[r0 + i] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_axpy_out(const double* __restrict__ x, double alpha, const double* __restrict__ p, double* __restrict__ out, int64_t n) {
+    int64_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j < n) out[j] = x[j] + alpha * p[j];
+}
+
+// ---- per-iteration reductions (one 1024-thread workgroup, fixed order)
+enum { RN_PRIM_INF = 0, RN_PRIM_1, RN_KT, RN_COMPL, RN_COUNT };
+struct SlpVecs {
+    const double *E, *g_L, *g_U, *x, *x_L, *x_U, *df, *lam, *mU, *mL, *jtl, *rown;   // jtl = J' lambda, rown = row norms of J
+    int64_t n, m;
+};
+// norm_violations (inf and 1 norm), norm_complementarity (inf norm), KT_residuals  - common.jl:35-98
+__global__ __launch_bounds__(1024) void k_slp_norms(SlpVecs V, double* __restrict__ out) {
+    __shared__ double sh[16];
+    double vinf = 0.0, v1 = 0.0, cinf = 0.0, den = 0.0, res = 0.0, ndf = 0.0, sc = 0.0;
+    for (int64_t i = threadIdx.x; i < V.m; i += 1024) {
+        const double e = V.E[i], lo = V.g_L[i], up = V.g_U[i];
+        const double v = e > up ? e - up : (e < lo ? lo - e : 0.0);
+        vinf = fmax(vinf, v);
+        v1 += v;
+        if (lo != up) {
+            const double l = V.lam[i];
+            cinf = fmax(cinf, fabs(fmin(e - lo, up - e) * l));
+            den += l * l;
+        }
+        sc = fmax(sc, fabs(V.lam[i]) * V.rown[i]);
+    }
+    for (int64_t j = threadIdx.x; j < V.n; j += 1024) {
+        const double xj = V.x[j];
+        const double v = xj > V.x_U[j] ? xj - V.x_U[j] : (xj < V.x_L[j] ? V.x_L[j] - xj : 0.0);
+        vinf = fmax(vinf, v);
+        v1 += v;
+        const double r = V.df[j] - V.jtl[j] - V.mU[j] - V.mL[j];
+        res += r * r;
+        ndf += V.df[j] * V.df[j];
+    }
+    vinf = blk_reduce_max(vinf, sh);
+    cinf = blk_reduce_max(cinf, sh);
+    sc = blk_reduce_max(sc, sh);
+    v1 = blk_reduce_sum(v1, sh);
+    den = blk_reduce_sum(den, sh);
+    res = blk_reduce_sum(res, sh);
+    ndf = blk_reduce_sum(ndf, sh);
+    if (threadIdx.x == 0) {
+        out[RN_PRIM_INF] = vinf;
+        out[RN_PRIM_1] = v1;
+        out[RN_KT] = sqrt(res) / fmax(fmax(1.0, sqrt(ndf)), sc);
+        out[RN_COMPL] = cinf / (1.0 + sqrt(den));
+    }
+}
+// compute_phi (slp.jl:79-115) / compute_derivative (slp.jl:122-147).  Et = constraint values at the trial point (E itself for
+// alpha = 0), ps = p_slack as 2 entries per row (second NaN when the row has one slack).
+//   mode 0 (phi):        normal  f_trial + nu . viol(Et)                restoration  prim_infeas + alpha * sum(slacks) + nu . viol(lhs)
+//   mode 1 (derivative): normal  df . p - nu . viol(E)                  restoration  sum(slacks) - nu . viol(E - viol(E))
+__global__ __launch_bounds__(1024) void k_slp_merit(SlpVecs V, const double* __restrict__ Et, const double* __restrict__ nu, const double* __restrict__ ps,
+                                                    const double* __restrict__ p, double alpha, int feasibility, double prim_infeas, const double* __restrict__ f_trial,
+                                                    int mode, double* __restrict__ out) {
+    __shared__ double sh[16];
+    double pen = 0.0, ssum = 0.0, dfp = 0.0;
+    for (int64_t i = threadIdx.x; i < V.m; i += 1024) {
+        const double lo = V.g_L[i], up = V.g_U[i], e = V.E[i];
+        const double viol = fmax(0.0, fmax(e - up, lo - e));
+        double lhs;
+        if (!feasibility) lhs = mode == 0 ? Et[i] : e;
+        else {
+            const bool both = lo > -INFINITY && up < INFINITY;
+            const double s1 = ps[2 * i], s2 = both ? ps[2 * i + 1] : 0.0;
+            ssum += s1 + s2;
+            lhs = (mode == 0 ? Et[i] : e) - viol;
+            if (mode == 0) lhs += alpha * (both ? s1 - s2 : (lo > -INFINITY ? s1 : (up < INFINITY ? -s1 : 0.0)));
+        }
+        pen += nu[i] * fmax(0.0, fmax(lhs - up, lo - lhs));
+    }
+    if (mode == 1 && !feasibility)
+        for (int64_t j = threadIdx.x; j < V.n; j += 1024) dfp += V.df[j] * p[j];
+    pen = blk_reduce_sum(pen, sh);
+    ssum = blk_reduce_sum(ssum, sh);
+    dfp = blk_reduce_sum(dfp, sh);
+    if (threadIdx.x == 0) {
+        if (mode == 0) out[0] = feasibility ? prim_infeas + alpha * ssum + pen : f_trial[0] + pen;
+        else out[0] = feasibility ? ssum - pen : dfp - pen;
+    }
+}

@@ -9,6 +9,7 @@
 #include "asm_kernels.hip.h"
 #include "asm_ipm_kernels.hip.h"
 #include "asm_as_kernels.hip.h"
+#include "asm_eval_kernels.hip.h"
 #include "../../include/asm_hip.h"
 
 #include <algorithm>
@@ -147,6 +148,16 @@ struct asm_handle {
     int* h_ascnt = nullptr;         // pinned read-back of its counters / scalars
     double* h_asscal = nullptr;
     double *d_Zbuf = nullptr, *d_nsu = nullptr, *d_nsdots = nullptr, *h_nsdots = nullptr;   // null-space active-set method (face_primal_anchored)
+    // ---- device-side evaluator (asm_eval_*): flattened function store, NLP block parameters, evaluation results in HBM
+    bool ev_ready = false;
+    int ev_nlp_kind = 0;
+    int64_t ev_nlp_rows = 0, ev_nlp_nnz = 0, ev_fn_nnz = 0;
+    FnStore ev_F;
+    std::vector<void*> ev_bufs;
+    int64_t* d_ev_ipar = nullptr;
+    double *d_ev_dpar = nullptr, *d_ev_x = nullptr, *d_ev_xt = nullptr, *d_ev_df = nullptr, *d_ev_E = nullptr, *d_ev_Et = nullptr, *d_ev_f = nullptr;
+    double *d_ev_vecs = nullptr, *h_ev = nullptr;     // reduction inputs (lambda, multipliers, nu, slacks, p, bounds) / pinned staging
+    bool J_valid = false;                               // the dense J in HBM matches the dE in HBM
     int64_t nsp = 0;
     double* h_scal = nullptr;       // pinned scalar read-back
     int* d_idx = nullptr;
@@ -622,6 +633,8 @@ struct Dev {
         }
     }
     void assemble() {
+        if (h->J_valid) return;                 // J in HBM already matches dE (one assembly per evaluation, shared by the norms and the LP)
+        h->J_valid = true;
         h->spv_J_valid = false;
         int id = begin(ASM_K_ASSEMBLE, 0.0, 8.0 * h->nnz + 8.0 * h->nu + (h->dense_fast ? 0.0 : 24.0 * h->nu + 8.0 * h->nnz));
         if (h->dense_fast) {
@@ -1520,6 +1533,12 @@ void free_device(asm_handle* h) {
     if (h->h_ascnt) (void)hipHostFree(h->h_ascnt);
     if (h->h_asscal) (void)hipHostFree(h->h_asscal);
     h->d_as = nullptr; h->d_as_i = nullptr; h->h_ascnt = nullptr; h->h_asscal = nullptr;
+    for (void* q : h->ev_bufs) F(q);
+    h->ev_bufs.clear();
+    h->ev_ready = false; h->d_ev_ipar = nullptr;
+    h->d_ev_dpar = h->d_ev_x = h->d_ev_xt = h->d_ev_df = h->d_ev_E = h->d_ev_Et = h->d_ev_f = h->d_ev_vecs = nullptr;
+    if (h->h_ev) (void)hipHostFree(h->h_ev);
+    h->h_ev = nullptr;
     F(h->d_Zbuf); F(h->d_nsu); F(h->d_nsdots);
     if (h->h_nsdots) (void)hipHostFree(h->h_nsdots);
     h->d_Zbuf = h->d_nsu = h->d_nsdots = h->h_nsdots = nullptr;
@@ -1550,6 +1569,7 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     free_device(h);
     h->setup_done = false;
     h->inputs_ready = false;
+    h->J_valid = false;
     h->n = n; h->m = m; h->nnz = nnz;
     h->c_lb.assign(c_lb, c_lb + m); h->c_ub.assign(c_ub, c_ub + m);
     h->v_lb.assign(v_lb, v_lb + n); h->v_ub.assign(v_ub, v_ub + n);
@@ -1747,6 +1767,7 @@ void do_upload(asm_handle* h, const double* dE, const double* df, double f, cons
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemcpyAsync(h->d_dE, dE, h->nnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    h->J_valid = false;
     h->df.assign(df, df + h->n); h->E.assign(E, E + h->m); h->x_k.assign(x_k, x_k + h->n);
     h->f = f;
     h->inputs_ready = true;
@@ -1897,6 +1918,41 @@ int guarded(asm_handle* h, F&& fn) {
     }
 }
 
+}  // namespace
+
+namespace {
+template <class T>
+T* ev_upload(asm_handle* h, const T* src, int64_t count) {
+    T* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, std::max<int64_t>(count, 1) * sizeof(T)));
+    h->ev_bufs.push_back((void*)d);
+    if (count > 0) HIPCHK(hipMemcpy(d, src, count * sizeof(T), hipMemcpyHostToDevice));
+    return d;
+}
+// kernels of one evaluation at the point in `xd`: values into Ed (m), objective into fd, optionally gradient / Jacobian values
+void ev_launch(asm_handle* h, const double* xd, double* Ed, double* fd, bool full) {
+    const FnStore& F = h->ev_F;
+    if (F.n_rows > 0)
+        hipLaunchKernelGGL(k_fn_rows, dim3((unsigned)((F.n_rows + 255) / 256)), dim3(256), 0, h->stream, F, xd, Ed, h->d_dE, full ? 1 : 0);
+    hipLaunchKernelGGL(k_fn_objective, dim3(1), dim3(64), 0, h->stream, F, xd, fd);
+    if (full) hipLaunchKernelGGL(k_fn_gradient, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, F, xd, h->d_ev_df);
+    if (h->ev_nlp_kind == 1) {
+        const int64_t nl = h->ev_nlp_rows / 4;
+        hipLaunchKernelGGL(k_nlp_acopf_ohm, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, h->stream, (const int64_t*)h->d_ev_ipar, (const double*)h->d_ev_dpar,
+                           xd, Ed, h->d_dE, F.n_rows, h->ev_fn_nnz, full ? 1 : 0);
+    } else if (h->ev_nlp_kind == 2) {
+        hipLaunchKernelGGL(k_nlp_dense_quadratic, dim3((unsigned)((h->ev_nlp_rows + 3) / 4)), dim3(256), 0, h->stream, (const double*)h->d_ev_dpar,
+                           h->ev_nlp_rows, h->n, xd, Ed, h->d_dE, F.n_rows, h->ev_fn_nnz, full ? 1 : 0);
+    }
+}
+SlpVecs ev_vecs(asm_handle* h, const double* lam, const double* mU, const double* mL, const double* jtl, const double* rown) {
+    SlpVecs V;
+    double* b = h->d_ev_vecs;      // layout: g_L, g_U (m each) | x_L, x_U (n each), written by asm_eval_setup
+    V.g_L = b; V.g_U = b + h->m; V.x_L = b + 2 * h->m; V.x_U = b + 2 * h->m + h->n;
+    V.E = h->d_ev_E; V.x = h->d_ev_x; V.df = h->d_ev_df; V.lam = lam; V.mU = mU; V.mL = mL; V.jtl = jtl; V.rown = rown;
+    V.n = h->n; V.m = h->m;
+    return V;
+}
 }  // namespace
 
 // =========================================================================================================
@@ -2072,6 +2128,162 @@ int asm_kt_residuals(asm_handle* h, const double* df, const double* lambda, cons
     });
 }
 
+// --------------------------------------------------------------------------------- device-side evaluators (rows a2 / f3)
+int asm_eval_setup(asm_handle* h, int64_t n_rows, const int64_t* aff_ptr, const int64_t* aff_var, const double* aff_coef, const int64_t* quad_ptr,
+                   const int64_t* q_v1, const int64_t* q_v2, const double* q_coef, const double* constant, const int64_t* jac_off,
+                   const int64_t* g_ptr, const int64_t* g_kind, const double* g_coef, const int64_t* g_other, double objective_scale, int nlp_kind,
+                   int64_t nlp_rows, int64_t nlp_nnz, const int64_t* nlp_ipar, int64_t n_ipar, const double* nlp_dpar, int64_t n_dpar) {
+    return guarded(h, [&] {
+        if (!h->setup_done) throw std::logic_error("asm_eval_setup: asm_sublp_setup first (it fixes n, m and the j_str order of dE)");
+        if (n_rows < 0 || !aff_ptr || !quad_ptr || !constant || !jac_off || !g_ptr || nlp_kind < 0 || nlp_kind > 2)
+            throw std::invalid_argument("asm_eval_setup: bad argument");
+        const int64_t fn_nnz = jac_off[n_rows];
+        if (n_rows + nlp_rows != h->m || fn_nnz + nlp_nnz != h->nnz)
+            throw std::invalid_argument("asm_eval_setup: row / Jacobian-entry counts do not match asm_sublp_setup");
+        if (nlp_kind == 1 && (nlp_rows % 4 != 0 || nlp_nnz != 5 * nlp_rows || n_ipar != 7 + 2 * (nlp_rows / 4) || n_dpar != 8 * (nlp_rows / 4)))
+            throw std::invalid_argument("asm_eval_setup: ACOPF block parameter sizes");
+        if (nlp_kind == 2 && (nlp_nnz != nlp_rows * h->n || n_dpar != 2 * nlp_rows * h->n)) throw std::invalid_argument("asm_eval_setup: dense block parameter sizes");
+        HIPCHK(hipSetDevice(h->device));
+        for (void* q : h->ev_bufs) (void)hipFree(q);
+        h->ev_bufs.clear();
+        FnStore& F = h->ev_F;
+        F.n_rows = n_rows; F.n = h->n; F.objective_scale = objective_scale;
+        const int64_t na = aff_ptr[n_rows + 1], nq = quad_ptr[n_rows + 1], ng = g_ptr[h->n];
+        F.aff_ptr = ev_upload(h, aff_ptr, n_rows + 2); F.aff_var = ev_upload(h, aff_var, na); F.aff_coef = ev_upload(h, aff_coef, na);
+        F.quad_ptr = ev_upload(h, quad_ptr, n_rows + 2); F.q_v1 = ev_upload(h, q_v1, nq); F.q_v2 = ev_upload(h, q_v2, nq); F.q_coef = ev_upload(h, q_coef, nq);
+        F.constant = ev_upload(h, constant, n_rows + 1); F.jac_off = ev_upload(h, jac_off, n_rows + 1);
+        F.g_ptr = ev_upload(h, g_ptr, h->n + 1); F.g_kind = ev_upload(h, g_kind, ng); F.g_coef = ev_upload(h, g_coef, ng); F.g_other = ev_upload(h, g_other, ng);
+        h->ev_nlp_kind = nlp_kind; h->ev_nlp_rows = nlp_rows; h->ev_nlp_nnz = nlp_nnz; h->ev_fn_nnz = fn_nnz;
+        h->d_ev_ipar = ev_upload(h, nlp_ipar, n_ipar);
+        h->d_ev_dpar = ev_upload(h, nlp_dpar, n_dpar);
+        h->d_ev_x = ev_upload<double>(h, nullptr, 0); (void)h->d_ev_x;
+        const int64_t n = h->n, m = std::max<int64_t>(h->m, 1);
+        auto dalloc = [&](int64_t cnt) { double* d = nullptr; HIPCHK(hipMalloc((void**)&d, std::max<int64_t>(cnt, 1) * sizeof(double))); h->ev_bufs.push_back((void*)d);
+                                          HIPCHK(hipMemset(d, 0, std::max<int64_t>(cnt, 1) * sizeof(double))); return d; };
+        h->d_ev_x = dalloc(n); h->d_ev_xt = dalloc(n); h->d_ev_df = dalloc(n); h->d_ev_E = dalloc(m); h->d_ev_Et = dalloc(m); h->d_ev_f = dalloc(8);
+        // bounds for the reductions + staging area: [g_L, g_U, x_L, x_U | lam, mU, mL, nu, ps(2m), p, jtl(ldn), rown(Mp), out(8)]
+        h->d_ev_vecs = dalloc(2 * m + 2 * n + 2 * m + 2 * n + 2 * m + n + h->ldn + h->Mp + 16);
+        HIPCHK(hipMemcpy(h->d_ev_vecs, h->c_lb.data(), h->m * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_ev_vecs + h->m, h->c_ub.data(), h->m * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_ev_vecs + 2 * h->m, h->v_lb.data(), n * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_ev_vecs + 2 * h->m + n, h->v_ub.data(), n * sizeof(double), hipMemcpyHostToDevice));
+        if (!h->h_ev) HIPCHK(hipHostMalloc((void**)&h->h_ev, (4 * (n + m) + 64) * sizeof(double)));
+        h->ev_ready = true;
+    });
+}
+
+// eval_functions! (slp.jl:186-191) on the device + what asm_sublp_upload does with the results: dE stays in HBM
+int asm_eval_functions(asm_handle* h, const double* x, double* f, double* df, double* E) {
+    return guarded(h, [&] {
+        if (!h->ev_ready || !x || !f || !df || (h->m > 0 && !E)) throw std::logic_error("asm_eval_functions: asm_eval_setup first / null pointer");
+        HIPCHK(hipSetDevice(h->device));
+        const int64_t n = h->n, m = h->m;
+        std::memcpy(h->h_ev, x, n * sizeof(double));
+        HIPCHK(hipMemcpyAsync(h->d_ev_x, h->h_ev, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        ev_launch(h, h->d_ev_x, h->d_ev_E, h->d_ev_f, true);
+        double* st = h->h_ev + n;
+        HIPCHK(hipMemcpyAsync(st, h->d_ev_df, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (m) HIPCHK(hipMemcpyAsync(st + n, h->d_ev_E, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(st + n + m, h->d_ev_f, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        std::memcpy(df, st, n * sizeof(double));
+        if (m) std::memcpy(E, st + n, m * sizeof(double));
+        *f = st[n + m];
+        h->df.assign(df, df + n); h->E.assign(E, E + m); h->x_k.assign(x, x + n);
+        h->f = *f;
+        h->inputs_ready = true;
+        h->J_valid = false;
+    });
+}
+
+// eval_f + eval_g at a trial point (compute_alpha, slp_line_search.jl:222-244; step_quality, slp_trust_region.jl:213-251)
+int asm_eval_constraints(asm_handle* h, const double* x, double* f, double* E) {
+    return guarded(h, [&] {
+        if (!h->ev_ready || !x || !f || (h->m > 0 && !E)) throw std::logic_error("asm_eval_constraints: asm_eval_setup first / null pointer");
+        HIPCHK(hipSetDevice(h->device));
+        const int64_t n = h->n, m = h->m;
+        std::memcpy(h->h_ev, x, n * sizeof(double));
+        HIPCHK(hipMemcpyAsync(h->d_ev_xt, h->h_ev, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        ev_launch(h, h->d_ev_xt, h->d_ev_Et, h->d_ev_f + 1, false);
+        double* st = h->h_ev + n;
+        if (m) HIPCHK(hipMemcpyAsync(st, h->d_ev_Et, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(st + m, h->d_ev_f + 1, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (m) std::memcpy(E, st, m * sizeof(double));
+        *f = st[m];
+    });
+}
+
+int asm_eval_jacobian_values(asm_handle* h, double* dE_out) {
+    return guarded(h, [&] {
+        if (!h->setup_done || !dE_out) throw std::logic_error("asm_eval_jacobian_values: no setup / null pointer");
+        HIPCHK(hipSetDevice(h->device));
+        HIPCHK(hipMemcpy(dE_out, h->d_dE, h->nnz * sizeof(double), hipMemcpyDeviceToHost));
+    });
+}
+
+// --------------------------------------------------------------------------------- per-iteration reductions on the device (row f1)
+// out[4] = { norm_violations(Inf), norm_violations(1), KT_residuals, norm_complementarity(Inf) }  (common.jl:35-98) from the
+// evaluation results of the last asm_eval_functions and the Jacobian assembled from its dE (assembled once, shared with the LP)
+int asm_slp_norms(asm_handle* h, const double* lambda, const double* mult_x_U, const double* mult_x_L, double* out4) {
+    return guarded(h, [&] {
+        if (!h->ev_ready || !h->inputs_ready || !mult_x_U || !mult_x_L || !out4 || (h->m > 0 && !lambda))
+            throw std::logic_error("asm_slp_norms: asm_eval_functions first / null pointer");
+        HIPCHK(hipSetDevice(h->device));
+        const int64_t n = h->n, m = h->m;
+        Dev d(h);
+        d.assemble();
+        double* v = h->d_ev_vecs + 2 * m + 2 * n;       // lam | mU | mL
+        double *lam = v, *mU = v + m, *mL = mU + n, *jtl = mL + n + m + 2 * m + n /* after nu (m), ps (2m), p (n) */, *rown = jtl + h->ldn, *outd = rown + h->Mp;
+        double* st = h->h_ev;
+        if (m) std::memcpy(st, lambda, m * sizeof(double));
+        std::memcpy(st + m, mult_x_U, n * sizeof(double));
+        std::memcpy(st + m + n, mult_x_L, n * sizeof(double));
+        HIPCHK(hipMemcpyAsync(lam, st, (m + 2 * n) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        // J' lambda over the first m rows: lambda padded with zeros on the extra range rows
+        HIPCHK(hipMemsetAsync(h->d_vecM, 0, h->Mp * sizeof(double), h->stream));
+        if (m) HIPCHK(hipMemcpyAsync(h->d_vecM, lam, m * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        d.launch_gemv_t(h->d_J, h->d_vecM, jtl);
+        if (m) hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, h->stream, h->d_J, h->ldn, rown, m, h->ldn);
+        hipLaunchKernelGGL(k_slp_norms, dim3(1), dim3(1024), 0, h->stream, ev_vecs(h, lam, mU, mL, jtl, rown), outd);
+        HIPCHK(hipMemcpyAsync(st, outd, RN_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (int k = 0; k < RN_COUNT; ++k) out4[k] = st[k];
+        d.resolve_timing();
+    });
+}
+
+// compute_phi(x, alpha, p) (slp.jl:79-115; mode 0) and compute_derivative (slp.jl:122-147; mode 1) with the trial evaluation on the
+// device.  p_slack: 2 entries per row as asm_sublp_solve returns them.
+int asm_slp_merit(asm_handle* h, int mode, double alpha, const double* p, const double* nu, const double* p_slack, int feasibility, double prim_infeas,
+                  double* out) {
+    return guarded(h, [&] {
+        if (!h->ev_ready || !h->inputs_ready || !p || !out || (h->m > 0 && (!nu || !p_slack)) || mode < 0 || mode > 1)
+            throw std::logic_error("asm_slp_merit: asm_eval_functions first / bad argument");
+        HIPCHK(hipSetDevice(h->device));
+        const int64_t n = h->n, m = h->m;
+        double* v = h->d_ev_vecs + 2 * m + 2 * n + m + 2 * n;    // nu | ps | p
+        double *nud = v, *psd = v + m, *pd = psd + 2 * m, *outd = pd + n + h->ldn + h->Mp;
+        double* st = h->h_ev;
+        if (m) { std::memcpy(st, nu, m * sizeof(double)); std::memcpy(st + m, p_slack, 2 * m * sizeof(double)); }
+        std::memcpy(st + 3 * m, p, n * sizeof(double));
+        HIPCHK(hipMemcpyAsync(nud, st, (3 * m + n) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        const double* Et = h->d_ev_E;
+        const double* ft = h->d_ev_f;
+        if (mode == 0 && alpha != 0.0) {
+            hipLaunchKernelGGL(k_axpy_out, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->d_ev_x, alpha, (const double*)pd, h->d_ev_xt, n);
+            ev_launch(h, h->d_ev_xt, h->d_ev_Et, h->d_ev_f + 1, false);
+            Et = h->d_ev_Et;
+            ft = h->d_ev_f + 1;
+        }
+        hipLaunchKernelGGL(k_slp_merit, dim3(1), dim3(1024), 0, h->stream, ev_vecs(h, nullptr, nullptr, nullptr, nullptr, nullptr), Et, (const double*)nud,
+                           (const double*)psd, (const double*)pd, alpha, feasibility, prim_infeas, ft, mode, outd);
+        HIPCHK(hipMemcpyAsync(st, outd, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        *out = st[0];
+    });
+}
+
 // --------------------------------------------------------------------------------- kernel test hooks
 static void test_alloc(asm_handle* h, int64_t M, int64_t K) {
     // minimal "problem" so that the generic buffers exist: dense pattern M x K
@@ -2176,6 +2388,7 @@ int asm_test_assemble(asm_handle* h, const double* dE, double* J_out) {
     return guarded(h, [&] {
         if (!h->setup_done) throw std::logic_error("setup first");
         HIPCHK(hipMemcpy(h->d_dE, dE, h->nnz * sizeof(double), hipMemcpyHostToDevice));
+        h->J_valid = false;
         Dev d(h);
         d.assemble();
         HIPCHK(hipStreamSynchronize(h->stream));

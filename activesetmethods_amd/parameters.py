@@ -26,6 +26,9 @@ class Parameters:
     tau: float = 0.9
     min_alpha: float = 1.e-6
     tr_size: float = 0.4
+    # not in the reference: evaluate f, grad f, g and the Jacobian values on the GPU (needs a Problem built from a FunctionModel,
+    # activesetmethods_amd/moi_evaluator.py) and run the per-iteration norms / merit reductions there
+    device_eval: bool = False
 
 
 def get_parameter(params, pname):          # src/parameters.jl:31-33

@@ -135,3 +135,16 @@ def synthetic_dense_nlp(n=1000, m=500):
                  np.zeros(n), eval_f, eval_grad_f, eval_g, eval_jac_g)
     pr.data = dict(A=A, Q=Q, c=c, d=d, xs=xs)
     return pr
+
+
+def synthetic_dense_function_model(n=1000, m=500):
+    """The synthetic dense NLP as a FunctionModel: quadratic objective in the affine / quadratic store, the dense rows as an NLP
+    block with the `dense_quadratic` device kernel (csrc/asm_eval_kernels.hip.h).  Same problem as `synthetic_dense_nlp`."""
+    from .moi_evaluator import FunctionModel, ScalarFunction, NlpBlock
+    pr = synthetic_dense_nlp(n, m)
+    d = pr.data
+    fm = FunctionModel(n, pr.x_L, pr.x_U)
+    fm.objective = ScalarFunction(0.0, [(float(d["c"][j]), j + 1) for j in range(n)], [(float(d["d"][j]), j + 1, j + 1) for j in range(n)])
+    fm.nlp = NlpBlock(pr.g_L, pr.g_U, pr.j_row, pr.j_col, pr.eval_g, pr.eval_jac_g,
+                      device=("dense_quadratic", np.zeros(1, np.int64), np.concatenate([d["A"].ravel(), d["Q"].ravel()])))
+    return fm

@@ -45,6 +45,7 @@ class Model:
         mdl = cls(pr.n, pr.m, pr.x_L, pr.x_U, pr.g_L, pr.g_U, pr.j_row, pr.j_col, pr.eval_f, pr.eval_g, pr.eval_grad_f,
                   pr.eval_jac_g, parameters)
         mdl.x[:] = pr.x0
+        mdl.function_model = getattr(pr, "function_model", None)      # the device evaluator's input (Parameters.device_eval)
         return mdl
 
 
@@ -71,6 +72,11 @@ class AbstractSlpOptimizer:
         self.lp_time = 0.0
         self.trace = []
         self._uploaded = False
+        # device-side evaluation / reductions (Parameters.device_eval): needs the FunctionModel the problem was built from
+        self._fm = getattr(problem, "function_model", None) if getattr(problem.parameters, "device_eval", False) else None
+        if getattr(problem.parameters, "device_eval", False) and self._fm is None:
+            raise ValueError("device_eval needs a problem built from a FunctionModel (activesetmethods_amd.moi_evaluator)")
+        self._norms = None
         # masks used by the merit function (slp.jl:90-96)
         gl, gu = problem.g_L, problem.g_U
         self._both = (gl > -INF) & (gu < INF)
@@ -80,21 +86,29 @@ class AbstractSlpOptimizer:
     # slp.jl:186-191
     def eval_functions(self):
         pr = self.problem
+        self._norms = None
+        if self._fm is not None:                          # f, df, E come back; the Jacobian values stay in HBM
+            self._ensure_optimizer(upload=False)
+            self.f, self.df, self.E = self.optimizer.eval_functions(self.x)
+            self._uploaded = True
+            return
         self.f = pr.eval_f(self.x)
         pr.eval_grad_f(self.x, self.df)
         pr.eval_g(self.x, self.E)
         pr.eval_jac_g(self.x, self.dE)
         self._uploaded = False
 
-    def _ensure_optimizer(self):
+    def _ensure_optimizer(self, upload=True):
         pr = self.problem
         data = QpData(self.df, self.f, self.dE, self.E, pr.g_L, pr.g_U, pr.x_L, pr.x_U)      # LpData, slp.jl:8-21
         if self.optimizer is None:                                                          # slp.jl:24-36
             factory = self.options.external_optimizer or _default_factory
             self.optimizer = factory(data, pr.j_row, pr.j_col)
+            if self._fm is not None:
+                self.optimizer.eval_setup(self._fm)
         else:
             self.optimizer.data = data                                                      # slp.jl:38-40
-        if not self._uploaded:
+        if upload and not self._uploaded:
             self.optimizer.upload(self.dE, self.df, self.f, self.E, self.x)
             self._uploaded = True
 
@@ -113,14 +127,24 @@ class AbstractSlpOptimizer:
         self.trace.append(rec)
         return out
 
+    def _device_norms(self):
+        key = (self.lam.tobytes(), self.mult_x_U.tobytes(), self.mult_x_L.tobytes())
+        if self._norms is None or self._norms[0] != key:
+            self._norms = (key, self.optimizer.slp_norms(self.lam, self.mult_x_U, self.mult_x_L))
+        return self._norms[1]
+
     # common.jl:35-44 on the HBM-resident Jacobian
     def KT_residuals(self):
+        if self._fm is not None:
+            return self._device_norms()[2]
         self._ensure_optimizer()
         return self.optimizer.kt_residuals(self.df, self.lam, self.mult_x_U, self.mult_x_L)
 
     # common.jl:51-68
     def norm_complementarity(self, p=INF):
         pr = self.problem
+        if self._fm is not None and p == INF:
+            return self._device_norms()[3]
         ineq = pr.g_L != pr.g_U
         compl = np.where(ineq, np.minimum(self.E - pr.g_L, pr.g_U - self.E) * self.lam, 0.0)
         denom = float(np.sum(self.lam[ineq] ** 2))
@@ -130,6 +154,8 @@ class AbstractSlpOptimizer:
     # common.jl:75-98
     def norm_violations(self, p=1, E=None):
         pr = self.problem
+        if self._fm is not None and E is None and p in (1, INF):
+            return self._device_norms()[0 if p == INF else 1]
         E = self.E if E is None else E
         vg = np.maximum(0.0, np.maximum(E - pr.g_U, pr.g_L - E))
         vx = np.maximum(0.0, np.maximum(self.x - pr.x_U, pr.x_L - self.x))
@@ -154,6 +180,8 @@ class AbstractSlpOptimizer:
     # slp.jl:79-115
     def compute_phi(self, x, alpha, p):
         pr = self.problem
+        if self._fm is not None:
+            return self.optimizer.slp_merit(0, alpha, p, self.nu, self.p_slack, self.feasibility_restoration, self.prim_infeas)
         xp = x + alpha * p
         E = self.E if alpha == 0.0 else pr.eval_g(xp, np.zeros(pr.m))
         if self.feasibility_restoration:
@@ -169,6 +197,8 @@ class AbstractSlpOptimizer:
     # slp.jl:122-147
     def compute_derivative(self):
         pr = self.problem
+        if self._fm is not None:
+            return self.optimizer.slp_merit(1, 0.0, self.p, self.nu, self.p_slack, self.feasibility_restoration, self.prim_infeas)
         viol = np.maximum(0.0, np.maximum(self.E - pr.g_U, pr.g_L - self.E))
         if self.feasibility_restoration:
             s1, s2 = self._slack_arrays()

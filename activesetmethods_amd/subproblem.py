@@ -120,6 +120,66 @@ class HipSubOptimizer:
             self._check(self._lib.asm_kernel_stats_reset(self._h))
         return out
 
+    # ------------------------------------------------------------------ device-side evaluators (include/asm_hip.h: asm_eval_*)
+    def eval_setup(self, fm):
+        """Hand the flattened function store of a FunctionModel (moi_evaluator.py) and its NLP block kernel to the handle."""
+        fl = fm.flatten()
+        kind, rows, nnz = 0, 0, 0
+        ipar, dpar = np.zeros(1, np.int64), np.zeros(1)
+        if fm.nlp is not None:
+            if fm.nlp.device is None:
+                raise AsmHipError("the model's NLP block has no device kernel")
+            name, ipar, dpar = fm.nlp.device
+            kind = {"acopf_ohm": 1, "dense_quadratic": 2}[name]
+            rows, nnz = fm.nlp.m, len(fm.nlp.rows)
+            ipar, dpar = np.ascontiguousarray(ipar, np.int64), np.ascontiguousarray(dpar, np.float64)
+        self._ev_keep = (fl, ipar, dpar)
+        a = lambda k: fl[k]
+        self._check(self._lib.asm_eval_setup(self._h, fl["n_rows"], _lib.i64ptr(a("aff_ptr")), _lib.i64ptr(a("aff_var")), _lib.dptr(a("aff_coef")),
+                                             _lib.i64ptr(a("quad_ptr")), _lib.i64ptr(a("q_v1")), _lib.i64ptr(a("q_v2")), _lib.dptr(a("q_coef")),
+                                             _lib.dptr(a("constant")), _lib.i64ptr(a("jac_off")), _lib.i64ptr(a("g_ptr")), _lib.i64ptr(a("g_kind")),
+                                             _lib.dptr(a("g_coef")), _lib.i64ptr(a("g_other")), float(fl["objective_scale"]), kind, rows, nnz,
+                                             _lib.i64ptr(ipar), len(ipar) if kind else 0, _lib.dptr(dpar), len(dpar) if kind else 0))
+
+    def eval_functions(self, x):
+        """eval_functions! (slp.jl:186-191) on the GPU: returns (f, df, E); dE stays in HBM as the next LP's input."""
+        x = _f64(x)
+        f = C.c_double(0.0); df = np.empty(self.n); E = np.empty(max(self.m, 1))
+        self._check(self._lib.asm_eval_functions(self._h, _lib.dptr(x), C.byref(f), _lib.dptr(df), _lib.dptr(E)))
+        return f.value, df, E[:self.m]
+
+    def eval_constraints(self, x):
+        x = _f64(x)
+        f = C.c_double(0.0); E = np.empty(max(self.m, 1))
+        self._check(self._lib.asm_eval_constraints(self._h, _lib.dptr(x), C.byref(f), _lib.dptr(E)))
+        return f.value, E[:self.m]
+
+    def jacobian_values(self):
+        dE = np.empty(max(len(self.j_row), 1))
+        self._check(self._lib.asm_eval_jacobian_values(self._h, _lib.dptr(dE)))
+        return dE[:len(self.j_row)]
+
+    def slp_norms(self, lam, mult_x_U, mult_x_L):
+        """(norm_violations(Inf), norm_violations(1), KT_residuals, norm_complementarity(Inf)) - common.jl:35-98 - on the device."""
+        out = np.empty(4)
+        lam, mult_x_U, mult_x_L = map(_f64, (lam, mult_x_U, mult_x_L))
+        self._check(self._lib.asm_slp_norms(self._h, _lib.dptr(lam), _lib.dptr(mult_x_U), _lib.dptr(mult_x_L), _lib.dptr(out)))
+        return tuple(float(v) for v in out)
+
+    def slp_merit(self, mode, alpha, p, nu, p_slack, feasibility, prim_infeas):
+        """mode 0: compute_phi(x, alpha, p) (slp.jl:79-115); mode 1: compute_derivative (slp.jl:122-147)."""
+        ps = np.full(2 * max(self.m, 1), np.nan)
+        for i in range(self.m):
+            v = p_slack.get(i, [0.0]) if p_slack else [0.0]
+            ps[2 * i] = v[0]
+            if len(v) > 1:
+                ps[2 * i + 1] = v[1]
+        out = C.c_double(0.0)
+        p, nu = _f64(p), _f64(nu)
+        self._check(self._lib.asm_slp_merit(self._h, int(mode), float(alpha), _lib.dptr(p), _lib.dptr(nu), _lib.dptr(ps), int(bool(feasibility)),
+                                            float(prim_infeas) if np.isfinite(prim_infeas) else 0.0, C.byref(out)))
+        return out.value
+
     # per-iteration reductions on the resident Jacobian (common.jl:35-44, slp.jl:54-66)
     def kt_residuals(self, df, lam, mult_x_U, mult_x_L):
         out = C.c_double(0.0)

@@ -91,8 +91,9 @@ def run_batch(args, rank, world, local_rank, dist, torch):
         return A.HipSubOptimizer(d, r, c, device=local_rank)
 
     def make_model(sidx):
-        pr = acopf.acopf_problem(acopf.scenario_case(base, sidx), "case300-sized scenario %d" % sidx)
-        return A.Model.from_problem(pr, A.Parameters(algorithm=args.algorithm, max_iter=args.max_iter, external_optimizer=factory))
+        pr = acopf.function_model(acopf.scenario_case(base, sidx)).to_problem("case300-sized scenario %d" % sidx)
+        return A.Model.from_problem(pr, A.Parameters(algorithm=args.algorithm, max_iter=args.max_iter, external_optimizer=factory,
+                                                     device_eval=not args.host_eval))
 
     def run(model, max_lp_solves=None):
         slp = A.optimize(model, max_lp_solves)
@@ -131,14 +132,21 @@ def run_batch(args, rank, world, local_rank, dist, torch):
         dist.destroy_process_group()
 
 
-def make_problem(name):
+def make_problem(name, device_eval=True):
+    """The workload as the reference receives it: a model of affine / quadratic functions + an NLP block in the MOI wrapper's
+    lists (activesetmethods_amd/moi_evaluator.py); f, grad f, g and the Jacobian values are evaluated by the device kernels and the
+    Jacobian values never leave HBM.  Second return value: the same NLP with vectorised NumPy callbacks (rows in another order) -
+    what --host-eval runs and what the CPU baselines evaluate with (the FunctionModel's own host evaluator is a term-by-term
+    Python loop, fine as a checker, unfair as a baseline)."""
     from activesetmethods_amd import problems, acopf
-    if name == "c4":
-        return acopf.acopf_problem(acopf.synthetic_case("case1354pegase", 1), "case1354pegase-sized")
-    if name == "c3":
-        return acopf.acopf_problem(acopf.synthetic_case("case118", 1), "case118-sized")
+    if name in ("c3", "c4"):
+        case = acopf.synthetic_case("case1354pegase" if name == "c4" else "case118", 1)
+        label = "case1354pegase-sized" if name == "c4" else "case118-sized"
+        host = acopf.acopf_problem(case, label)
+        return (acopf.function_model(case).to_problem(label) if device_eval else host), host
     n, m = (1000, 500) if name == "c2" else (200, 100)
-    return problems.synthetic_dense_nlp(n, m)
+    host = problems.synthetic_dense_nlp(n, m)
+    return (problems.synthetic_dense_function_model(n, m).to_problem(host.name) if device_eval else host), host
 
 
 def run_steps(pr, algorithm, device, n_steps, state):
@@ -147,12 +155,12 @@ def run_steps(pr, algorithm, device, n_steps, state):
     done = 0
     while done < n_steps:
         if state.get("slp") is None:
-            par = A.Parameters(algorithm=algorithm, max_iter=10 ** 9,
+            par = A.Parameters(algorithm=algorithm, max_iter=10 ** 9, device_eval=state.get("device_eval", True),
                                external_optimizer=lambda d, r, c: A.HipSubOptimizer(d, r, c, device=device))
             mdl = A.Model.from_problem(pr, par)
             slp = A.SlpTR(mdl) if algorithm == "Trust Region" else A.SlpLS(mdl)
             state["slp"], state["resume"] = slp, False
-            if state.get("opt") is not None:            # keep one handle (and its HBM buffers) per rank
+            if state.get("opt") is not None:            # keep one handle (its HBM buffers and the evaluator's function store) per rank
                 slp.optimizer = state["opt"]
         slp = state["slp"]
         before = slp.lp_solves
@@ -328,6 +336,7 @@ def main():
     ap.add_argument("--max-iter", type=int, default=100, help="workload c5: SLP iteration cap per scenario")
     ap.add_argument("--concurrency", type=int, default=3, help="workload c5: scenarios in flight per GPU (one handle / HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-eval", action="store_true", help="evaluate f, grad f, g, Jacobian values with the NumPy callbacks instead of the device kernels")
     ap.add_argument("--kernel-breakdown", action="store_true",
                     help="time every kernel family with HIP events (adds kernels_ms; default: only the dominant kernel, k_syrk, is timed)")
     args = ap.parse_args()
@@ -370,8 +379,8 @@ def main():
         if args.scenarios_per_gpu is not None:
             args.steps = args.scenarios_per_gpu
         return run_batch(args, rank, world, local_rank, dist, torch)
-    pr = make_problem(args.workload)
-    state = {}
+    pr, pr_host = make_problem(args.workload, not args.host_eval)
+    state = {"device_eval": not args.host_eval}
     run_steps(pr, args.algorithm, local_rank, args.warmup, state)
     opt = state["opt"]
     opt.kernel_stats(reset=True)
@@ -421,6 +430,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": w["desc"], "algorithm": args.algorithm, "n": pr.n, "m": pr.m, "nnz": pr.nnz,
                        "parallelism": "replicas x%d" % world, "restarts": state.get("restarts", 0),
+                       "evaluation": "host NumPy callbacks, dE uploaded per step" if args.host_eval else "device kernels (dE stays in HBM)",
                        "factorisations_per_step": nfact / max(args.steps, 1)},
             "roofline": roof,
         }
@@ -444,7 +454,7 @@ def main():
                        eqp=sum(r["stats"]["eqp"] for r in timed))
             if not timed:
                 mix = dict(steps=args.steps, col_iters=0, row_iters=nfact, eqp=0)
-            out["cpu_baseline"] = cpu_baseline(pr, args.algorithm, args.cpu_seconds, mix, timed)
+            out["cpu_baseline"] = cpu_baseline(pr_host, args.algorithm, args.cpu_seconds, mix, timed)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

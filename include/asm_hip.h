@@ -118,6 +118,42 @@ int asm_kt_residuals(asm_handle* h, const double* df, const double* lambda,
 /* per-row 2-norms of the assembled Jacobian (compute_nu!, slp.jl:54-66). */
 int asm_jac_row_norms(asm_handle* h, double* out_m);
 
+/* ---- device-side evaluators: eval_functions! (slp.jl:186-191) without the host ------------------------------------
+ * The affine / quadratic evaluator of the MOI wrapper (MOI_wrapper.jl:776-944) on a flattened function store, plus one
+ * optional NLP block kernel; Jacobian values are written straight into the handle's dE buffer in the j_str order given to
+ * asm_sublp_setup (which must precede this call).  Rows 0..n_rows-1 are the constraint functions in the wrapper's block
+ * order (linear <=, >=, ==, quadratic <=, >=, ==; MOI_wrapper.jl:683-689), row n_rows is the objective (MOI_wrapper.jl:809-820).
+ *   aff_ptr/quad_ptr [n_rows+2]  term ranges per row;  aff_var, q_v1, q_v2: 0-based variables;  constant [n_rows+1]
+ *   jac_off [n_rows+1]           offset of each row's values in dE (affine terms, then per quadratic term 1 or 2 values:
+ *                                fill_constraint_jacobian!, MOI_wrapper.jl:889-918)
+ *   g_ptr [n+1], g_kind, g_coef, g_other   per-variable contributions to the objective gradient in term order
+ *                                (fill_gradient!, MOI_wrapper.jl:827-850; kind 0: += coef, 1: += coef * x[other])
+ *   objective_scale              +1 MIN, -1 MAX, 0 FEASIBILITY (MOI_wrapper.jl:1037-1054)
+ *   nlp_kind                     0 none; 1 Ohm's-law rows of the polar ACOPF model (4 rows and 20 values per branch;
+ *                                ipar = [n_branch, va0, vm0, pf0, pt0, qf0, qt0, f_bus.., t_bus..], dpar = 8 coefficient
+ *                                arrays); 2 dense quadratic rows g = A x + 1/2 Q x^2 (dpar = A then Q, row-major)
+ * The affine / quadratic part is bit-identical to the host evaluator (no fused multiply-add, the reference's term order). */
+int asm_eval_setup(asm_handle* h, int64_t n_rows, const int64_t* aff_ptr, const int64_t* aff_var, const double* aff_coef,
+                   const int64_t* quad_ptr, const int64_t* q_v1, const int64_t* q_v2, const double* q_coef,
+                   const double* constant, const int64_t* jac_off,
+                   const int64_t* g_ptr, const int64_t* g_kind, const double* g_coef, const int64_t* g_other,
+                   double objective_scale, int nlp_kind, int64_t nlp_rows, int64_t nlp_nnz,
+                   const int64_t* nlp_ipar, int64_t n_ipar, const double* nlp_dpar, int64_t n_dpar);
+/* f, df, E at x (returned) and dE (kept in HBM); equivalent to evaluating on the host + asm_sublp_upload. */
+int asm_eval_functions(asm_handle* h, const double* x, double* f, double* df, double* E);
+/* eval_f + eval_g at a trial point (line search / step quality); does not touch the inputs of the next LP. */
+int asm_eval_constraints(asm_handle* h, const double* x, double* f, double* E);
+/* copy of the dE buffer (tests). */
+int asm_eval_jacobian_values(asm_handle* h, double* dE_out);
+
+/* ---- per-iteration reductions of the SLP callers on the evaluation results in HBM (need asm_eval_functions) ----------
+ * out4 = { norm_violations(Inf), norm_violations(1), KT_residuals, norm_complementarity(Inf) }   (common.jl:35-98). */
+int asm_slp_norms(asm_handle* h, const double* lambda, const double* mult_x_U, const double* mult_x_L, double* out4);
+/* mode 0: compute_phi(x, alpha, p) (slp.jl:79-115; the trial point is evaluated on the device);
+ * mode 1: compute_derivative (slp.jl:122-147).  p_slack as asm_sublp_solve returns it. */
+int asm_slp_merit(asm_handle* h, int mode, double alpha, const double* p, const double* nu, const double* p_slack,
+                  int feasibility, double prim_infeas, double* out);
+
 /* ---- kernel-level test hooks (used by tests/ to check each kernel against NumPy) ---------------- */
 int asm_test_syrk(asm_handle* h, const double* A, int64_t M, int64_t K, const int32_t* idx, int64_t Ms,
                   const double* theta, const double* diag, double* S_out /* Ms*Ms, lower valid */, int tile);

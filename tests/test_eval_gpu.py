@@ -1,0 +1,185 @@
+"""Device-side evaluators and SLP reductions against the host restatement of the MOI
+wrapper's evaluator block (activesetmethods_amd/moi_evaluator.py, src/MOI_wrapper.jl:683-944) and the oracle's norms / merit
+functions (src/algorithms/common.jl:35-98, src/algorithms/slp.jl:79-147), through the C ABI."""
+import numpy as np
+import pytest
+
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_function_model(seed, n=30, sense="MIN_SENSE"):
+    from activesetmethods_amd.moi_evaluator import FunctionModel, ScalarFunction
+    rng = np.random.default_rng(seed)
+    fm = FunctionModel(n, -np.ones(n), np.ones(n))
+    fm.sense = sense
+
+    def func(quad):
+        aff = [(float(rng.standard_normal()), int(rng.integers(1, n + 1))) for _ in range(int(rng.integers(0, 6)))]
+        q = []
+        if quad:
+            for _ in range(int(rng.integers(1, 5))):
+                a, b = int(rng.integers(1, n + 1)), int(rng.integers(1, n + 1))
+                if rng.random() < 0.4:
+                    b = a
+                q.append((float(rng.standard_normal()), a, b))
+        return ScalarFunction(float(rng.standard_normal()), aff, q)
+    for kind in ("le", "ge", "eq"):
+        for _ in range(int(rng.integers(1, 5))):
+            fm.add_constraint(func(False), kind, float(rng.standard_normal()))
+        for _ in range(int(rng.integers(1, 5))):
+            fm.add_constraint(func(True), kind, float(rng.standard_normal()))
+    fm.objective = func(True)
+    return fm
+
+
+def _optimizer_for(pr):
+    from activesetmethods_amd import QpData, HipSubOptimizer
+    z = np.zeros
+    return HipSubOptimizer(QpData(z(pr.n), 0.0, z(pr.nnz), z(pr.m), pr.g_L, pr.g_U, pr.x_L, pr.x_U), pr.j_row, pr.j_col)
+
+
+@pytest.mark.parametrize("seed,sense", [(1, "MIN_SENSE"), (2, "MAX_SENSE"), (3, "FEASIBILITY_SENSE"), (4, "MIN_SENSE")])
+def test_affine_quadratic_evaluator_is_bit_identical(seed, sense):
+    """f, grad f, g and the Jacobian values (duplicates and all, in j_str order) from the device kernels equal the host
+    evaluator bit for bit: same term order, no fused multiply-add."""
+    fm = _random_function_model(seed, sense=sense)
+    pr = fm.to_problem()
+    opt = _optimizer_for(pr)
+    opt.eval_setup(fm)
+    rng = np.random.default_rng(seed + 50)
+    for _ in range(3):
+        x = rng.uniform(-1.0, 1.0, pr.n)
+        f, df, E = opt.eval_functions(x)
+        assert f == pr.eval_f(x)
+        assert np.array_equal(df, pr.eval_grad_f(x, np.zeros(pr.n)))
+        assert np.array_equal(E, pr.eval_g(x, np.zeros(pr.m)))
+        assert np.array_equal(opt.jacobian_values(), pr.eval_jac_g(x, np.zeros(pr.nnz)))
+        ft, Et = opt.eval_constraints(0.5 * x)
+        assert ft == pr.eval_f(0.5 * x) and np.array_equal(Et, pr.eval_g(0.5 * x, np.zeros(pr.m)))
+    opt.close()
+
+
+def test_acopf_device_evaluator():
+    """Polar ACOPF through the wrapper's lists + the Ohm's-law NLP-block kernel: the affine / quadratic rows bit-identical,
+    the trigonometric rows and their Jacobian values within 1e-13 relative (device sin / cos vs NumPy's)."""
+    from activesetmethods_amd import acopf
+    fm = acopf.function_model(acopf.synthetic_case("case118", 2))
+    pr = fm.to_problem("case118")
+    opt = _optimizer_for(pr)
+    opt.eval_setup(fm)
+    rng = np.random.default_rng(7)
+    x = pr.x0 + 0.02 * rng.standard_normal(pr.n)
+    f, df, E = opt.eval_functions(x)
+    Eh = pr.eval_g(x, np.zeros(pr.m)); dEh = pr.eval_jac_g(x, np.zeros(pr.nnz)); dEd = opt.jacobian_values()
+    k = fm.nlp_constraint_offset
+    nf = fm.flatten()["nnz_functions"]
+    assert f == pr.eval_f(x) and np.array_equal(df, pr.eval_grad_f(x, np.zeros(pr.n)))
+    assert np.array_equal(E[:k], Eh[:k]) and np.array_equal(dEd[:nf], dEh[:nf])
+    assert rel_err(E[k:], Eh[k:]) < 1e-13 and rel_err(dEd[nf:], dEh[nf:]) < 1e-13
+    opt.close()
+
+
+def test_dense_quadratic_device_evaluator():
+    from activesetmethods_amd import problems
+    fm = problems.synthetic_dense_function_model(96, 40)
+    pr = fm.to_problem()
+    opt = _optimizer_for(pr)
+    opt.eval_setup(fm)
+    x = np.random.default_rng(3).uniform(-0.5, 0.5, pr.n)
+    f, df, E = opt.eval_functions(x)
+    assert f == pr.eval_f(x) and np.array_equal(df, pr.eval_grad_f(x, np.zeros(pr.n)))
+    assert rel_err(E, pr.eval_g(x, np.zeros(pr.m))) < 1e-13
+    assert rel_err(opt.jacobian_values(), pr.eval_jac_g(x, np.zeros(pr.nnz))) < 1e-14
+    opt.close()
+
+
+def test_slp_reductions_on_device():
+    """KT_residuals, norm_violations (Inf and 1), norm_complementarity, compute_phi and compute_derivative (both phases) on the
+    device against the oracle's / the host driver's formulas."""
+    import activesetmethods_amd as A
+    from activesetmethods_amd import acopf
+    from oracle import slp as O
+    from oracle.subproblem import compute_jacobian_matrix
+    fm = acopf.function_model(acopf.synthetic_case("case118", 4))
+    pr = fm.to_problem("case118")
+    rng = np.random.default_rng(11)
+    x = pr.x0 + 0.05 * rng.standard_normal(pr.n)
+    opt = _optimizer_for(pr)
+    opt.eval_setup(fm)
+    f, df, E = opt.eval_functions(x)
+    lam = rng.standard_normal(pr.m); mU = 0.1 * rng.standard_normal(pr.n); mL = 0.1 * rng.standard_normal(pr.n)
+    J, _ = compute_jacobian_matrix(pr.m, pr.n, pr.j_row - 1, pr.j_col - 1, pr.eval_jac_g(x, np.zeros(pr.nnz)))
+    ref = (O.norm_violations(E, pr.g_L, pr.g_U, x, pr.x_L, pr.x_U, np.inf), O.norm_violations(E, pr.g_L, pr.g_U, x, pr.x_L, pr.x_U, 1),
+           O.KT_residuals(df, lam, mU, mL, J), O.norm_complementarity(E, pr.g_L, pr.g_U, lam))
+    got = opt.slp_norms(lam, mU, mL)
+    for a, b in zip(got, ref):
+        assert abs(a - b) <= 1e-12 * max(1.0, abs(b)), (got, ref)
+    # merit function and its directional derivative: the host driver's formulas (activesetmethods_amd/slp.py) on the same data
+    mdl = A.Model.from_problem(pr, A.Parameters())
+    host = A.SlpLS(mdl)
+    host.x = x.copy(); host.f, host.df, host.E = f, df.copy(), E.copy()
+    host.nu = np.abs(rng.standard_normal(pr.m)); host.p = 0.01 * rng.standard_normal(pr.n)
+    host.prim_infeas = ref[0]
+    both = (pr.g_L > -np.inf) & (pr.g_U < np.inf)
+    host.p_slack = {i: ([abs(rng.standard_normal()), abs(rng.standard_normal())] if both[i] else [abs(rng.standard_normal())]) for i in range(pr.m)}
+    for fr in (False, True):
+        host.feasibility_restoration = fr
+        for alpha in (0.0, 1.0, 0.37):
+            want = host.compute_phi(host.x, alpha, host.p)
+            got = opt.slp_merit(0, alpha, host.p, host.nu, host.p_slack, fr, host.prim_infeas)
+            assert abs(got - want) <= 1e-11 * max(1.0, abs(want)), (fr, alpha, got, want)
+        want = host.compute_derivative()
+        got = opt.slp_merit(1, 0.0, host.p, host.nu, host.p_slack, fr, host.prim_infeas)
+        assert abs(got - want) <= 1e-11 * max(1.0, abs(want)), (fr, got, want)
+    opt.close()
+
+
+def _toy_function_model():
+    """The toy NLP of test/ext_solver.jl:12-18 with its three nonlinear rows stated as quadratic functions."""
+    from activesetmethods_amd.moi_evaluator import FunctionModel, ScalarFunction
+    fm = FunctionModel(2)
+    fm.objective = ScalarFunction(0.0, [(1.0, 1)], [(2.0, 1, 1)])                      # X^2 + X
+    fm.add_constraint(ScalarFunction(0.0, [(1.0, 1)]), "ge", -2.0)                      # X >= -2
+    fm.add_constraint(ScalarFunction(0.0, [(-1.0, 1)], [(2.0, 1, 1)]), "eq", 2.0)       # X^2 - X == 2
+    fm.add_constraint(ScalarFunction(0.0, [], [(1.0, 1, 2)]), "eq", 1.0)                # X Y == 1
+    fm.add_constraint(ScalarFunction(0.0, [], [(1.0, 1, 2)]), "ge", 0.0)                # X Y >= 0
+    return fm
+
+
+@pytest.mark.parametrize("alg", ["Line Search", "Trust Region"])
+def test_toy_with_device_evaluation_reaches_the_known_answer(alg):
+    """test/runtests.jl:11-13 with every evaluation and reduction on the GPU: X = Y = -1, LOCALLY_SOLVED; same run as with the
+    host evaluator."""
+    import activesetmethods_amd as A
+    runs = []
+    for dev in (True, False):
+        pr = _toy_function_model().to_problem("toy")
+        m = A.Model.from_problem(pr, A.Parameters(algorithm=alg, device_eval=dev))
+        s = A.optimize(m)
+        runs.append((m, s))
+    (md, sd), (mh, sh) = runs
+    assert md.status == mh.status == 0
+    assert np.allclose(md.x, [-1.0, -1.0], rtol=1e-4)
+    assert sd.lp_solves == sh.lp_solves and rel_err(md.x, mh.x) < 1e-9
+
+
+def test_acopf_slp_run_device_evaluation_matches_host_evaluation():
+    """case118-sized ACOPF (FunctionModel + Ohm's-law kernel), Line Search, 15 iterations: the run with device-side
+    evaluation, norms and merit reductions follows the run with the host evaluator (same LP statuses and phases, steps within
+    1e-8: the two differ only by the last bits of sin / cos and of the reductions)."""
+    import activesetmethods_amd as A
+    from activesetmethods_amd import acopf
+    case = acopf.synthetic_case("case118", 1)
+    runs = []
+    for dev in (True, False):
+        pr = acopf.function_model(case).to_problem("case118")
+        m = A.Model.from_problem(pr, A.Parameters(algorithm="Line Search", max_iter=15, device_eval=dev))
+        runs.append((m, A.optimize(m)))
+    (md, sd), (mh, sh) = runs
+    assert len(sd.trace) == len(sh.trace)
+    for a, b in zip(sd.trace, sh.trace):
+        assert a["status"] == b["status"] and a["fr"] == b["fr"]
+        assert rel_err(a["p"], b["p"]) < 1e-8
+    assert rel_err(md.x, mh.x) < 1e-8

@@ -184,3 +184,28 @@ def test_bench_launcher_starts_one_rank_per_gpu(tmp_path):
     assert [r["rank"] for r in res] == [0, 1, 2] and [r["local"] for r in res] == [0, 1, 2]
     assert all(r["world"] == 3 and r["addr"] == "127.0.0.1" and r["total"] == 3.0 for r in res)
     assert bench.launch_ranks(2, [out, "7"], script=str(child)) == 7      # a failing rank's exit code is returned
+
+
+def test_function_model_follows_the_wrapper():
+    """moi_evaluator.FunctionModel against src/MOI_wrapper.jl:683-1012 on a hand-worked model: block order of the rows, the
+    Jacobian pattern with the duplicates quadratic terms emit, the 1/2 convention of diagonal quadratic terms, bounds, sense."""
+    from activesetmethods_amd.moi_evaluator import FunctionModel, ScalarFunction
+    fm = FunctionModel(3, [-1, -1, -1], [2, 2, 2])
+    fm.add_constraint(ScalarFunction(1.0, [], [(2.0, 1, 1), (3.0, 1, 2)]), "le", 5.0)           # quadratic <= : 1 + x1^2 + 3 x1 x2
+    fm.add_constraint(ScalarFunction(0.0, [(1.0, 2), (2.0, 3)]), "eq", 1.0)                      # linear ==
+    fm.add_constraint(ScalarFunction(0.5, [(4.0, 1)]), "ge", 0.0)                                # linear >=
+    fm.objective = ScalarFunction(0.0, [(1.0, 3)], [(4.0, 2, 2), (1.0, 1, 3)])                   # x3 + 2 x2^2 + x1 x3
+    fm.sense = "MAX_SENSE"
+    # rows: linear >= (0.5 + 4 x1), linear == (x2 + 2 x3), quadratic <=          MOI_wrapper.jl:683-689
+    assert fm.jacobian_structure() == [(1, 1), (2, 2), (2, 3), (3, 1), (3, 1), (3, 2)]          # :693-746 (x1^2 -> one entry, x1 x2 -> two)
+    lb, ub = fm.constraint_bounds()
+    assert list(lb) == [0.0, 1.0, -np.inf] and list(ub) == [np.inf, 1.0, 5.0]
+    x = np.array([1.0, 2.0, 3.0])
+    g = fm.eval_g(x, np.zeros(3))
+    assert list(g) == [4.5, 8.0, 1.0 + 1.0 + 6.0]
+    assert list(fm.eval_jac_g(x, np.zeros(6))) == [4.0, 1.0, 2.0, 2.0 * 1.0, 3.0 * 2.0, 3.0 * 1.0]   # :889-918
+    assert fm.eval_f(x) == -(3.0 + 8.0 + 3.0)                                                    # MAX: scale -1 (:1037-1049)
+    assert list(fm.eval_grad_f(x, np.zeros(3))) == [-3.0, -8.0, -2.0]
+    assert list(fm.start_point()) == [0.0, 0.0, 0.0]
+    pr = fm.to_problem()
+    assert pr.m == 3 and pr.nnz == 6 and list(pr.j_row) == [1, 2, 2, 3, 3, 3]
