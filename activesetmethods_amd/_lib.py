@@ -31,7 +31,9 @@ PROTOTYPES = {
     "asm_destroy": (C.c_int, [_P]),
     "asm_last_error": (C.c_char_p, [_P]),
     "asm_sublp_setup": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, _I64, _I64, _D, _D, _D, _D]),
+    "asm_sublp_set_bounds": (C.c_int, [_P, _D, _D, _D, _D]),
     "asm_sublp_solve": (C.c_int, [_P, _D, _D, C.c_double, _D, _D, C.c_double, C.c_int, _D, _D, _D, _D, _D, _I32]),
+    "asm_lp_solve": (C.c_int, [_P, _D, _D, _D, _D, _D, C.c_int, _D, _D, _D, _D, _D, _D, _I32, _I32]),
     "asm_sublp_upload": (C.c_int, [_P, _D, _D, C.c_double, _D, _D]),
     "asm_sublp_solve_resident": (C.c_int, [_P, C.c_double, C.c_int, _D, _D, _D, _D, _D, _I32]),
     "asm_sublp_active_set": (C.c_int, [_P, _I32, _I32, _I32, _I64, _I64]),

@@ -1773,6 +1773,83 @@ void do_upload(asm_handle* h, const double* dE, const double* df, double f, cons
     h->inputs_ready = true;
 }
 
+// the LP in caller units: min q'p + w's  s.t.  J_i p + E s (=,>=,<=) r_i (rows m.. = the extra `<=` rows of range constraints),
+// lb <= p <= ub, s >= slo (slack columns only in the restoration phase; layout of create_model!, subproblem.jl:83-112)
+struct LpRaw {
+    vec q, r, lb, ub, w, slo;
+    bool slacks = false;
+};
+struct LpSol {
+    int status = ASM_OTHER;
+    vec p, s, y, z;          // p exactly on its bound where bound-active; y per LP row; z = q - J'y (reduced costs)
+    ActiveSet as;
+};
+
+// assemble J from the dE in HBM, scale, solve, unscale (oracle: solve_lp).  `slot`: which retained active set / hints to use.
+void solve_raw(asm_handle* h, const LpRaw& L, int slot, LpSol& out) {
+    const int64_t n = h->n, M = h->M;
+    Solver sv(h);
+    SLP& lp = sv.lp;
+    std::memset(&h->stats, 0, sizeof(h->stats));
+    lp.n = n; lp.M = M; lp.ns = L.slacks ? h->ns : 0;
+    lp.rtype = h->rtype.data(); lp.srow = h->srow.data(); lp.scoef = h->scoef.data();
+    h->stats.M = (int)M; h->stats.n = (int)n; h->stats.ns = (int)lp.ns;
+    // Jacobian -> dense rows incl. range rows; scaled copy (column scale = min(box, matrix cap), oracle: scale_lp)
+    vec c(n), rel(n);
+    sv.dev.assemble();
+    sv.dev.col_relmax(rel.data());
+    for (int64_t j = 0; j < n; ++j) {
+        double c_mat = rel[j] > 0.0 ? 1.0 / rel[j] : 1.0;
+        c[j] = pow2_round(std::min(std::max(L.ub[j], -L.lb[j]), c_mat));
+    }
+    vec rho(M);
+    sv.dev.scale(c.data(), rho.data());
+    sv.dev.tile_flags();
+    lp.q.resize(n); lp.lb.resize(n); lp.ub.resize(n); lp.r.resize(M); lp.w.resize(lp.ns); lp.slo.resize(lp.ns);
+    double qmax = 0.0;
+    for (int64_t j = 0; j < n; ++j) { lp.q[j] = L.q[j] * c[j]; qmax = std::max(qmax, std::fabs(lp.q[j])); }
+    for (int64_t k = 0; k < lp.ns; ++k) { lp.w[k] = L.w[k] * rho[h->srow[k]]; qmax = std::max(qmax, std::fabs(lp.w[k])); }
+    double kap = pow2_round(qmax);
+    for (int64_t j = 0; j < n; ++j) { lp.q[j] /= kap; lp.lb[j] = L.lb[j] / c[j]; lp.ub[j] = L.ub[j] / c[j]; }
+    for (int64_t k = 0; k < lp.ns; ++k) { lp.w[k] /= kap; lp.slo[k] = L.slo[k] / rho[h->srow[k]]; }
+    for (int64_t i = 0; i < M; ++i) lp.r[i] = L.r[i] / rho[i];
+    lp.scale_q = 1.0;
+    for (double v : lp.q) lp.scale_q = std::max(lp.scale_q, std::fabs(v));
+    for (double v : lp.w) lp.scale_q = std::max(lp.scale_q, std::fabs(v));
+
+    Solver::EqpOut o;
+    out.status = sv.solve_scaled(&h->warm[slot], h->hint[slot]);
+    if (out.status == ASM_OPTIMAL) {
+        sv.as_download(o, out.as);
+        const ActiveSet& prev = h->warm[slot];
+        h->hint[slot].stable = prev.valid && prev.rowst == out.as.rowst && prev.bst == out.as.bst && prev.sst == out.as.sst;
+        h->warm[slot] = out.as;
+        h->last = out.as;
+        // unscale - bound-active components are exactly on their bound
+        out.p.resize(n); out.z.resize(n); out.y.resize(M); out.s.resize(lp.ns);
+        for (int64_t j = 0; j < n; ++j) {
+            double pj = o.p[j] * c[j];
+            pj = std::min(std::max(pj, L.lb[j]), L.ub[j]);
+            if (out.as.bst[j] < 0) pj = L.lb[j];
+            else if (out.as.bst[j] > 0) pj = L.ub[j];
+            out.p[j] = pj;
+            out.z[j] = o.z[j] * kap / c[j];                  // z = q - J'y  ==  kap * zhat / c
+        }
+        for (int64_t i = 0; i < M; ++i) {
+            double yi = o.y[i] * kap / rho[i];
+            // multipliers with the sign their row type admits (a simplex code returns sign-feasible duals)
+            if (h->rtype[i] == 1) yi = std::max(yi, 0.0);
+            else if (h->rtype[i] == -1) yi = std::min(yi, 0.0);
+            out.y[i] = yi;
+        }
+        for (int64_t k = 0; k < lp.ns; ++k) out.s[k] = o.s[k] * rho[h->srow[k]];
+    } else {
+        h->last = ActiveSet();
+    }
+    sv.dev.resolve_timing();
+    check_panel_timeout(h);
+}
+
 void do_solve(asm_handle* h, double delta, int feasibility, double* p_out, double* lambda, double* mult_x_U, double* mult_x_L,
               double* p_slack, int32_t* status) {
     if (!h->setup_done || !h->inputs_ready) throw std::logic_error("inputs have not been uploaded");
@@ -1780,120 +1857,95 @@ void do_solve(asm_handle* h, double delta, int feasibility, double* p_out, doubl
     auto t0 = std::chrono::steady_clock::now();
     const int64_t n = h->n, m = h->m, M = h->M;
     const bool fr = feasibility != 0;
-    Solver sv(h);
-    SLP& lp = sv.lp;
-    std::memset(&h->stats, 0, sizeof(h->stats));
-    lp.n = n; lp.M = M; lp.ns = fr ? h->ns : 0;
-    lp.rtype = h->rtype.data(); lp.srow = h->srow.data(); lp.scoef = h->scoef.data();
-    h->stats.M = (int)M; h->stats.n = (int)n; h->stats.ns = (int)lp.ns;
-
+    LpRaw L;
+    L.slacks = fr;
     // trust region intersected with the variable bounds (subproblem.jl:427-434)
-    vec lb(n), ub(n), c(n), rel(n);
-    // Jacobian -> dense rows incl. range rows; scaled copy (column scale = min(box, matrix cap), oracle: scale_lp)
-    sv.dev.assemble();
-    sv.dev.col_relmax(rel.data());
+    L.lb.resize(n); L.ub.resize(n);
     for (int64_t j = 0; j < n; ++j) {
-        ub[j] = std::min(delta, h->v_ub[j] - h->x_k[j]);
-        lb[j] = std::max(-delta, h->v_lb[j] - h->x_k[j]);
-        double c_mat = rel[j] > 0.0 ? 1.0 / rel[j] : 1.0;
-        c[j] = pow2_round(std::min(std::max(ub[j], -lb[j]), c_mat));
+        L.ub[j] = std::min(delta, h->v_ub[j] - h->x_k[j]);
+        L.lb[j] = std::max(-delta, h->v_lb[j] - h->x_k[j]);
     }
-    vec rho(M);
-    sv.dev.scale(c.data(), rho.data());
-    sv.dev.tile_flags();
-
     // feasibility-restoration shift (subproblem.jl:287-295) and slack lower bounds (:298-381)
-    vec b(h->E), viol(m, 0.0), slo_un;
+    vec b(h->E);
     if (fr) {
-        slo_un.reserve(h->ns);
+        L.slo.reserve(h->ns);
         for (int64_t i = 0; i < m; ++i) {
             double v = 0.0;
             if (h->E[i] > h->c_ub[i]) v = h->c_ub[i] - h->E[i];
             else if (h->E[i] < h->c_lb[i]) v = h->c_lb[i] - h->E[i];
-            viol[i] = v;
             b[i] -= std::fabs(v);
             if (h->nslack[i] == 2) {
-                if (v < 0) { slo_un.push_back(0.0); slo_un.push_back(v); }
-                else { slo_un.push_back(-v); slo_un.push_back(0.0); }
+                if (v < 0) { L.slo.push_back(0.0); L.slo.push_back(v); }
+                else { L.slo.push_back(-v); L.slo.push_back(0.0); }
             } else {
-                slo_un.push_back(-std::fabs(v));
+                L.slo.push_back(-std::fabs(v));
             }
         }
     }
     // right-hand sides (subproblem.jl:461-484)
-    vec r(M);
-    for (int64_t i = 0; i < m; ++i) r[i] = h->kind[i] == -1 ? h->c_ub[i] - b[i] : h->c_lb[i] - b[i];
-    for (int64_t k = 0; k < h->nadj; ++k) r[m + k] = h->c_ub[h->adj[k]] - b[h->adj[k]];
+    L.r.resize(M);
+    for (int64_t i = 0; i < m; ++i) L.r[i] = h->kind[i] == -1 ? h->c_ub[i] - b[i] : h->c_lb[i] - b[i];
+    for (int64_t k = 0; k < h->nadj; ++k) L.r[m + k] = h->c_ub[h->adj[k]] - b[h->adj[k]];
     // objective (subproblem.jl:250-272 | 384-405)
-    vec q(n, 0.0), w(lp.ns, fr ? 1.0 : 0.0);
-    if (!fr) q = h->df;
+    L.q.assign(n, 0.0);
+    L.w.assign(fr ? h->ns : 0, 1.0);
+    if (!fr) L.q = h->df;
 
-    // scaling (oracle: scale_lp)
-    lp.q.resize(n); lp.lb.resize(n); lp.ub.resize(n); lp.r.resize(M); lp.w.resize(lp.ns); lp.slo.resize(lp.ns);
-    double qmax = 0.0;
-    for (int64_t j = 0; j < n; ++j) { lp.q[j] = q[j] * c[j]; qmax = std::max(qmax, std::fabs(lp.q[j])); }
-    for (int64_t k = 0; k < lp.ns; ++k) { lp.w[k] = w[k] * rho[h->srow[k]]; qmax = std::max(qmax, std::fabs(lp.w[k])); }
-    double kap = pow2_round(qmax);
-    for (int64_t j = 0; j < n; ++j) { lp.q[j] /= kap; lp.lb[j] = lb[j] / c[j]; lp.ub[j] = ub[j] / c[j]; }
-    for (int64_t k = 0; k < lp.ns; ++k) { lp.w[k] /= kap; lp.slo[k] = slo_un[k] / rho[h->srow[k]]; }
-    for (int64_t i = 0; i < M; ++i) lp.r[i] = r[i] / rho[i];
-    lp.scale_q = 1.0;
-    for (double v : lp.q) lp.scale_q = std::max(lp.scale_q, std::fabs(v));
-    for (double v : lp.w) lp.scale_q = std::max(lp.scale_q, std::fabs(v));
-
-    Solver::EqpOut o;
-    ActiveSet as;
-    int st = sv.solve_scaled(&h->warm[fr ? 1 : 0], h->hint[fr ? 1 : 0]);
-    *status = st;
-    if (st == ASM_OPTIMAL) sv.as_download(o, as);
-
+    LpSol sol;
+    solve_raw(h, L, fr ? 1 : 0, sol);
+    *status = sol.status;
     for (int64_t j = 0; j < n; ++j) { p_out[j] = 0.0; mult_x_U[j] = 0.0; mult_x_L[j] = 0.0; }
     for (int64_t i = 0; i < m; ++i) { lambda[i] = 0.0; p_slack[2 * i] = 0.0; p_slack[2 * i + 1] = h->nslack[i] == 2 ? 0.0 : std::nan(""); }
-    if (st == ASM_OPTIMAL) {
-        {
-            const ActiveSet& prev = h->warm[fr ? 1 : 0];
-            h->hint[fr ? 1 : 0].stable = prev.valid && prev.rowst == as.rowst && prev.bst == as.bst && prev.sst == as.sst;
-        }
-        h->warm[fr ? 1 : 0] = as;
-        h->last = as;
-        // unscale (oracle: solve_lp) - bound-active components are exactly on their bound
-        vec y(M), z(n);
-        for (int64_t j = 0; j < n; ++j) {
-            double pj = o.p[j] * c[j];
-            pj = std::min(std::max(pj, lb[j]), ub[j]);
-            if (as.bst[j] < 0) pj = lb[j];
-            else if (as.bst[j] > 0) pj = ub[j];
-            p_out[j] = pj;                                                     // subproblem.jl:502
-        }
-        for (int64_t i = 0; i < M; ++i) y[i] = o.y[i] * kap / rho[i];
-        // reduced costs in caller units: z = q - J'y  ==  kap * zhat / c
-        for (int64_t j = 0; j < n; ++j) z[j] = o.z[j] * kap / c[j];
+    if (sol.status == ASM_OPTIMAL) {
+        for (int64_t j = 0; j < n; ++j) p_out[j] = sol.p[j];                                    // subproblem.jl:502
         if (fr) {
             int64_t k = 0;
             for (int64_t i = 0; i < m; ++i)
-                for (int t = 0; t < h->nslack[i]; ++t, ++k) p_slack[2 * i + t] = o.s[k] * rho[h->srow[k]];   // :503-505
+                for (int t = 0; t < h->nslack[i]; ++t, ++k) p_slack[2 * i + t] = sol.s[k];       // :503-505
         }
-        for (int64_t i = 0; i < M; ++i) {
-            if (h->rtype[i] == 1) y[i] = std::max(y[i], 0.0);
-            else if (h->rtype[i] == -1) y[i] = std::min(y[i], 0.0);
-        }
-        for (int64_t i = 0; i < m; ++i) lambda[i] = y[i];                       // :510-512
-        for (int64_t k = 0; k < h->nadj; ++k) lambda[h->adj[k]] += y[m + k];    // :513-515
-        for (int64_t j = 0; j < n; ++j) {                                       // :519-529
-            bool fixed = ub[j] <= lb[j];
-            double mL = as.bst[j] < 0 ? std::max(z[j], 0.0) : 0.0;
-            double mU = as.bst[j] > 0 ? std::min(z[j], 0.0) : 0.0;
-            if (fixed) mU = std::min(z[j], 0.0);
+        for (int64_t i = 0; i < m; ++i) lambda[i] = sol.y[i];                                   // :510-512
+        for (int64_t k = 0; k < h->nadj; ++k) lambda[h->adj[k]] += sol.y[m + k];                // :513-515
+        for (int64_t j = 0; j < n; ++j) {                                                       // :519-529
+            bool fixed = L.ub[j] <= L.lb[j];
+            double mL = sol.as.bst[j] < 0 ? std::max(sol.z[j], 0.0) : 0.0;
+            double mU = sol.as.bst[j] > 0 ? std::min(sol.z[j], 0.0) : 0.0;
+            if (fixed) mU = std::min(sol.z[j], 0.0);
             if (p_out[j] < h->v_ub[j] - h->x_k[j]) mU = 0.0;
             if (p_out[j] > h->v_lb[j] - h->x_k[j]) mL = 0.0;
             mult_x_L[j] = mL;
             mult_x_U[j] = mU;
         }
-    } else {
-        h->last = ActiveSet();
     }
-    sv.dev.resolve_timing();
-    check_panel_timeout(h);
+    h->stats.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// The LP itself, as an MOI optimizer receives it from the reference (subproblem.jl:250-484): for AsmHip.Optimizer
+void do_lp_solve(asm_handle* h, const double* dE, const double* q, const double* r, const double* lb, const double* ub, int use_slacks,
+                 const double* w, const double* slo, double* p, double* s, double* y, double* z, int32_t* bound_state, int32_t* status) {
+    if (!h->setup_done) throw std::logic_error("asm_lp_solve: asm_sublp_setup first");
+    HIPCHK(hipSetDevice(h->device));
+    auto t0 = std::chrono::steady_clock::now();
+    const int64_t n = h->n, M = h->M;
+    for (int64_t j = 0; j < n; ++j)
+        if (!(lb[j] > -INF && ub[j] < INF && lb[j] <= ub[j])) throw std::invalid_argument("asm_lp_solve: every structural column needs a finite box (the trust region)");
+    HIPCHK(hipMemcpyAsync(h->d_dE, dE, h->nnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->J_valid = false;
+    LpRaw L;
+    L.slacks = use_slacks != 0;
+    L.q.assign(q, q + n); L.r.assign(r, r + M); L.lb.assign(lb, lb + n); L.ub.assign(ub, ub + n);
+    if (L.slacks) { L.w.assign(w, w + h->ns); L.slo.assign(slo, slo + h->ns); }
+    LpSol sol;
+    solve_raw(h, L, L.slacks ? 1 : 0, sol);
+    *status = sol.status;
+    for (int64_t j = 0; j < n; ++j) { p[j] = 0.0; z[j] = 0.0; if (bound_state) bound_state[j] = 0; }
+    for (int64_t i = 0; i < M; ++i) y[i] = 0.0;
+    if (s) for (int64_t k = 0; k < h->ns; ++k) s[k] = L.slacks ? slo[k] : 0.0;
+    if (sol.status == ASM_OPTIMAL) {
+        for (int64_t j = 0; j < n; ++j) { p[j] = sol.p[j]; z[j] = sol.z[j]; if (bound_state) bound_state[j] = sol.as.bst[j]; }
+        for (int64_t i = 0; i < M; ++i) y[i] = sol.y[i];
+        if (s && L.slacks) for (int64_t k = 0; k < h->ns; ++k) s[k] = sol.s[k];
+    }
     h->stats.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
@@ -2017,6 +2069,29 @@ int asm_sublp_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int6
     });
 }
 
+int asm_sublp_set_bounds(asm_handle* h, const double* c_lb, const double* c_ub, const double* v_lb, const double* v_ub) {
+    return guarded(h, [&] {
+        if (!h->setup_done) throw std::logic_error("asm_sublp_set_bounds: asm_sublp_setup first");
+        if ((h->m > 0 && (!c_lb || !c_ub)) || !v_lb || !v_ub) throw std::invalid_argument("asm_sublp_set_bounds: null pointer");
+        for (int64_t i = 0; i < h->m; ++i)
+            if (row_kind(c_lb[i], c_ub[i]) != h->kind[i])
+                throw std::invalid_argument("asm_sublp_set_bounds: the kind of a row changes - the LP skeleton is not representable (call asm_sublp_setup)");
+        HIPCHK(hipSetDevice(h->device));
+        h->c_lb.assign(c_lb, c_lb + h->m); h->c_ub.assign(c_ub, c_ub + h->m);
+        h->v_lb.assign(v_lb, v_lb + h->n); h->v_ub.assign(v_ub, v_ub + h->n);
+        if (h->ev_ready) {              // the reductions' copy of the bounds
+            HIPCHK(hipMemcpy(h->d_ev_vecs, h->c_lb.data(), h->m * sizeof(double), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(h->d_ev_vecs + h->m, h->c_ub.data(), h->m * sizeof(double), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(h->d_ev_vecs + 2 * h->m, h->v_lb.data(), h->n * sizeof(double), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(h->d_ev_vecs + 2 * h->m + h->n, h->v_ub.data(), h->n * sizeof(double), hipMemcpyHostToDevice));
+        }
+        h->warm[0] = ActiveSet(); h->warm[1] = ActiveSet(); h->last = ActiveSet();
+        h->hint[0] = SolveHint(); h->hint[1] = SolveHint();
+        h->hint[1].prefer_ref = true;
+        h->inputs_ready = false;
+    });
+}
+
 int asm_sublp_upload(asm_handle* h, const double* dE, const double* df, double f, const double* E, const double* x_k) {
     return guarded(h, [&] {
         if ((h->nnz > 0 && !dE) || !df || (h->m > 0 && !E) || !x_k) throw std::invalid_argument("asm_sublp_upload: null pointer");
@@ -2040,6 +2115,15 @@ int asm_sublp_solve(asm_handle* h, const double* dE, const double* df, double f,
     int rc = asm_sublp_upload(h, dE, df, f, E, x_k);
     if (rc != ASM_OK) return rc;
     return asm_sublp_solve_resident(h, delta, feasibility, p, lambda, mult_x_U, mult_x_L, p_slack, status);
+}
+
+int asm_lp_solve(asm_handle* h, const double* dE, const double* q, const double* r, const double* lb, const double* ub, int use_slacks,
+                 const double* w, const double* slo, double* p, double* s, double* y, double* z, int32_t* bound_state, int32_t* status) {
+    return guarded(h, [&] {
+        if ((h->nnz > 0 && !dE) || !q || (h->M > 0 && (!r || !y)) || !lb || !ub || !p || !z || !status || (use_slacks && (!w || !slo)))
+            throw std::invalid_argument("asm_lp_solve: null pointer");
+        do_lp_solve(h, dE, q, r, lb, ub, use_slacks, w, slo, p, s, y, z, bound_state, status);
+    });
 }
 
 int asm_sublp_active_set(const asm_handle* h, int32_t* row_state, int32_t* bound_state, int32_t* slack_state, int64_t* n_rows,

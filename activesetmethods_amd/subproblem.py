@@ -53,6 +53,15 @@ class HipSubOptimizer:
                                               _lib.dptr(v_lb), _lib.dptr(v_ub)))
         self.nslack = np.where((c_lb > -np.inf) & (c_ub < np.inf), 2, 1)
 
+    def set_bounds(self, data):
+        """Re-use the handle (all its HBM buffers, the assembly plan, the device evaluator) for another instance with the same
+        pattern and new bounds - the next scenario of a batch."""
+        c_lb, c_ub, v_lb, v_ub = map(_f64, (data.c_lb, data.c_ub, data.v_lb, data.v_ub))
+        assert len(c_lb) == self.m and len(v_lb) == self.n
+        self._check(self._lib.asm_sublp_set_bounds(self._h, _lib.dptr(c_lb), _lib.dptr(c_ub), _lib.dptr(v_lb), _lib.dptr(v_ub)))
+        self.data = data
+        self.nslack = np.where((c_lb > -np.inf) & (c_ub < np.inf), 2, 1)
+
     def _check(self, rc):
         if rc != 0:
             raise AsmHipError("libasmhip error %d: %s" % (rc, self._lib.asm_last_error(self._h).decode()))
@@ -93,6 +102,19 @@ class HipSubOptimizer:
         for i in range(m):                                       # Dict{Int,Vector{Float64}}, subproblem.jl:495-505
             p_slack[i] = [float(ps[2 * i])] if self.nslack[i] == 1 else [float(ps[2 * i]), float(ps[2 * i + 1])]
         return Xsol, lam, mU, mL, p_slack, int(status.value)
+
+    def lp_solve(self, dE, q, r, lb, ub, w=None, slo=None):
+        """The LP as an MOI optimizer receives it (include/asm_hip.h: asm_lp_solve): returns (p, s, y, z, bound_state, status)."""
+        dE, q, r, lb, ub = map(_f64, (dE, q, r, lb, ub))
+        use = w is not None
+        ns = int(self.nslack.sum())
+        w_, slo_ = (_f64(w), _f64(slo)) if use else (np.zeros(1), np.zeros(1))
+        p = np.empty(self.n); s = np.empty(max(ns, 1)); y = np.empty(max(len(r), 1)); z = np.empty(self.n)
+        bs = np.empty(self.n, np.int32); status = C.c_int32(0)
+        self._check(self._lib.asm_lp_solve(self._h, _lib.dptr(dE), _lib.dptr(q), _lib.dptr(r), _lib.dptr(lb), _lib.dptr(ub), int(use),
+                                           _lib.dptr(w_), _lib.dptr(slo_), _lib.dptr(p), _lib.dptr(s), _lib.dptr(y), _lib.dptr(z),
+                                           _lib.i32ptr(bs), C.byref(status)))
+        return p, s[:ns], y[:len(r)], z, bs, int(status.value)
 
     # ------------------------------------------------------------------ observability
     def active_set(self):

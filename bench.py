@@ -81,14 +81,25 @@ WORKLOADS = {
 
 def run_batch(args, rank, world, local_rank, dist, torch):
     """Workload c5: scenarios are block-partitioned over ranks (activesetmethods_amd.batch), every rank solves its share
-    on its own GPU with one persistent handle, no data-path collective; one all-reduce merges the statistics."""
+    on its own GPU - `--concurrency` scenarios at a time, each worker thread with one persistent handle that moves from scenario to
+    scenario through asm_sublp_set_bounds (nothing is re-allocated) -, no data-path collective; one all-reduce merges the statistics."""
     import activesetmethods_amd as A
     from activesetmethods_amd import acopf, batch
     base = acopf.synthetic_case("case300", 1, 0.5)     # half the nominal synthetic load: Line-Search SLP converges in ~30 iterations
     per_gpu = args.steps
     total = per_gpu * world
-    def factory(d, r, c):                   # constraint bounds (the loads) differ per scenario: one LP skeleton = one handle each
-        return A.HipSubOptimizer(d, r, c, device=local_rank)
+    import threading
+    tls = threading.local()                 # one handle per worker thread of the stream pool, kept for the whole batch
+
+    def factory(d, r, c):                   # scenarios differ in constraint bounds only (the loads): same pattern, same LP skeleton
+        opt = getattr(tls, "opt", None)
+        if opt is None:
+            opt = tls.opt = A.HipSubOptimizer(d, r, c, device=local_rank)
+            tls.fresh = True
+        else:
+            opt.set_bounds(d)               # keeps J, Ah, S, the assembly plan and the evaluator's function store in HBM
+            tls.fresh = False
+        return opt
 
     def make_model(sidx):
         pr = acopf.function_model(acopf.scenario_case(base, sidx)).to_problem("case300-sized scenario %d" % sidx)
@@ -96,10 +107,7 @@ def run_batch(args, rank, world, local_rank, dist, torch):
                                                      device_eval=not args.host_eval))
 
     def run(model, max_lp_solves=None):
-        slp = A.optimize(model, max_lp_solves)
-        if slp.optimizer is not None:
-            slp.optimizer.close()           # frees the handle's HBM; the statistics live on the SLP object
-        return slp
+        return A.optimize(model, max_lp_solves)     # the handle stays with the worker thread (closed when the pool ends)
 
     if args.warmup:
         run(make_model(10 ** 6 + rank), 2)

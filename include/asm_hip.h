@@ -48,6 +48,12 @@ int asm_sublp_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz,
                     const double* c_lb, const double* c_ub,
                     const double* v_lb, const double* v_ub);
 
+/* Same pattern, new bounds (a new scenario of a batch: the loads of an ACOPF scenario are constraint bounds): keeps every
+ * device buffer, the assembly plan and the evaluator's function store; the retained active sets are dropped.  The kind of
+ * each row (==, range, >= only, <= only) must not change - that would be another LP skeleton (create_model!,
+ * subproblem.jl:137-214): ASM_ERR_UNSUPPORTED. */
+int asm_sublp_set_bounds(asm_handle* h, const double* c_lb, const double* c_ub, const double* v_lb, const double* v_ub);
+
 /* Replaces sub_optimize!(qp, x_k, Δ, feasibility) (subproblem.jl:229-542) with data = LpData(slp)
  * (slp.jl:8-21): dE = Jacobian values in j_str order, df = gradient (c), f = objective value (c0),
  * E = constraint values (b).
@@ -68,6 +74,18 @@ int asm_sublp_upload(asm_handle* h, const double* dE, const double* df, double f
 int asm_sublp_solve_resident(asm_handle* h, double delta, int feasibility,
                              double* p, double* lambda, double* mult_x_U, double* mult_x_L, double* p_slack,
                              int32_t* status);
+
+/* The LP itself, in the form an MOI `external_optimizer` receives it from the UNMODIFIED reference (subproblem.jl:250-484):
+ * after asm_sublp_setup has fixed the skeleton (row kinds -> row types and slack layout of create_model!, subproblem.jl:83-214),
+ *   min q'p + w's   s.t.  J_i p + (slack terms of row i) (= | >= | <=) r_i ,  lb <= p <= ub (finite) ,  s >= slo
+ * with J from dE (j_str order), r of length m + n_adj (rows m.. = the extra `<=` rows of range constraints, subproblem.jl:200-214).
+ * use_slacks = 0: all slack columns fixed at 0 (normal phase, subproblem.jl:410-423), w / slo ignored.
+ * Outputs: p[n], s[n_slack] (may be NULL), y[m + n_adj] row duals in the MOI sign convention, z[n] = q - J'y reduced costs,
+ * bound_state[n] (-1 at lower, +1 at upper, 0 between; may be NULL), status.  This is what AsmHip.Optimizer calls
+ * from MOI.optimize!; asm_sublp_solve is the same solve with the formulation done inside the library. */
+int asm_lp_solve(asm_handle* h, const double* dE, const double* q, const double* r, const double* lb, const double* ub,
+                 int use_slacks, const double* w, const double* slo,
+                 double* p, double* s, double* y, double* z, int32_t* bound_state, int32_t* status);
 
 /* Active set of the last OPTIMAL solve, as the reference could observe it from the LP solution:
  * row_state[m+nadj]: 1 active / 0 inactive (rows m.. are the extra `<=` rows of range constraints,

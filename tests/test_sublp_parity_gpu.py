@@ -310,3 +310,35 @@ def test_full_size_restoration_lp_properties(name, delta):
     opt, out = hip_solve(sp, True)
     _restoration_lp_properties(sp, out)
     opt.close()
+
+
+@pytest.mark.parametrize("seed,infeasible", [(61, False), (62, True)])
+def test_lp_entry_for_an_moi_optimizer(seed, infeasible):
+    """asm_lp_solve takes the LP the way an MOI `external_optimizer` gets it from the unmodified reference (objective, row
+    right-hand sides incl. the extra rows of range constraints, column box, slack weights and lower bounds -
+    subproblem.jl:250-484) - here produced by the oracle's build_lp.  It must return what asm_sublp_solve returns for the
+    same sub-problem (the formulation done inside the library), in both phases."""
+    from activesetmethods_amd.subproblem import QpData, HipSubOptimizer
+    sp = random_subproblem(seed, 50, 36, 0.4, 0.2, 4, infeasible=infeasible)
+    qp, o_out = oracle_solve(sp)
+    opt, h_out = hip_solve(sp)
+    fr = o_out[5] == 2
+    if fr:
+        qp, o_out = oracle_solve(sp, True, qp)
+        opt, h_out = hip_solve(sp, True, opt)
+    assert o_out[5] == h_out[5] == 1
+    lp = qp.build_lp(sp['x_k'], sp['delta'], fr)
+    opt2 = HipSubOptimizer(QpData(sp['df'], sp['f'], sp['dE'], sp['E'], sp['c_lb'], sp['c_ub'], sp['v_lb'], sp['v_ub']), sp['j_row'], sp['j_col'])
+    p, s, y, z, bs, st = opt2.lp_solve(sp['dE'], lp.q, lp.r, lp.lb, lp.ub, lp.w if fr else None, lp.slo if fr else None)
+    assert st == 1
+    assert rel_err(p, h_out[0]) < 1e-12
+    m = sp['m']
+    lam = y[:m].copy()
+    for k, val in enumerate(qp.adj):
+        lam[val] += y[m + k]
+    assert rel_err(lam, h_out[1]) < 1e-12
+    if fr:
+        flat = np.concatenate([np.asarray(h_out[4][i], float) for i in range(m)])
+        assert rel_err(s, flat) < 1e-12
+    assert np.array_equal(bs, opt.active_set()[1])
+    opt.close(); opt2.close()
