@@ -184,6 +184,7 @@ struct asm_handle {
     bool fused_panel = true;        // Cholesky inner panels as one dataflow launch (k_chol_panel) instead of three launches per 64-wide step
     int panel_wgs = 240;            // its grid bound: every workgroup must be able to become resident
     unsigned *d_pflags = nullptr, *d_ptmo = nullptr;
+    unsigned panel_epoch = 0;
     int timing = 1;                 // HIP-event timing: 0 off, 1 the dominant kernel only (every k_syrk launch), 2 every kernel family
     bool verbose = false;
 };
@@ -196,6 +197,7 @@ namespace {
 struct Dev {
     asm_handle* h;
     hipStream_t cur;                 // stream the factorisation kernels are launched on (h->stream, or the look-ahead stream)
+    double* solve_w = nullptr;       // buffer the wide-block substitution runs in (default d_vecM2)
     explicit Dev(asm_handle* hh) : h(hh), cur(hh->stream) {}
 
     hipEvent_t get_event() {
@@ -410,11 +412,13 @@ struct Dev {
         return tot > 0 ? act / tot : 1.0;
     }
     void chol_solve_dev(const double* rhs_dev, double* out_dev, int Ms) {
-        HIPCHK(hipMemcpyAsync(h->d_vecM2, rhs_dev, Ms * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        // the substitution runs in place in the caller's output buffer (w), z in d_vecM
+        if (out_dev != rhs_dev) HIPCHK(hipMemcpyAsync(out_dev, rhs_dev, Ms * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         int id = begin(ASM_K_TRSV, 2.0 * Ms * (double)Ms, 8.0 * Ms * (double)Ms);
-        run_sequence(3, Ms, Ms == (int)h->M, [&] { solve_launches(Ms); });
+        solve_w = out_dev;
+        run_sequence(3, Ms, false, [&] { solve_launches(Ms); });
+        solve_w = h->d_vecM2;
         end(id);
-        HIPCHK(hipMemcpyAsync(out_dev, h->d_vecM2, Ms * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     }
 
     static int pick_tile(int64_t Ms) { return Ms >= 3072 ? 4 : (Ms >= 768 ? 2 : 1); }
@@ -439,7 +443,14 @@ struct Dev {
         // timed on the stream it is launched on (HIP events see only their own stream)
         int kid = h->use_graphs ? -1 : begin(ASM_K_SYRK_KERNEL, fl, 8.0 * ((double)(Ms + MsB) * K + (double)Ms * MsB), cur);
         struct EndGuard { Dev* d; int id; ~EndGuard() { d->end(id); } } guard_{this, kid};
-        if (T == 4 && mode == 1 && !nz && K % 16 == 0)      // Cholesky updates: 16-wide k-chunks, two workgroups per CU
+        static const int variant = [] { const char* v = std::getenv("ASM_SYRK_VARIANT"); return v ? std::atoi(v) : 0; }();
+        if (T == 4 && mode == 1 && !nz && K % 16 == 0 && variant == 1)      // experiment: 4 wavefronts, 64 x 64 per wavefront
+            hipLaunchKernelGGL((k_syrk<4, 4, 16, 2>), dim3((unsigned)blocks), dim3(256), 0, cur, A, ld, idx, row0, Ms, K, theta, diag, S,
+                               ldS, srow0, mode, MsB, ntj, nz, nzpitch);
+        else if (T == 4 && mode == 1 && !nz && K % 32 == 0 && variant == 2)
+            hipLaunchKernelGGL((k_syrk<4, 8, 32, 2>), dim3((unsigned)blocks), dim3(512), 0, cur, A, ld, idx, row0, Ms, K, theta, diag, S,
+                               ldS, srow0, mode, MsB, ntj, nz, nzpitch);
+        else if (T == 4 && mode == 1 && !nz && K % 16 == 0)      // Cholesky updates: 16-wide k-chunks, two workgroups per CU
             hipLaunchKernelGGL((k_syrk<4, 8, 16, 4>), dim3((unsigned)blocks), dim3(512), 0, cur, A, ld, idx, row0, Ms, K, theta, diag, S,
                                ldS, srow0, mode, MsB, ntj, nz, nzpitch);
         else if (T == 4)
@@ -533,10 +544,13 @@ struct Dev {
                 // the <= 4 steps of this inner panel in one dataflow launch (k_chol_panel): row tiles are owned by workgroups,
                 // diagonal-block factors and the panel tiles other workgroups need travel through release / acquire flags
                 const int nrt = (Ms - I0 + ASM_NB - 1) / ASM_NB;
-                const int G = std::min(nrt, h->panel_wgs);
-                HIPCHK(hipMemsetAsync(h->d_pflags, 0, 32 * sizeof(unsigned), cur));
+                // grid: one workgroup per row tile while they all fit (77 KB of LDS: two per CU); measured: fewer workgroups with several
+                // tiles each lengthen every step (M = 11192: 16.7 ms with one tile per workgroup, 21.1 ms with three)
+                const int G = std::max(1, std::min(nrt, h->panel_wgs));
+                h->panel_epoch += 1;              // flags are "set" when they hold this launch's epoch: no reset between launches
+                if (h->panel_epoch == 0) h->panel_epoch = 1;
                 hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)G), dim3(256), 0, cur, h->d_S, h->Mp, I0, std::min(I1, Ms), Ms, (const double*)h->d_diag0, thr,
-                                   h->d_Linv, h->d_pflags, h->d_ptmo);
+                                   h->d_Linv, h->d_pflags, h->d_ptmo, h->panel_epoch);
             } else
             for (int k0 = I0; k0 < I1; k0 += ASM_NB) {
                 int nb = std::min(ASM_NB, Ms - k0);
@@ -610,7 +624,7 @@ struct Dev {
     template <int WB>
     void solve_launches_wb(int Ms) {
         // forward: w = copy of rhs (d_vecM2, updated in place), z -> d_vecM ; backward: x -> d_vecM2 (w is dead by then)
-        double* w = h->d_vecM2;
+        double* w = solve_w ? solve_w : h->d_vecM2;
         double* z = h->d_vecM;
         const int nB = (Ms + WB - 1) / WB;
         for (int B = 0; B < nB; ++B) {
@@ -1675,6 +1689,7 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     dmalloc(&h->d_pflags, 32);
     dmalloc(&h->d_ptmo, 4);
     HIPCHK(hipMemsetAsync(h->d_ptmo, 0, 4 * sizeof(unsigned), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_pflags, 0, 32 * sizeof(unsigned), h->stream));
     h->wb = h->M > 1536 ? 1024 : 512;      // wide-block width of the triangular solves (k_wtrsv_*<WB>)
     if (h->M >= RED_MIN_M) {
         dmalloc(&h->d_idxI, h->Mp); dmalloc(&h->d_rdI, h->Mp); dmalloc(&h->d_rce, h->Mp); dmalloc(&h->d_rze, h->Mp); dmalloc(&h->d_sdiag, h->Mp);
@@ -2035,7 +2050,8 @@ int asm_create(int device, asm_handle** out) {
     h->fused_panel = !(fp && fp[0] == '0');
     {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 16) h->panel_wgs = prop.multiProcessorCount - 16;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 16) h->panel_wgs = 2 * prop.multiProcessorCount - 32;
+        if (const char* pw = std::getenv("ASM_PANEL_WGS")) h->panel_wgs = std::max(1, std::atoi(pw));
     }
     const char* gr = std::getenv("ASM_HIP_GRAPHS");
     h->use_graphs = gr && gr[0] == '1';      // opt-in: no measured gain on this ROCm build, and rocprofv3 crashes on captured streams

@@ -592,19 +592,20 @@ __global__ __launch_bounds__(256) void k_panel_update64(double* __restrict__ S, 
 // The owner of row tile k+1 factors diagonal block k+1 as soon as that tile has its step-k update (look-ahead): the
 // critical path of a step is  panel solve + update of ONE tile + the 64 x 64 factorisation, everything else overlaps.
 // Every workgroup must be able to become resident (G <= #CUs); every spin is bounded (tmo[0] != 0 -> the host fails the
-// factorisation).  Flags are zeroed by a memset node ahead of every launch.
+// factorisation).  A flag is "set" when it holds the launch's epoch (a per-handle counter, never 0, never repeated: the panel
+// launches of a handle are stream-ordered and not replayed from a graph), so the flag words need no reset between launches.
 // The payload is stored write-through (sc1: __hip_atomic_store relaxed / agent scope), so publishing needs no release fence
 // (which would write back every dirty line of the XCD's L2): every storing wavefront drains its stores, then one lane sets
 // the flag (Guideline 16, recipe R1).
-__device__ __forceinline__ void pnl_publish(unsigned* flag) {
+__device__ __forceinline__ void pnl_publish(unsigned* flag, unsigned epoch) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void pnl_wait(unsigned* flag, unsigned* tmo) {
+__device__ __forceinline__ void pnl_wait(unsigned* flag, unsigned epoch, unsigned* tmo) {
     if (threadIdx.x == 0) {
         unsigned spins = 0;
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) {
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
             __builtin_amdgcn_s_sleep(4);
             if (++spins > (1u << 22)) {                       // bounded: a lost producer must not hang the GPU
                 __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -619,7 +620,7 @@ __device__ __forceinline__ void pnl_wait(unsigned* flag, unsigned* tmo) {
 #define ASM_PNL_LDS (2 * ASM_NB * ASM_XP + 4 * 16 * 17 + 2 * ASM_NB)
 __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms,
                                                     const double* __restrict__ diag0, double thr, double* __restrict__ Linv,
-                                                    unsigned* __restrict__ flags, unsigned* __restrict__ tmo) {
+                                                    unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch) {
     __shared__ __attribute__((aligned(16))) double sm[ASM_PNL_LDS];
     double* B0 = sm;                                  // the tile being solved, then X
     double* B1 = sm + ASM_NB * ASM_XP;                // block inverse, then the right operand X(tj)
@@ -632,7 +633,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int6
     const int nrt = (Ms - I0 + ASM_NB - 1) / ASM_NB;
     if (wg == 0) {
         potrf64_body<true>(B0, B1, Tt, d0, dinv, S, ldS, I0, min(ASM_NB, Ms - I0), diag0, thr, Linv);
-        pnl_publish(flags + 0);
+        pnl_publish(flags + 0, epoch);
     }
     for (int k = 0; k < nsteps; ++k) {
         const int k0 = I0 + k * ASM_NB;
@@ -643,7 +644,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int6
         int rt = wg;
         while (rt <= k) rt += G;
         for (; rt < nrt; rt += G) {
-            if (!waited) { pnl_wait(flags + k, tmo); waited = true; }
+            if (!waited) { pnl_wait(flags + k, epoch, tmo); waited = true; }
             const int i0 = I0 + rt * ASM_NB;
             const double* Lb = Linv + (int64_t)(k0 / ASM_NB) * ASM_NB * ASM_NB;
             // ---- panel solve of the tile: X = S[tile, k0:k1] Linv'
@@ -681,7 +682,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int6
                         else *dst = acc[t][r];
                     }
                 }
-            if (rt < nsteps) pnl_publish(flags + 4 + 4 * k + rt);      // a later diagonal row tile: its X is an operand for others
+            if (rt < nsteps) pnl_publish(flags + 4 + 4 * k + rt, epoch);      // a later diagonal row tile: its X is an operand for others
             else __syncthreads();
             // ---- rank-64 update of the panel's remaining column tiles tj = k+1 .. min(rt, nsteps-1)
             const int tj_hi = min(rt, nsteps - 1);
@@ -689,7 +690,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int6
                 const int c0 = I0 + tj * ASM_NB, c_end = min(c0 + ASM_NB, min(I1, Ms));
                 const double* Pb = B0;
                 if (tj != rt) {
-                    pnl_wait(flags + 4 + 4 * k + tj, tmo);
+                    pnl_wait(flags + 4 + 4 * k + tj, epoch, tmo);
                     for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
                         int rr = e >> 6, c = e & 63;
                         B1[rr * ASM_XP + c] = (c0 + rr < Ms && c < nb) ? S[(int64_t)(c0 + rr) * ldS + k0 + c] : 0.0;
@@ -728,7 +729,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int6
                 __syncthreads();
                 const int kn = I0 + rt * ASM_NB;
                 potrf64_body<true>(B0, B1, Tt, d0, dinv, S, ldS, kn, min(ASM_NB, Ms - kn), diag0, thr, Linv);
-                pnl_publish(flags + rt);
+                pnl_publish(flags + rt, epoch);
             }
         }
     }

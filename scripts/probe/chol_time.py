@@ -1,5 +1,5 @@
 """Cholesky timing through the kernel test hook (development probe; GPU box).  usage: chol_time.py N [N ...]"""
-import sys, ctypes as C; sys.path.insert(0, '.')
+import os, sys, ctypes as C; sys.path.insert(0, "."); os.environ.setdefault("ASM_HIP_TIMING", "2")
 import numpy as np
 from activesetmethods_amd import _lib
 lib = _lib.load()
