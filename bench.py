@@ -459,7 +459,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             mix = dict(steps=args.steps, col_iters=sum(r["stats"].get("col_iters", 0) for r in timed),
                        row_iters=sum(r["stats"]["ipm_iters"] - r["stats"].get("col_iters", 0) for r in timed),
-                       eqp=sum(r["stats"]["eqp"] for r in timed))
+                       eqp=sum(max(r["stats"]["nfact"] - r["stats"]["ipm_iters"], 0) for r in timed))   # active-set FACTORISATIONS
             if not timed:
                 mix = dict(steps=args.steps, col_iters=0, row_iters=nfact, eqp=0)
             out["cpu_baseline"] = cpu_baseline(pr_host, args.algorithm, args.cpu_seconds, mix, timed)

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""profiles/r02_<wl>_pmc_mfma.txt, profiles/r02_<wl>_pmc_traffic.{txt,json} from the per-kernel sums scripts/probe/pmc_collect.sh
+leaves under gpurun_out/pmc_r02_{mfma,fetch,write}/ (three separate rocprofv3 --pmc passes of the same command).
+FETCH_SIZE is doubled for gfx950 as /opt/skills/guides/MI355X_MICROARCH.md prescribes (wide coalesced reads are tallied at 1/2).
+usage: pmc_summaries.py <workload>"""
+import json, sys
+wl = sys.argv[1]
+M = json.load(open("gpurun_out/pmc_r02_mfma/m_summary.json"))["sums"]
+F = json.load(open("gpurun_out/pmc_r02_fetch/f_summary.json"))["sums"]
+W = json.load(open("gpurun_out/pmc_r02_write/w_summary.json"))["sums"]
+CMD = "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+with open("profiles/r02_%s_pmc_mfma.txt" % wl, "w") as f:
+    f.write("# rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS --kernel-trace -- %s\n" % CMD)
+    f.write("# (workload %s, MI355X, round 2; counters collected in their own pass: kernels run serialised under --pmc, so these are the kernels ALONE on the chip)\n" % wl)
+    f.write("# mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (kernel time x 2.4 GHz x 1024 SIMDs); tflops = SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 / kernel time;\n")
+    f.write("# wait_any / wait_inst / active / wait_lds = share of SQ_WAVE_CYCLES\n")
+    f.write("%-28s %8s %10s %9s %8s %9s %9s %8s %9s\n" % ("kernel", "launches", "time_ms", "mfma_util", "tflops", "wait_any", "wait_inst", "active", "wait_lds"))
+    for k, v in sorted(M.items(), key=lambda kv: -kv[1].get("_duration_ns", 0))[:16]:
+        d = v.get("_duration_ns", 0.0) or 1.0
+        wc = v.get("SQ_WAVE_CYCLES", 0.0) or 1.0
+        f.write("%-28s %8d %10.1f %9.3f %8.2f %9.3f %9.3f %8.3f %9.3f\n" % (k[:28], v.get("_launches", 0), d / 1e6, v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (d * 2.4 * 1024),
+                v.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0) * 512 / d / 1e3, v.get("SQ_WAIT_ANY", 0.0) / wc, v.get("SQ_WAIT_INST_ANY", 0.0) / wc,
+                v.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, v.get("SQ_WAIT_INST_LDS", 0.0) / wc))
+syrk = sorted(k for k in F if k.startswith("k_syrk"))
+per = {}
+for k in syrk:
+    n = F[k].get("_launches", 0) or 1
+    per[k] = dict(launches=n, fetch_bytes=2.0 * F[k].get("FETCH_SIZE", 0.0) * 1024.0, write_bytes=W.get(k, {}).get("WRITE_SIZE", 0.0) * 1024.0,
+                  time_ms=F[k].get("_duration_ns", 0.0) / 1e6)
+dom = "k_syrk<4, 8, 16, 4>"
+L = sum(v["launches"] for v in per.values())
+doc = {"_comment": "HBM traffic per launch of the dominant kernel family k_syrk<T,NW,KC,WPE> on workload %s: rocprofv3 PMC, FETCH_SIZE and WRITE_SIZE in separate passes "
+                   "(KB; FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes), command: %s.  Made by scripts/pmc_summaries.py." % (wl, CMD),
+       "workload": wl, "kernel": "k_syrk<T,NW,KC,WPE> (all instantiations)", "launches": L,
+       "fetch_bytes_per_launch": sum(v["fetch_bytes"] for v in per.values()) / L, "write_bytes_per_launch": sum(v["write_bytes"] for v in per.values()) / L,
+       "traffic_bytes_per_launch": sum(v["fetch_bytes"] + v["write_bytes"] for v in per.values()) / L, "per_instantiation": per}
+json.dump(doc, open("profiles/r02_%s_pmc_traffic.json" % wl, "w"), indent=1)
+with open("profiles/r02_%s_pmc_traffic.txt" % wl, "w") as f:
+    f.write("# HBM traffic of the k_syrk kernels (PMC, separate passes, one counter per pass), MI355X, round 2\n")
+    f.write("#   rocprofv3 --pmc FETCH_SIZE --kernel-trace -- %s\n#   rocprofv3 --pmc WRITE_SIZE --kernel-trace -- %s\n" % (CMD, CMD))
+    f.write("# FETCH_SIZE / WRITE_SIZE are reported in KB; FETCH_SIZE x2 (gfx950: wide coalesced reads are tallied at 1/2, MI355X_MICROARCH.md, HBM section).\n")
+    f.write("%-24s %8s %16s %16s %12s\n" % ("kernel", "launches", "fetch MB/launch", "write MB/launch", "ms/launch"))
+    for k, v in per.items():
+        f.write("%-24s %8d %16.1f %16.1f %12.3f\n" % (k, v["launches"], v["fetch_bytes"] / v["launches"] / 1e6, v["write_bytes"] / v["launches"] / 1e6, v["time_ms"] / v["launches"]))
+    g = F.get("k_gemv_n", None)
+print(open("profiles/r02_%s_pmc_mfma.txt" % wl).read())
+print(open("profiles/r02_%s_pmc_traffic.txt" % wl).read())
