@@ -173,6 +173,10 @@ class AbstractSlpOptimizer:
 
     def _slack_arrays(self):
         m = self.problem.m
+        raw = getattr(self.p_slack, "raw", None)            # flat array of the C ABI (two entries per row, NaN = no second slack)
+        if raw is not None and m:
+            s2 = raw[1:2 * m:2]
+            return raw[0:2 * m:2].copy(), np.where(np.isnan(s2), 0.0, s2)
         s1 = np.array([self.p_slack[i][0] for i in range(m)]) if m else np.zeros(0)
         s2 = np.array([self.p_slack[i][1] if len(self.p_slack[i]) > 1 else 0.0 for i in range(m)]) if m else np.zeros(0)
         return s1, s2

@@ -18,6 +18,12 @@ class AsmHipError(RuntimeError):
     pass
 
 
+class PSlack(dict):
+    """`p_slack::Dict{Int,Vector{Float64}}` of subproblem.jl:495-505 that also keeps the flat array the C ABI returned (two entries
+    per row, NaN where a row has one slack), so that the device-side merit function gets it back without a Python loop."""
+    raw = None
+
+
 class QpData:
     """LpData(slp) of slp.jl:8-21: c = df, c0 = f, A = Jacobian (as COO values dE), b = E."""
 
@@ -98,9 +104,10 @@ class HipSubOptimizer:
         self._check(self._lib.asm_sublp_solve_resident(self._h, float(Delta), int(bool(feasibility)), _lib.dptr(Xsol),
                                                        _lib.dptr(lam), _lib.dptr(mU), _lib.dptr(mL), _lib.dptr(ps),
                                                        C.byref(status)))
-        p_slack = {}
-        for i in range(m):                                       # Dict{Int,Vector{Float64}}, subproblem.jl:495-505
-            p_slack[i] = [float(ps[2 * i])] if self.nslack[i] == 1 else [float(ps[2 * i]), float(ps[2 * i + 1])]
+        pl = ps.tolist()
+        one = (self.nslack == 1).tolist()
+        p_slack = PSlack((i, [pl[2 * i]] if one[i] else [pl[2 * i], pl[2 * i + 1]]) for i in range(m))   # subproblem.jl:495-505
+        p_slack.raw = ps
         return Xsol, lam, mU, mL, p_slack, int(status.value)
 
     def lp_solve(self, dE, q, r, lb, ub, w=None, slo=None):
@@ -190,12 +197,14 @@ class HipSubOptimizer:
 
     def slp_merit(self, mode, alpha, p, nu, p_slack, feasibility, prim_infeas):
         """mode 0: compute_phi(x, alpha, p) (slp.jl:79-115); mode 1: compute_derivative (slp.jl:122-147)."""
-        ps = np.full(2 * max(self.m, 1), np.nan)
-        for i in range(self.m):
-            v = p_slack.get(i, [0.0]) if p_slack else [0.0]
-            ps[2 * i] = v[0]
-            if len(v) > 1:
-                ps[2 * i + 1] = v[1]
+        ps = getattr(p_slack, "raw", None)
+        if ps is None:
+            ps = np.full(2 * max(self.m, 1), np.nan)
+            for i in range(self.m):
+                v = p_slack.get(i, [0.0]) if p_slack else [0.0]
+                ps[2 * i] = v[0]
+                if len(v) > 1:
+                    ps[2 * i + 1] = v[1]
         out = C.c_double(0.0)
         p, nu = _f64(p), _f64(nu)
         self._check(self._lib.asm_slp_merit(self._h, int(mode), float(alpha), _lib.dptr(p), _lib.dptr(nu), _lib.dptr(ps), int(bool(feasibility)),
