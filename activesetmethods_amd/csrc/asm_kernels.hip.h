@@ -396,7 +396,11 @@ __device__ __forceinline__ void potrf64_body(double* __restrict__ D, double* __r
             for (int j = 0; j < 16; ++j) {
                 double d = readlane_f64(a[j], j);
                 if (!(d > thr * d0[c0 + j])) d = 1e256;
-                double inv = rsqrt(d);                   // one transcendental on the dependent chain instead of sqrt + division
+                // 1/sqrt(d): hardware estimate (v_rsq_f64) + two Newton steps - the shortest dependent chain that is accurate to the
+                // last bits (the library rsqrt() adds range handling this pivot never needs: d is a guarded positive number)
+                double inv = __builtin_amdgcn_rsq(d);
+                inv = inv * fma(-0.5 * d * inv, inv, 1.5);
+                inv = inv * fma(-0.5 * d * inv, inv, 1.5);
                 double l = a[j] * inv;
                 if (lane == j) { l = d * inv; my_inv = inv; }
                 a[j] = l;
