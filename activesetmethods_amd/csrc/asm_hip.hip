@@ -183,6 +183,7 @@ struct asm_handle {
     bool use_graphs = false;
     bool fused_panel = true;        // Cholesky inner panels as one dataflow launch (k_chol_panel) instead of three launches per 64-wide step
     int panel_wgs = 240;            // its grid bound: every workgroup must be able to become resident
+    int num_cus = 256;              // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     unsigned *d_pflags = nullptr, *d_ptmo = nullptr;
     unsigned panel_epoch = 0;
     int timing = 1;                 // HIP-event timing: 0 off, 1 the dominant kernel only (every k_syrk launch), 2 every kernel family
@@ -429,7 +430,7 @@ struct Dev {
         int TS = 32 * T;
         int64_t nt = (Ms + TS - 1) / TS;
         int ntj = 0;
-        int64_t blocks = nt * (nt + 1) / 2;
+        int64_t blocks = (nt * (nt + 1) / 2 + 7) / 8 * 8;      // triangular: eight equal runs of the tile curve, one per XCD label (tri_tile_xcd)
         if (MsB >= 0) {                       // rectangular: all row tiles x the column tiles covering MsB columns
             ntj = (int)((MsB + TS - 1) / TS);
             blocks = nt * ntj;
@@ -450,6 +451,8 @@ struct Dev {
         else if (T == 4 && mode == 1 && !nz && K % 32 == 0 && variant == 2)
             hipLaunchKernelGGL((k_syrk<4, 8, 32, 2>), dim3((unsigned)blocks), dim3(512), 0, cur, A, ld, idx, row0, Ms, K, theta, diag, S,
                                ldS, srow0, mode, MsB, ntj, nz, nzpitch);
+        else if (T == 4 && mode == 1 && !nz && !idx && !theta && K % (2 * ASM_UPD_KC) == 0 && variant != 3)      // Cholesky updates: their own kernel
+            hipLaunchKernelGGL(k_syrk_upd, dim3((unsigned)blocks), dim3(256), 0, cur, A, ld, row0, Ms, K, S, ldS, srow0, MsB, ntj);
         else if (T == 4 && mode == 1 && !nz && K % 16 == 0)      // Cholesky updates: 16-wide k-chunks, two workgroups per CU
             hipLaunchKernelGGL((k_syrk<4, 8, 16, 4>), dim3((unsigned)blocks), dim3(512), 0, cur, A, ld, idx, row0, Ms, K, theta, diag, S,
                                ldS, srow0, mode, MsB, ntj, nz, nzpitch);
@@ -2050,7 +2053,7 @@ int asm_create(int device, asm_handle** out) {
     h->fused_panel = !(fp && fp[0] == '0');
     {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 16) h->panel_wgs = 2 * prop.multiProcessorCount - 32;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 16) { h->num_cus = prop.multiProcessorCount; h->panel_wgs = 2 * prop.multiProcessorCount - 32; }
         if (const char* pw = std::getenv("ASM_PANEL_WGS")) h->panel_wgs = std::max(1, std::atoi(pw));
     }
     const char* gr = std::getenv("ASM_HIP_GRAPHS");
@@ -2499,3 +2502,11 @@ int asm_test_assemble(asm_handle* h, const double* dE, double* J_out) {
 }
 
 }  // extern "C"
+
+#ifdef ASM_UPD_PROF
+extern "C" int asm_debug_upd_prof(unsigned long long* out8) {       // diagnostic build only: read and clear the k_syrk_upd phase sums
+    unsigned long long z[8] = {0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_upd_prof), sizeof(z)) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_upd_prof), z, sizeof(z)) != hipSuccess;
+}
+#endif

@@ -140,6 +140,42 @@ __global__ __launch_bounds__(256) void k_gemv_t_stage2(const double* __restrict_
     out[j] = acc;
 }
 
+// Lower-triangular tile pair (bi >= bj) of workgroup blockIdx.x, XCD-aware.  Workgroups g, g+8, g+16, ... share an XCD (and
+// its L2), so the NT = ntr (ntr + 1) / 2 tile pairs are laid along a curve that walks 8 x 8 super-tiles (row-major inside,
+// super-rows top to bottom) and the XCD with label g % 8 works through one contiguous eighth of it.  The workgroups an XCD
+// holds at a time then cover about one super-tile: 8 + 8 operand row blocks for 64 tile pairs instead of ~4 + 64 with a
+// row-major enumeration - the operand re-reads that go beyond L2 drop ~4x (measured: fetch per launch -32 %).  Pure
+// placement: any dispatch order is correct.  Grid = 8 * ceil(NT / 8) workgroups; false = no tile for this workgroup.
+__device__ __forceinline__ bool tri_tile_xcd(int ntr, int& bi, int& bj) {
+    const int64_t NT = (int64_t)ntr * (ntr + 1) / 2, per = (NT + 7) / 8;
+    const int64_t p = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((int64_t)(blockIdx.x >> 3) >= per || p >= NT) return false;
+    const int nst = (ntr + 7) / 8, rlast = ntr - 8 * (nst - 1);
+    int I = (int)((sqrt(16.0 + 128.0 * (double)p) - 4.0) * (1.0 / 64.0));          // 32 I^2 + 4 I tile pairs precede super-row I
+    if (I > nst - 1) I = nst - 1;
+    while (I < nst - 1 && 32ll * (I + 1) * (I + 1) + 4ll * (I + 1) <= p) ++I;
+    while (I > 0 && 32ll * I * I + 4ll * I > p) --I;
+    const int rem = (int)(p - (32ll * I * I + 4ll * I));
+    const int R = (I == nst - 1) ? rlast : 8;                                       // tile rows of this super-row
+    int J, ti, tj;
+    if (rem < I * R * 8) {
+        J = rem / (R * 8);
+        const int wv = rem - J * R * 8;
+        ti = wv >> 3;
+        tj = wv & 7;
+    } else {
+        J = I;
+        const int wv = rem - I * R * 8;
+        ti = (int)((sqrt(8.0 * (double)wv + 1.0) - 1.0) * 0.5);
+        while ((ti + 1) * (ti + 2) / 2 <= wv) ++ti;
+        while (ti * (ti + 1) / 2 > wv) --ti;
+        tj = wv - ti * (ti + 1) / 2;
+    }
+    bi = 8 * I + ti;
+    bj = 8 * J + tj;
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Symmetric rank-K kernel on the f64 matrix cores.
 //   mode 0:  S[a,b]  = sum_k A[row(a),k] theta[k] A[row(b),k]  (+ diag[a] if a==b)      a >= b
@@ -167,12 +203,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void k_syrk(const double* __restrict_
         bj = blockIdx.x - bi * ntj;
         if (bj > bi) return;
     } else {
-        // lower-triangular tile pair (bi >= bj) from the linear block id
-        int t = blockIdx.x;
-        bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-        while ((int64_t)(bi + 1) * (bi + 2) / 2 <= t) ++bi;
-        while ((int64_t)bi * (bi + 1) / 2 > t) --bi;
-        bj = t - (int)((int64_t)bi * (bi + 1) / 2);
+        if (!tri_tile_xcd((Ms + TS - 1) / TS, bi, bj)) return;
     }
 
     // NW wavefronts as a 2 x (NW/2) grid; each owns TI x TJ MFMA tiles (NW = 8: two wavefronts per SIMD, so one
@@ -297,6 +328,167 @@ __global__ __launch_bounds__(64 * NW, WPE) void k_syrk(const double* __restrict_
                     *dst = v;
                 }
             }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The Cholesky update  S[a,b] -= sum_k P[a,k] P[b,k]  (a >= b; trailing and in-panel updates: nearly all of a factorisation's
+// flops), written for the f64 matrix pipe rather than shared with the Schur build.  The loop never waits on anything it has not
+// had a chunk's time to get:
+//   * tile 128 x 128, FOUR wavefronts as 2 x 2, each owning 64 x 64 = 4 x 4 MFMA tiles (128 accumulator registers): 16 matrix
+//     instructions per k-step for 8 fragment loads per two k-steps; two workgroups per CU (256 registers per lane), so one
+//     workgroup's prologue / epilogue (the S tile) runs under the other's matrix instructions.
+//   * operands go global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write, no VALU work): one
+//     wave-instruction writes 1 KiB = 16 rows x 8 doubles, lane-linear, so the slot swizzle is applied on the SOURCE address.
+//   * LDS image of a chunk of 8 k: row = 8 doubles = 4 slots of 16 B, slot q of row r at q ^ (2 * bit3(r)).  The k index is permuted
+//     inside the chunk: lane (row i, quarter kq) of an MFMA operand owns the contiguous doubles k = 2 kq, 2 kq + 1 and uses
+//     element s in step s (same permutation on both operands), so the fragment for a chunk's two k-steps is ONE ds_read_b128 and
+//     the 16-lane groups the LDS serves per cycle hit 16 distinct slots (MI355X_MICROARCH.md, LDS table).
+//   * FOUR LDS stages: in iteration c the loads of chunk c+3 are issued between the matrix instructions (one per four MFMAs),
+//     the fragments of chunk c+1 are read while the matrix pipe works on chunk c, and the wait at the end of the iteration is
+//     for chunk c+2 only (vmcnt(4): chunk c+3 stays in flight across the barrier), reached with the next fragments in registers.
+//   * accumulators start at -S and the result is stored negated: S - P P' with no multiply in the loop, bitwise the same sum.
+// Rows past Ms are clamped for the loads (their products land in accumulator entries that are never stored).
+#define ASM_UPD_TS 128
+#define ASM_UPD_KC 8
+#ifdef ASM_UPD_PROF
+// diagnostic build only (-DASM_UPD_PROF): cycle sums of wavefront 0 of every workgroup, read by asm_debug_upd_prof
+__device__ unsigned long long g_upd_prof[8];
+#define UPD_STAMP(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define UPD_STAMP(v) do { } while (0)
+#endif
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+// one LDS-DMA load: 16 B per lane to LDS address lds_dst + 16 * lane (M0 = destination; cdna_hip_programming.md, LDS-DMA recipe).
+// Issued from an asm statement, so the compiler does not count it: it puts no vmcnt(0) between such a load and fragment reads of
+// the other stages, and the kernel waits for them itself.  No compiler-counted global load may be outstanding when one is issued.
+__device__ __forceinline__ void glds16(const double* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_syrk_upd(const double* __restrict__ A, int64_t ld, int64_t row0, int Ms, int K, double* __restrict__ S, int64_t ldS, int64_t srow0,
+                int MsB, int ntj) {
+    constexpr int TS = ASM_UPD_TS, KC = ASM_UPD_KC;
+    constexpr int STG = 2 * TS * KC;                                           // doubles per stage: A image (8 KB), then B image (8 KB)
+    __shared__ __attribute__((aligned(1024))) double lds[4 * STG];            // 64 KB
+    int bi, bj;
+    if (ntj > 0) {
+        bi = blockIdx.x / ntj;
+        bj = blockIdx.x - bi * ntj;
+        if (bj > bi) return;
+    } else {
+        if (!tri_tile_xcd((Ms + TS - 1) / TS, bi, bj)) return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
+#ifdef ASM_UPD_PROF
+    unsigned long long tb0 = 0, tb1 = 0, tb2 = 0;
+    UPD_STAMP(tb0);
+#endif
+
+    // ---- LDS-DMA sources: 16 wave-instructions fill a stage (16 rows x 8 doubles each: 8 for the A image, 8 for the B image);
+    // wavefront w issues t = 4 j + w, j = 0..3.  lane -> (row t * 16 + lane / 4, physical slot lane % 4); bit3(row) = bit5(lane)
+    const int lslot = (lane & 3) ^ (2 * ((lane >> 5) & 1));             // the logical slot this lane fetches
+    const double* src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int t = 4 * j + w;
+        const int g = j < 2 ? bi * TS + t * 16 + (lane >> 2) : bj * TS + (t - 8) * 16 + (lane >> 2);
+        src[j] = A + (row0 + min(g, Ms - 1)) * ld + 2 * lslot;
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)&lds[w * 128]);
+    auto dma = [&](int j, int c) { glds16(src[j] + c * KC, lds0 + (unsigned)((c & 3) * STG * 8 + j * 4 * 1024)); };      // instruction t lands at t KiB
+    const int nchunks = K / KC;                                         // even (K is a multiple of 64)
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc)
+        if (cc < nchunks) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dma(j, cc);
+        }
+
+    // ---- accumulators = -S tile (read while the first chunks are in flight).  Unconditional loads from clamped (always valid)
+    // addresses, selected afterwards: a load under a branch would be waited for before the next one is issued.
+    v4f64 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = bi * TS + wr * 64 + i * 16 + (lane >> 4) + 4 * r;
+                const int col = bj * TS + wc * 64 + j * 16 + (lane & 15);
+                const int rr = min(row, Ms - 1), cc = min(col, rr);
+                const double v = S[(srow0 + rr) * ldS + (srow0 + cc)];
+                acc[i][j][r] = (row < Ms && col < MsB && col <= row) ? -v : 0.0;
+            }
+
+    // ---- fragment addresses: lane (row i = lane & 15, quarter kq = lane >> 4) reads slot kq ^ (2 * bit3(i))
+    const int fslot = (lane >> 4) ^ (2 * ((lane >> 3) & 1));
+    const int foA = (wr * 64 + (lane & 15)) * KC + 2 * fslot, foB = TS * KC + (wc * 64 + (lane & 15)) * KC + 2 * fslot;
+    double2 fa0[4], fb0[4], fa1[4], fb1[4];
+    auto frags = [&](double2* fa, double2* fb, int c) {
+        const double* stage = lds + (c & 3) * STG;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const double2*>(stage + foA + i * 16 * KC);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const double2*>(stage + foB + j * 16 * KC);
+    };
+    // one iteration: matrix instructions of chunk c on (xa, xb); fragments of chunk c+1 into (ya, yb); loads of chunk c+3
+    auto body = [&](int c, const double2* xa, const double2* xb, double2* ya, double2* yb) {
+        const bool pf = c + 3 < nchunks;
+        frags(ya, yb, c + 1);           // unconditional (after the last chunk: unused values from a quiescent stage): a branch here costs the counted waits
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[i].x, xb[j].x, acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (pf) dma(i, c + 3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[i].y, xb[j].y, acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // chunk c+2 has landed (this wave's part; the barrier covers the rest); chunk c+3's four loads may stay in flight
+        if (pf) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    UPD_STAMP(tb1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    frags(fa0, fb0, 0);
+#ifdef ASM_UPD_PROF
+    unsigned long long tk0 = 0, tk1 = 0;
+    UPD_STAMP(tk0);
+#endif
+    for (int c = 0; c < nchunks; c += 2) {
+        body(c, fa0, fb0, fa1, fb1);
+        body(c + 1, fa1, fb1, fa0, fb0);
+    }
+#ifdef ASM_UPD_PROF
+    UPD_STAMP(tk1);
+#endif
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = bi * TS + wr * 64 + i * 16 + (lane >> 4) + 4 * r;
+                const int col = bj * TS + wc * 64 + j * 16 + (lane & 15);
+                if (row < Ms && col < MsB && col <= row) S[(srow0 + row) * ldS + (srow0 + col)] = -acc[i][j][r];
+            }
+#ifdef ASM_UPD_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    UPD_STAMP(tb2);
+    if (tid == 0) {
+        atomicAdd(&g_upd_prof[0], tk0 - tb0); atomicAdd(&g_upd_prof[1], tb2 - tk1); atomicAdd(&g_upd_prof[2], tb1 - tb0);
+        atomicAdd(&g_upd_prof[5], tk1 - tk0); atomicAdd(&g_upd_prof[6], (unsigned long long)nchunks); atomicAdd(&g_upd_prof[7], 1ull);
+    }
+#endif
 }
 
 // diag0[i] = S_ii ; then S_ii += reg.   mode 0: reg_i = rel*S_ii + absv ;  mode 1: reg = rel*max(max_i S_ii, 1e-300)
