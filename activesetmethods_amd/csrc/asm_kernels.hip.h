@@ -225,7 +225,9 @@ __global__ __launch_bounds__(64 * NW, WPE) void k_syrk(const double* __restrict_
                 for (int r = 0; r < 4; ++r) {
                     int row = bi * TS + wr * 16 * TI + i * 16 + (lane >> 4) + 4 * r;
                     int col = bj * TS + wc * 16 * TJ + j * 16 + (lane & 15);
-                    if (row < Ms && col < MsB && col <= row) acc[i][j][r] = S[(srow0 + row) * ldS + (srow0 + col)];
+                    const int rc = min(row, Ms - 1), cc = min(col, rc);                // unconditional load from a clamped address
+                    const double v = S[(srow0 + rc) * ldS + (srow0 + cc)];
+                    acc[i][j][r] = ((row < Ms) & (col < MsB) & (col <= row)) ? v : 0.0;
                 }
             }
         }
@@ -381,6 +383,9 @@ void k_syrk_upd(const double* __restrict__ A, int64_t ld, int64_t row0, int Ms, 
         if (!tri_tile_xcd((Ms + TS - 1) / TS, bi, bj)) return;
     }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
+    // Claim the full 256-register half of the SIMD's file (the kernel needs 244 -> 248 allocated): with 2 x 256 the slot a retiring
+    // wavefront frees is one contiguous block of 256, which fits a wavefront of the look-ahead panel kernel (<= 256) as well.
+    asm volatile("" ::: "v255");
 #ifdef ASM_UPD_PROF
     unsigned long long tb0 = 0, tb1 = 0, tb2 = 0;
     UPD_STAMP(tb0);
@@ -419,7 +424,7 @@ void k_syrk_upd(const double* __restrict__ A, int64_t ld, int64_t row0, int Ms, 
                 const int col = bj * TS + wc * 64 + j * 16 + (lane & 15);
                 const int rr = min(row, Ms - 1), cc = min(col, rr);
                 const double v = S[(srow0 + rr) * ldS + (srow0 + cc)];
-                acc[i][j][r] = (row < Ms && col < MsB && col <= row) ? -v : 0.0;
+                acc[i][j][r] = ((row < Ms) & (col < MsB) & (col <= row)) ? -v : 0.0;
             }
 
     // ---- fragment addresses: lane (row i = lane & 15, quarter kq = lane >> 4) reads slot kq ^ (2 * bit3(i))
@@ -547,10 +552,24 @@ __device__ __forceinline__ void potrf64_body(double* __restrict__ D, double* __r
 #define PSTAMP() do {} while (0)
 #endif
     PSTAMP();
-    for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
-        int rr = e >> 6, c = e & 63;
-        D[rr * ASM_DP + c] = (rr < nb && c <= rr) ? S[(int64_t)(k0 + rr) * ldS + k0 + c] : (rr == c ? 1.0 : 0.0);
-        W[rr * ASM_DP + c] = 0.0;
+    {
+        // Tile loads here and below: (1) unconditional loads from clamped (always valid) addresses, selected afterwards with '&' rather
+        // than '&&' - a load under a branch (or one the compiler can sink into one) is waited for before the next is issued;
+        // (2) all sixteen loads of a thread first, the LDS stores after a scheduling fence - one round trip instead of sixteen.
+        double tv[ASM_NB * ASM_NB / 256];
+#pragma unroll
+        for (int it = 0; it < ASM_NB * ASM_NB / 256; ++it) {
+            const int e = tid + 256 * it, rr = e >> 6, c = e & 63;
+            const int rc = min(rr, nb - 1), cc = min(c, rc);
+            tv[it] = S[(int64_t)(k0 + rc) * ldS + k0 + cc];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < ASM_NB * ASM_NB / 256; ++it) {
+            const int e = tid + 256 * it, rr = e >> 6, c = e & 63;
+            D[rr * ASM_DP + c] = ((rr < nb) & (c <= rr)) ? tv[it] : (rr == c ? 1.0 : 0.0);
+            W[rr * ASM_DP + c] = 0.0;
+        }
     }
     if (tid < ASM_NB) d0[tid] = tid < nb ? diag0[k0 + tid] : 1.0;
     __syncthreads();
@@ -631,9 +650,11 @@ __device__ __forceinline__ void potrf64_body(double* __restrict__ D, double* __r
         }
         __syncthreads();
     }
-    for (int e = tid; e < nb * ASM_NB; e += 256) {
+#pragma unroll
+    for (int e_it = 0; e_it < ASM_NB * ASM_NB / 256; ++e_it) {
+        const int e = tid + 256 * e_it;
         int rr = e >> 6, c = e & 63;
-        if (c <= rr && c < nb) S[(int64_t)(k0 + rr) * ldS + k0 + c] = D[rr * ASM_DP + c];
+        if (rr < nb && c <= rr) S[(int64_t)(k0 + rr) * ldS + k0 + c] = D[rr * ASM_DP + c];
     }
     PSTAMP();
     // ---- inverse W = L^-1 by 16x16 blocks (diagonal blocks 0..2 were inverted beside the factorisation of their successors)
@@ -675,7 +696,8 @@ __device__ __forceinline__ void potrf64_body(double* __restrict__ D, double* __r
 #ifdef ASM_POTRF_PROF
     if (tid == 0 && k0 == 64) { stamp_[ns_++] = clock64(); printf("potrf stamps:"); for (int q = 1; q < ns_; ++q) printf(" %lld", stamp_[q] - stamp_[q - 1]); printf("\n"); }
 #endif
-    for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
+    _Pragma("unroll") for (int e_it = 0; e_it < ASM_NB * ASM_NB / 256; ++e_it) {      /* constant trip count, fully unrolled: all of a thread's loads in flight */
+        const int e = tid + 256 * e_it;
         const double v = W[(e >> 6) * ASM_DP + (e & 63)];
         if (SC1) __hip_atomic_store(out + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // write-through: read by other workgroups of this launch
         else out[e] = v;
@@ -703,11 +725,13 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ S, int6
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i0 = k0 + nb + blockIdx.x * ASM_NB;
     const double* Lb = Linv + (int64_t)(k0 / ASM_NB) * ASM_NB * ASM_NB;
-    for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
+    _Pragma("unroll") for (int e_it = 0; e_it < ASM_NB * ASM_NB / 256; ++e_it) {      /* constant trip count, fully unrolled: all of a thread's loads in flight */
+        const int e = tid + 256 * e_it;
         int rr = e >> 6, c = e & 63;
         Li[rr * ASM_XP + c] = Lb[e];
         int gi = i0 + rr;
-        Xa[rr * ASM_XP + c] = (gi < Ms && c < nb) ? S[(int64_t)gi * ldS + k0 + c] : 0.0;
+        const double v = S[(int64_t)min(gi, Ms - 1) * ldS + k0 + min(c, nb - 1)];
+        Xa[rr * ASM_XP + c] = ((gi < Ms) & (c < nb)) ? v : 0.0;
     }
     __syncthreads();
     v4f64 acc[4];
@@ -743,10 +767,12 @@ __global__ __launch_bounds__(256) void k_panel_update64(double* __restrict__ S, 
     if (tj > ti) return;                                   // strictly upper tile
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r0 = k1 + ti * ASM_NB, c0 = k1 + tj * ASM_NB;
-    for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
+    _Pragma("unroll") for (int e_it = 0; e_it < ASM_NB * ASM_NB / 256; ++e_it) {      /* constant trip count, fully unrolled: all of a thread's loads in flight */
+        const int e = tid + 256 * e_it;
         int rr = e >> 6, c = e & 63;
-        Pa[rr * ASM_XP + c] = (r0 + rr < Ms) ? -S[(int64_t)(r0 + rr) * ldS + k0 + c] : 0.0;
-        Pb[rr * ASM_XP + c] = (c0 + rr < Ms) ? S[(int64_t)(c0 + rr) * ldS + k0 + c] : 0.0;
+        const double va = S[(int64_t)min(r0 + rr, Ms - 1) * ldS + k0 + c], vb = S[(int64_t)min(c0 + rr, Ms - 1) * ldS + k0 + c];
+        Pa[rr * ASM_XP + c] = (r0 + rr < Ms) ? -va : 0.0;
+        Pb[rr * ASM_XP + c] = (c0 + rr < Ms) ? vb : 0.0;
     }
     v4f64 acc[4];
 #pragma unroll
@@ -754,7 +780,9 @@ __global__ __launch_bounds__(256) void k_panel_update64(double* __restrict__ S, 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             int row = r0 + w * 16 + (lane >> 4) + 4 * r, col = c0 + t * 16 + (lane & 15);
-            acc[t][r] = (row < Ms && col < c_end && col <= row) ? S[(int64_t)row * ldS + col] : 0.0;
+            const int rc = min(row, Ms - 1);
+            const double v = S[(int64_t)rc * ldS + min(col, min(c_end - 1, rc))];
+            acc[t][r] = ((row < Ms) & (col < c_end) & (col <= row)) ? v : 0.0;
         }
     __syncthreads();
 #pragma unroll 4
@@ -814,7 +842,12 @@ __device__ __forceinline__ void pnl_wait(unsigned* flag, unsigned epoch, unsigne
     __syncthreads();
 }
 #define ASM_PNL_LDS (2 * ASM_NB * ASM_XP + 4 * 16 * 17 + 2 * ASM_NB)
-__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms,
+// Register budget: two wavefronts per SIMD = 256 registers per lane, AGPRs included.  The panel kernel runs beside k_syrk_upd
+// (256 per wavefront, two per SIMD): a panel wavefront must fit into the slot ONE retiring update wavefront frees.  Left to
+// itself the compiler takes 256 VGPRs + 56 AGPRs (occupancy 1 is allowed for a 256-thread kernel), such a wavefront fits
+// nowhere while updates are queued and the look-ahead chain starts only after the whole trailing update (measured at
+// M = 18637: first panel launch 5.2 ms instead of 1.0 ms).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chol_panel(double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms,
                                                     const double* __restrict__ diag0, double thr, double* __restrict__ Linv,
                                                     unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch) {
     __shared__ __attribute__((aligned(16))) double sm[ASM_PNL_LDS];
@@ -827,6 +860,12 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int6
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nsteps = (I1 - I0 + ASM_NB - 1) / ASM_NB;
     const int nrt = (Ms - I0 + ASM_NB - 1) / ASM_NB;
+#ifdef ASM_PANEL_PROF
+    long long qs_[12]; int qn_ = 0;
+#define QSTAMP(cond) do { if (tid == 0 && (cond)) qs_[qn_++] = clock64(); } while (0)
+#else
+#define QSTAMP(cond) do {} while (0)
+#endif
     if (wg == 0) {
         potrf64_body<true>(B0, B1, Tt, d0, dinv, S, ldS, I0, min(ASM_NB, Ms - I0), diag0, thr, Linv);
         pnl_publish(flags + 0, epoch);
@@ -840,18 +879,31 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int6
         int rt = wg;
         while (rt <= k) rt += G;
         for (; rt < nrt; rt += G) {
+            QSTAMP(k == 1 && rt == 2);
             if (!waited) { pnl_wait(flags + k, epoch, tmo); waited = true; }
+            QSTAMP(k == 1 && rt == 2);
             const int i0 = I0 + rt * ASM_NB;
             const double* Lb = Linv + (int64_t)(k0 / ASM_NB) * ASM_NB * ASM_NB;
             // ---- panel solve of the tile: X = S[tile, k0:k1] Linv'
             __syncthreads();
-            for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
-                int rr = e >> 6, c = e & 63;
-                B1[rr * ASM_XP + c] = Lb[e];
-                int gi = i0 + rr;
-                B0[rr * ASM_XP + c] = (gi < Ms && c < nb) ? S[(int64_t)gi * ldS + k0 + c] : 0.0;
+            {
+                double lv[ASM_NB * ASM_NB / 256], tv[ASM_NB * ASM_NB / 256];
+#pragma unroll
+                for (int it = 0; it < ASM_NB * ASM_NB / 256; ++it) {
+                    const int e = tid + 256 * it, rr = e >> 6, c = e & 63;
+                    lv[it] = Lb[e];
+                    tv[it] = S[(int64_t)min(i0 + rr, Ms - 1) * ldS + k0 + min(c, nb - 1)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int it = 0; it < ASM_NB * ASM_NB / 256; ++it) {
+                    const int e = tid + 256 * it, rr = e >> 6, c = e & 63;
+                    B1[rr * ASM_XP + c] = lv[it];
+                    B0[rr * ASM_XP + c] = ((i0 + rr < Ms) & (c < nb)) ? tv[it] : 0.0;
+                }
             }
             __syncthreads();
+            QSTAMP(k == 1 && rt == 2);
             v4f64 acc[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
@@ -878,8 +930,10 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int6
                         else *dst = acc[t][r];
                     }
                 }
+            QSTAMP(k == 1 && rt == 2);
             if (rt < nsteps) pnl_publish(flags + 4 + 4 * k + rt, epoch);      // a later diagonal row tile: its X is an operand for others
             else __syncthreads();
+            QSTAMP(k == 1 && rt == 2);
             // ---- rank-64 update of the panel's remaining column tiles tj = k+1 .. min(rt, nsteps-1)
             const int tj_hi = min(rt, nsteps - 1);
             for (int tj = k + 1; tj <= tj_hi; ++tj) {
@@ -887,9 +941,19 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int6
                 const double* Pb = B0;
                 if (tj != rt) {
                     pnl_wait(flags + 4 + 4 * k + tj, epoch, tmo);
-                    for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
-                        int rr = e >> 6, c = e & 63;
-                        B1[rr * ASM_XP + c] = (c0 + rr < Ms && c < nb) ? S[(int64_t)(c0 + rr) * ldS + k0 + c] : 0.0;
+                    {
+                        double tv[ASM_NB * ASM_NB / 256];
+#pragma unroll
+                        for (int it = 0; it < ASM_NB * ASM_NB / 256; ++it) {
+                            const int e = tid + 256 * it, rr = e >> 6, c = e & 63;
+                            tv[it] = S[(int64_t)min(c0 + rr, Ms - 1) * ldS + k0 + min(c, nb - 1)];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int it = 0; it < ASM_NB * ASM_NB / 256; ++it) {
+                            const int e = tid + 256 * it, rr = e >> 6, c = e & 63;
+                            B1[rr * ASM_XP + c] = ((c0 + rr < Ms) & (c < nb)) ? tv[it] : 0.0;
+                        }
                     }
                     __syncthreads();
                     Pb = B1;
@@ -899,7 +963,9 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int6
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         int row = i0 + w * 16 + (lane >> 4) + 4 * r, col = c0 + t * 16 + (lane & 15);
-                        acc[t][r] = (row < Ms && col < c_end && col <= row) ? S[(int64_t)row * ldS + col] : 0.0;
+                        const int rc = min(row, Ms - 1);
+                        const double v = S[(int64_t)rc * ldS + min(col, min(c_end - 1, rc))];
+                        acc[t][r] = ((row < Ms) & (col < c_end) & (col <= row)) ? v : 0.0;
                     }
 #pragma unroll 4
                 for (int kk = 0; kk < ASM_NB; kk += 4) {
@@ -921,11 +987,18 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int6
             }
             // ---- look-ahead: this tile is the next diagonal block and has all its updates now
             if (rt == k + 1 && rt < nsteps) {
+                QSTAMP(k == 1 && rt == 2);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
+                QSTAMP(k == 1 && rt == 2);
                 const int kn = I0 + rt * ASM_NB;
                 potrf64_body<true>(B0, B1, Tt, d0, dinv, S, ldS, kn, min(ASM_NB, Ms - kn), diag0, thr, Linv);
+                QSTAMP(k == 1 && rt == 2);
                 pnl_publish(flags + rt, epoch);
+                QSTAMP(k == 1 && rt == 2);
+#ifdef ASM_PANEL_PROF
+                if (tid == 0 && k == 1 && I0 == 256) { printf("panel stamps (wait, load, trsm+store, publish, update, drain, potrf, publish):"); for (int q = 1; q < qn_; ++q) printf(" %lld", qs_[q] - qs_[q - 1]); printf("\n"); }
+#endif
             }
         }
     }
@@ -1043,7 +1116,8 @@ __global__ __launch_bounds__(256) void k_trtri_init(const double* __restrict__ L
     const int nsub = min((WB / ASM_NB), (Ms - b0 + ASM_NB - 1) / ASM_NB);
     double* X = Binv + (int64_t)B * WB * WB;
     const double* src = (i == j && i < nsub) ? Linv + (int64_t)((b0 / ASM_NB) + i) * ASM_NB * ASM_NB : nullptr;
-    for (int e = threadIdx.x; e < ASM_NB * ASM_NB; e += 256) {
+    _Pragma("unroll") for (int e_it = 0; e_it < ASM_NB * ASM_NB / 256; ++e_it) {
+        const int e = threadIdx.x + 256 * e_it;
         int rr = e >> 6, c = e & 63;
         double v = src ? src[e] : ((i == j && rr == c) ? 1.0 : 0.0);      // missing sub-blocks: identity
         X[(int64_t)(i * ASM_NB + rr) * WB + j * ASM_NB + c] = v;
@@ -1065,12 +1139,14 @@ __global__ __launch_bounds__(256) void k_trtri_level(const double* __restrict__ 
     for (int t = 0; t < 4; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
     const int k_lo = stage == 0 ? tj : 0, k_hi = stage == 0 ? h - 1 : ti;
     for (int k = k_lo; k <= k_hi; ++k) {
-        for (int e = tid; e < ASM_NB * ASM_NB; e += 256) {
+        _Pragma("unroll") for (int e_it = 0; e_it < ASM_NB * ASM_NB / 256; ++e_it) {      /* constant trip count, fully unrolled: all of a thread's loads in flight */
+        const int e = tid + 256 * e_it;
             int rr = e >> 6, c = e & 63;
             double pv, qv;
             if (stage == 0) {          // P = L21[ti][k] (rows of the factor), Q = X11[k][tj]
                 int gi = b0 + r0 + ti * ASM_NB + rr;
-                pv = gi < Ms ? L[(int64_t)gi * ld + b0 + c0 + k * ASM_NB + c] : 0.0;
+                pv = L[(int64_t)min(gi, Ms - 1) * ld + b0 + c0 + k * ASM_NB + c];      // clamped row: an unconditional load
+                pv = gi < Ms ? pv : 0.0;
                 qv = X[(int64_t)(c0 + k * ASM_NB + rr) * WB + c0 + tj * ASM_NB + c];
             } else {                   // P = X22[ti][k], Q = T[k][tj]
                 pv = X[(int64_t)(r0 + ti * ASM_NB + rr) * WB + r0 + k * ASM_NB + c];
@@ -1115,7 +1191,10 @@ __global__ __launch_bounds__(256) void k_wtrsv_fwd_diag(const double* __restrict
 #pragma unroll
     for (int u = 0; u < WB / 64; ++u) {
         int c = u * 64 + lane;
-        v[u] = (c <= row) ? X[(int64_t)row * WB + c] * w[b0 + c] : 0.0;
+        // unconditional loads (the block and the clamped vector entry are always valid), selected afterwards: loads under a branch
+        // are waited for one pair at a time - sixteen serialised round trips instead of "all loads of a row in flight"
+        const double xv = X[(int64_t)row * WB + c], wv_ = w[min(b0 + c, Ms - 1)];
+        v[u] = (c <= row) ? xv * wv_ : 0.0;
     }
     double acc = 0.0;
 #pragma unroll
@@ -1236,7 +1315,8 @@ __global__ __launch_bounds__(256) void k_wtrsv_bwd_diag(const double* __restrict
 #pragma unroll
     for (int u = 0; u < WB / 64; ++u) {
         int c = u * 64 + lane;
-        v[u] = (c >= row) ? XT[(int64_t)row * WB + c] * t[c] : 0.0;
+        const double xv = XT[(int64_t)row * WB + c], tv = t[c];          // unconditional, as in k_wtrsv_fwd_diag (t has WB entries)
+        v[u] = (c >= row) ? xv * tv : 0.0;
     }
     double acc = 0.0;
 #pragma unroll
@@ -1251,12 +1331,14 @@ __global__ __launch_bounds__(256) void k_transpose_wb(const double* __restrict__
     const int B = blockIdx.x, ti = blockIdx.y / (WB / ASM_NB), tj = blockIdx.y % (WB / ASM_NB);
     const double* X = Binv + (int64_t)B * WB * WB;
     double* XT = BinvT + (int64_t)B * WB * WB;
-    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    _Pragma("unroll") for (int e_it = 0; e_it < 16; ++e_it) {
+        const int e = threadIdx.x + 256 * e_it;
         int r = e >> 6, c = e & 63;
         tile[r * 65 + c] = X[(int64_t)(ti * 64 + r) * WB + tj * 64 + c];
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    _Pragma("unroll") for (int e_it = 0; e_it < 16; ++e_it) {
+        const int e = threadIdx.x + 256 * e_it;
         int r = e >> 6, c = e & 63;
         XT[(int64_t)(tj * 64 + r) * WB + ti * 64 + c] = tile[c * 65 + r];
     }
@@ -1296,12 +1378,14 @@ __global__ __launch_bounds__(256) void k_transpose_dense(const double* __restric
                                                          double* __restrict__ out, int64_t ld_out) {
     __shared__ double tile[64 * 65];
     const int64_t i0 = (int64_t)blockIdx.y * 64, j0 = (int64_t)blockIdx.x * 64;
-    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    _Pragma("unroll") for (int e_it = 0; e_it < 16; ++e_it) {
+        const int e = threadIdx.x + 256 * e_it;
         int r = e >> 6, c = e & 63;
         tile[r * 65 + c] = (i0 + r < rows && j0 + c < cols) ? A[(i0 + r) * ld_in + j0 + c] : 0.0;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    _Pragma("unroll") for (int e_it = 0; e_it < 16; ++e_it) {
+        const int e = threadIdx.x + 256 * e_it;
         int r = e >> 6, c = e & 63;          // out row j0 + r, out col i0 + c
         if (j0 + r < cols && i0 + c < rows) out[(j0 + r) * ld_out + i0 + c] = tile[c * 65 + r];
     }

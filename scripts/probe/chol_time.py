@@ -2,6 +2,7 @@
 import os, sys, ctypes as C; sys.path.insert(0, "."); os.environ.setdefault("ASM_HIP_TIMING", "2")
 import numpy as np
 from activesetmethods_amd import _lib
+if os.environ.get("ASM_LIB"): _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ["ASM_LIB"])      # A/B against another build in one call
 lib = _lib.load()
 for N in map(int, sys.argv[1:]):
     h = C.c_void_p(); assert lib.asm_create(0, C.byref(h)) == 0
