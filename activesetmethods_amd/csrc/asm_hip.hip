@@ -540,7 +540,7 @@ struct Dev {
     }
     // block chain of one outer panel [K0, K1): 64-wide potrf / panel solve steps whose rank-64 updates stay inside a
     // 256-wide inner panel; the rest of the outer panel is updated once per inner panel with K = 256
-    void chol_chain(int Ms, double thr, int K0, int K1) {
+    void chol_chain(int Ms, double thr, int K0, int K1, bool beside_updates = false) {
         for (int I0 = K0; I0 < K1; I0 += CHOL_NBI) {
             const int I1 = std::min(I0 + CHOL_NBI, K1);
             if (h->fused_panel) {
@@ -552,8 +552,13 @@ struct Dev {
                 const int G = std::max(1, std::min(nrt, h->panel_wgs));
                 h->panel_epoch += 1;              // flags are "set" when they hold this launch's epoch: no reset between launches
                 if (h->panel_epoch == 0) h->panel_epoch = 1;
-                hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)G), dim3(256), 0, cur, h->d_S, h->Mp, I0, std::min(I1, Ms), Ms, (const double*)h->d_diag0, thr,
-                                   h->d_Linv, h->d_pflags, h->d_ptmo, h->panel_epoch);
+                // beside the trailing update the register-capped build must be used (its wavefronts have to fit into freed update slots)
+                if (beside_updates)
+                    hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)G), dim3(256), 0, cur, h->d_S, h->Mp, I0, std::min(I1, Ms), Ms, (const double*)h->d_diag0, thr,
+                                       h->d_Linv, h->d_pflags, h->d_ptmo, h->panel_epoch);
+                else
+                    hipLaunchKernelGGL(k_chol_panel_solo, dim3((unsigned)G), dim3(256), 0, cur, h->d_S, h->Mp, I0, std::min(I1, Ms), Ms, (const double*)h->d_diag0, thr,
+                                       h->d_Linv, h->d_pflags, h->d_ptmo, h->panel_epoch);
             } else
             for (int k0 = I0; k0 < I1; k0 += ASM_NB) {
                 int nb = std::min(ASM_NB, Ms - k0);
@@ -600,7 +605,7 @@ struct Dev {
                 HIPCHK(hipEventRecord(e_a, h->stream));
                 HIPCHK(hipStreamWaitEvent(h->stream2, e_a, 0));
                 cur = h->stream2;
-                chol_chain(Ms, thr, K1, std::min(K1 + NBO, Ms));           // next panel's chain beside (b)
+                chol_chain(Ms, thr, K1, std::min(K1 + NBO, Ms), true);     // next panel's chain beside (b)
                 HIPCHK(hipEventRecord(e_c, h->stream2));
                 cur = h->stream;
             }

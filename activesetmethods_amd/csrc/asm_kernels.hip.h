@@ -847,10 +847,9 @@ __device__ __forceinline__ void pnl_wait(unsigned* flag, unsigned epoch, unsigne
 // itself the compiler takes 256 VGPRs + 56 AGPRs (occupancy 1 is allowed for a 256-thread kernel), such a wavefront fits
 // nowhere while updates are queued and the look-ahead chain starts only after the whole trailing update (measured at
 // M = 18637: first panel launch 5.2 ms instead of 1.0 ms).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chol_panel(double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms,
-                                                    const double* __restrict__ diag0, double thr, double* __restrict__ Linv,
-                                                    unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch) {
-    __shared__ __attribute__((aligned(16))) double sm[ASM_PNL_LDS];
+__device__ __forceinline__ void chol_panel_body(double* __restrict__ sm, double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms,
+                                                const double* __restrict__ diag0, double thr, double* __restrict__ Linv,
+                                                unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch) {
     double* B0 = sm;                                  // the tile being solved, then X
     double* B1 = sm + ASM_NB * ASM_XP;                // block inverse, then the right operand X(tj)
     potrf_T_t* Tt = reinterpret_cast<potrf_T_t*>(sm + 2 * ASM_NB * ASM_XP);
@@ -1002,6 +1001,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
     }
+}
+
+// k_chol_panel: the version that runs BESIDE the trailing update (look-ahead stream), capped at 256 registers;
+// k_chol_panel_solo: the same body without the cap (312 registers, no spills) for chains that have the chip to themselves.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chol_panel(double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms,
+                                                    const double* __restrict__ diag0, double thr, double* __restrict__ Linv,
+                                                    unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch) {
+    __shared__ __attribute__((aligned(16))) double sm[ASM_PNL_LDS];
+    chol_panel_body(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch);
+}
+__global__ __launch_bounds__(256) void k_chol_panel_solo(double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms,
+                                                         const double* __restrict__ diag0, double thr, double* __restrict__ Linv,
+                                                         unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch) {
+    __shared__ __attribute__((aligned(16))) double sm[ASM_PNL_LDS];
+    chol_panel_body(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch);
 }
 
 // out[i] = || A[i, :] ||_2   (one wavefront per row) - KT_residuals / compute_nu! (common.jl:41, slp.jl:58)
