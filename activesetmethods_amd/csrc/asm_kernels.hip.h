@@ -1152,24 +1152,36 @@ __global__ __launch_bounds__(256) void k_trtri_level(const double* __restrict__ 
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
     const int k_lo = stage == 0 ? tj : 0, k_hi = stage == 0 ? h - 1 : ti;
-    for (int k = k_lo; k <= k_hi; ++k) {
-        _Pragma("unroll") for (int e_it = 0; e_it < ASM_NB * ASM_NB / 256; ++e_it) {      /* constant trip count, fully unrolled: all of a thread's loads in flight */
-        const int e = tid + 256 * e_it;
-            int rr = e >> 6, c = e & 63;
-            double pv, qv;
+    // rows of this output tile past the end of the matrix: the block inverse is the identity there, the off-diagonal tile is zero
+    const bool dead = b0 + r0 + ti * ASM_NB >= Ms;
+    // operand tiles of step k: sixteen loads per operand and thread, all in flight (unconditional, clamped rows), kept in registers
+    // until the LDS image of the previous step has been consumed - the loads of step k+1 run under the matrix instructions of step k
+    double pv[ASM_NB * ASM_NB / 256], qv[ASM_NB * ASM_NB / 256];
+    auto load = [&](int k) {
+#pragma unroll
+        for (int it = 0; it < ASM_NB * ASM_NB / 256; ++it) {
+            const int e = tid + 256 * it, rr = e >> 6, c = e & 63;
             if (stage == 0) {          // P = L21[ti][k] (rows of the factor), Q = X11[k][tj]
-                int gi = b0 + r0 + ti * ASM_NB + rr;
-                pv = L[(int64_t)min(gi, Ms - 1) * ld + b0 + c0 + k * ASM_NB + c];      // clamped row: an unconditional load
-                pv = gi < Ms ? pv : 0.0;
-                qv = X[(int64_t)(c0 + k * ASM_NB + rr) * WB + c0 + tj * ASM_NB + c];
+                const int gi = b0 + r0 + ti * ASM_NB + rr;
+                const double v = L[(int64_t)min(gi, Ms - 1) * ld + b0 + c0 + k * ASM_NB + c];
+                pv[it] = gi < Ms ? v : 0.0;
+                qv[it] = X[(int64_t)(c0 + k * ASM_NB + rr) * WB + c0 + tj * ASM_NB + c];
             } else {                   // P = X22[ti][k], Q = T[k][tj]
-                pv = X[(int64_t)(r0 + ti * ASM_NB + rr) * WB + r0 + k * ASM_NB + c];
-                qv = T[(int64_t)(r0 + k * ASM_NB + rr) * WB + c0 + tj * ASM_NB + c];
+                pv[it] = X[(int64_t)(r0 + ti * ASM_NB + rr) * WB + r0 + k * ASM_NB + c];
+                qv[it] = T[(int64_t)(r0 + k * ASM_NB + rr) * WB + c0 + tj * ASM_NB + c];
             }
-            Pa[rr * ASM_TP + c] = pv;
-            Qt[c * ASM_TP + rr] = qv;
+        }
+    };
+    if (!dead) load(k_lo);
+    for (int k = k_lo; k <= k_hi && !dead; ++k) {
+#pragma unroll
+        for (int it = 0; it < ASM_NB * ASM_NB / 256; ++it) {
+            const int e = tid + 256 * it, rr = e >> 6, c = e & 63;
+            Pa[rr * ASM_TP + c] = pv[it];
+            Qt[c * ASM_TP + rr] = qv[it];
         }
         __syncthreads();
+        if (k < k_hi) load(k + 1);
 #pragma unroll 4
         for (int kk = 0; kk < ASM_NB; kk += 4) {
             double af = Pa[(w * 16 + (lane & 15)) * ASM_TP + kk + (lane >> 4)];
