@@ -438,6 +438,7 @@ struct Dev {
             MsB = Ms;
         }
         if (blocks <= 0) return;
+        if (nz && ntj == 0) blocks = (nt * (nt + 1) / 2 + 511) / 512 * 512;      // sparse build: runs of 64 tile pairs dealt to the XCD labels (tri_tile_xcd)
         // per-launch timing of the MFMA kernel itself (algorithmic flops: Ms*MsB*K over the stored triangle/rectangle)
         double fl = (MsB == Ms && ntj == 0) ? (double)Ms * (Ms + 1) * K : 2.0 * ((double)Ms * MsB - 0.5 * (double)MsB * MsB) * K;
         if (nz) fl *= nzfrac >= 0.0 ? nzfrac : h->nz_fraction;

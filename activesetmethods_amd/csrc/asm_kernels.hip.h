@@ -145,11 +145,16 @@ __global__ __launch_bounds__(256) void k_gemv_t_stage2(const double* __restrict_
 // super-rows top to bottom) and the XCD with label g % 8 works through one contiguous eighth of it.  The workgroups an XCD
 // holds at a time then cover about one super-tile: 8 + 8 operand row blocks for 64 tile pairs instead of ~4 + 64 with a
 // row-major enumeration - the operand re-reads that go beyond L2 drop ~4x (measured: fetch per launch -32 %).  Pure
-// placement: any dispatch order is correct.  Grid = 8 * ceil(NT / 8) workgroups; false = no tile for this workgroup.
-__device__ __forceinline__ bool tri_tile_xcd(int ntr, int& bi, int& bj) {
+// placement: any dispatch order is correct.  Grid = 8 * ceil(NT / 8) workgroups (512 * ceil(NT / 512) when dealt); false = no tile
+// for this workgroup.
+// deal = false: XCD label x takes the contiguous eighth [x per, (x + 1) per) of the curve (equal work per tile: the Cholesky updates);
+// deal = true: runs of 64 curve positions are dealt round-robin to the XCD labels (the sparse Schur build, where the chunk lists make
+// the work per tile follow the sparsity pattern - contiguous eighths put all the dense tiles on a few XCDs: measured 1.9 -> 3.1 ms).
+__device__ __forceinline__ bool tri_tile_xcd(int ntr, int& bi, int& bj, bool deal = false) {
     const int64_t NT = (int64_t)ntr * (ntr + 1) / 2, per = (NT + 7) / 8;
-    const int64_t p = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if ((int64_t)(blockIdx.x >> 3) >= per || p >= NT) return false;
+    const int64_t l = blockIdx.x >> 3;
+    const int64_t p = deal ? ((l >> 6) * 8 + (blockIdx.x & 7)) * 64 + (l & 63) : (int64_t)(blockIdx.x & 7) * per + l;
+    if ((!deal && l >= per) || p >= NT) return false;
     const int nst = (ntr + 7) / 8, rlast = ntr - 8 * (nst - 1);
     int I = (int)((sqrt(16.0 + 128.0 * (double)p) - 4.0) * (1.0 / 64.0));          // 32 I^2 + 4 I tile pairs precede super-row I
     if (I > nst - 1) I = nst - 1;
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void k_syrk(const double* __restrict_
         bj = blockIdx.x - bi * ntj;
         if (bj > bi) return;
     } else {
-        if (!tri_tile_xcd((Ms + TS - 1) / TS, bi, bj)) return;
+        if (!tri_tile_xcd((Ms + TS - 1) / TS, bi, bj, nzflags != nullptr)) return;
     }
 
     // NW wavefronts as a 2 x (NW/2) grid; each owns TI x TJ MFMA tiles (NW = 8: two wavefronts per SIMD, so one
