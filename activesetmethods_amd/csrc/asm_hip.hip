@@ -445,16 +445,11 @@ struct Dev {
         // timed on the stream it is launched on (HIP events see only their own stream)
         int kid = h->use_graphs ? -1 : begin(ASM_K_SYRK_KERNEL, fl, 8.0 * ((double)(Ms + MsB) * K + (double)Ms * MsB), cur);
         struct EndGuard { Dev* d; int id; ~EndGuard() { d->end(id); } } guard_{this, kid};
-        static const int variant = [] { const char* v = std::getenv("ASM_SYRK_VARIANT"); return v ? std::atoi(v) : 0; }();
-        if (T == 4 && mode == 1 && !nz && K % 16 == 0 && variant == 1)      // experiment: 4 wavefronts, 64 x 64 per wavefront
-            hipLaunchKernelGGL((k_syrk<4, 4, 16, 2>), dim3((unsigned)blocks), dim3(256), 0, cur, A, ld, idx, row0, Ms, K, theta, diag, S,
-                               ldS, srow0, mode, MsB, ntj, nz, nzpitch);
-        else if (T == 4 && mode == 1 && !nz && K % 32 == 0 && variant == 2)
-            hipLaunchKernelGGL((k_syrk<4, 8, 32, 2>), dim3((unsigned)blocks), dim3(512), 0, cur, A, ld, idx, row0, Ms, K, theta, diag, S,
-                               ldS, srow0, mode, MsB, ntj, nz, nzpitch);
-        else if (T == 4 && mode == 1 && !nz && !idx && !theta && K % (2 * ASM_UPD_KC) == 0 && variant != 3)      // Cholesky updates: their own kernel
+        // ASM_SYRK_UPD=0: the Cholesky updates through the generic kernel (ablation: what the dedicated kernel is worth)
+        static const bool use_upd = [] { const char* v = std::getenv("ASM_SYRK_UPD"); return !(v && v[0] == '0'); }();
+        if (T == 4 && mode == 1 && !nz && !idx && !theta && K % (2 * ASM_UPD_KC) == 0 && use_upd)      // Cholesky updates: their own kernel
             hipLaunchKernelGGL(k_syrk_upd, dim3((unsigned)blocks), dim3(256), 0, cur, A, ld, row0, Ms, K, S, ldS, srow0, MsB, ntj);
-        else if (T == 4 && mode == 1 && !nz && K % 16 == 0)      // Cholesky updates: 16-wide k-chunks, two workgroups per CU
+        else if (T == 4 && mode == 1 && !nz && K % 16 == 0)      // 16-wide k-chunks, two workgroups per CU
             hipLaunchKernelGGL((k_syrk<4, 8, 16, 4>), dim3((unsigned)blocks), dim3(512), 0, cur, A, ld, idx, row0, Ms, K, theta, diag, S,
                                ldS, srow0, mode, MsB, ntj, nz, nzpitch);
         else if (T == 4)

@@ -415,7 +415,7 @@ def main():
     # roofline of the dominant kernel: k_syrk<T> (Schur builds + Cholesky trailing updates), every launch timed with HIP events
     d = ks["syrk_kernel"]
     ach = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-    roof = dict(bound="mfma", kernel="k_syrk<T> (f64 MFMA rank-K update: Schur builds + Cholesky trailing updates)", achieved=ach,
+    roof = dict(bound="mfma", kernel="k_syrk_upd + k_syrk<T> (f64 MFMA rank-K kernels: Cholesky updates + Schur builds; every launch, in situ beside the look-ahead chain)", achieved=ach,
                 peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP64_MFMA_PEAK_TFLOPS, traffic=None,
                 avg_launch_ms=d["ms"] / max(d["calls"], 1), launches=d["calls"],
                 share_of_step_time=d["ms"] / (1e3 * elapsed) if elapsed > 0 else None)

@@ -117,7 +117,7 @@ int asm_sublp_last_stats(const asm_handle* h, asm_solve_stats* out);
 
 /* Device time per kernel family, measured with HIP events on the handle's stream. */
 /* ASM_K_SYRK: the Schur build; ASM_K_CHOL / ASM_K_TRSV: whole factorisation / solve (many launches);
- * ASM_K_SYRK_KERNEL: every single launch of the k_syrk<T> MFMA kernel (Schur builds + Cholesky trailing updates). */
+ * ASM_K_SYRK_KERNEL: every single launch of the rank-K MFMA kernels k_syrk_upd (Cholesky updates) and k_syrk<T> (Schur builds). */
 enum { ASM_K_ASSEMBLE = 0, ASM_K_SCALE, ASM_K_GEMV, ASM_K_SYRK, ASM_K_CHOL, ASM_K_TRSV, ASM_K_SYRK_KERNEL, ASM_K_COUNT };
 typedef struct {
     double  ms[ASM_K_COUNT];      /* accumulated device milliseconds */
