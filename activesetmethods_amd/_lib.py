@@ -51,6 +51,7 @@ PROTOTYPES = {
     "asm_slp_norms": (C.c_int, [_P, _D, _D, _D, _D]),
     "asm_slp_merit": (C.c_int, [_P, C.c_int, C.c_double, _D, _D, _D, C.c_int, C.c_double, _D]),
     "asm_test_syrk": (C.c_int, [_P, _D, C.c_int64, C.c_int64, _I32, C.c_int64, _D, _D, _D, C.c_int]),
+    "asm_test_syrk_update": (C.c_int, [_P, _D, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _D, C.c_int]),
     "asm_test_cholesky": (C.c_int, [_P, _D, C.c_int64, _D]),
     "asm_test_chol_solve": (C.c_int, [_P, _D, C.c_int64, _D, _D]),
     "asm_test_gemv": (C.c_int, [_P, _D, C.c_int64, C.c_int64, _D, _D, _D, _D]),

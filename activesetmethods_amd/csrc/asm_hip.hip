@@ -2479,6 +2479,27 @@ int asm_test_syrk(asm_handle* h, const double* A, int64_t M, int64_t K, const in
     });
 }
 
+// S[a,b] -= sum_k P[a,k] P[b,k] for a >= b (and b < MsB when MsB >= 0): the Cholesky update as the factorisation launches it
+// (k_syrk_upd for tile 4, the generic kernel otherwise), with an offset origin inside a larger matrix (srow0) like a trailing update
+int asm_test_syrk_update(asm_handle* h, const double* Pm, int64_t Ms, int64_t K, int64_t MsB, int64_t srow0, double* S_inout, int tile) {
+    return guarded(h, [&] {
+        if (K % 64 != 0) throw HipError("asm_test_syrk_update: K must be a multiple of 64 (panel widths)");
+        const int64_t N = srow0 + Ms;
+        test_alloc(h, N, std::max<int64_t>(K, 16));
+        Dev d(h);
+        HIPCHK(hipMemset(h->d_Ah, 0, h->Mp * h->ldn * sizeof(double)));
+        for (int64_t i = 0; i < Ms; ++i)
+            HIPCHK(hipMemcpy(h->d_Ah + (srow0 + i) * h->ldn, Pm + i * K, K * sizeof(double), hipMemcpyHostToDevice));
+        for (int64_t i = 0; i < Ms; ++i)
+            HIPCHK(hipMemcpy(h->d_S + (srow0 + i) * h->Mp + srow0, S_inout + i * Ms, Ms * sizeof(double), hipMemcpyHostToDevice));
+        d.launch_syrk(tile > 0 ? tile : Dev::pick_tile(Ms), h->d_Ah, h->ldn, nullptr, srow0, (int)Ms, (int)K, nullptr, nullptr, h->d_S, h->Mp, srow0, 1, (int)MsB);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (int64_t i = 0; i < Ms; ++i)
+            HIPCHK(hipMemcpy(S_inout + i * Ms, h->d_S + (srow0 + i) * h->Mp + srow0, Ms * sizeof(double), hipMemcpyDeviceToHost));
+        d.resolve_timing();
+    });
+}
+
 static void test_load_S(asm_handle* h, const double* S, int64_t N) {
     test_alloc(h, N, 16);
     for (int64_t i = 0; i < N; ++i)

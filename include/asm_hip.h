@@ -175,6 +175,9 @@ int asm_slp_merit(asm_handle* h, int mode, double alpha, const double* p, const 
 /* ---- kernel-level test hooks (used by tests/ to check each kernel against NumPy) ---------------- */
 int asm_test_syrk(asm_handle* h, const double* A, int64_t M, int64_t K, const int32_t* idx, int64_t Ms,
                   const double* theta, const double* diag, double* S_out /* Ms*Ms, lower valid */, int tile);
+/* S[a,b] -= sum_k P[a,k] P[b,k], a >= b (b < MsB when MsB >= 0), the block at (srow0, srow0) of a larger matrix: the Cholesky update */
+int asm_test_syrk_update(asm_handle* h, const double* P /* Ms*K */, int64_t Ms, int64_t K, int64_t MsB, int64_t srow0,
+                         double* S_inout /* Ms*Ms */, int tile);
 int asm_test_cholesky(asm_handle* h, const double* S /* N*N sym */, int64_t N, double* L_out /* N*N lower */);
 int asm_test_chol_solve(asm_handle* h, const double* S, int64_t N, const double* b, double* x);
 int asm_test_gemv(asm_handle* h, const double* A, int64_t M, int64_t K, const double* x, const double* y,

@@ -36,6 +36,30 @@ def test_syrk_matches_numpy(hip_lib, handle, M, K, Ms, tile):
     assert err < 1e-13          # f64 MFMA accumulation, K <= 1000
 
 
+@pytest.mark.parametrize("Ms,K,MsB,srow0,tile", [
+    (3100, 1024, -1, 0, 4),        # triangular trailing update, rows not a multiple of the 128-tile: k_syrk_upd, XCD-aware tile order
+    (4001, 256, -1, 64, 4),        # odd size, offset origin
+    (3333, 256, 768, 128, 4),      # rectangular in-panel update: all rows x the first 768 columns
+    (3200, 64, 130, 0, 4),         # shortest k (two ring stages of the update kernel never fill), ragged column count
+    (1000, 256, -1, 0, 2), (1000, 256, 300, 64, 2), (300, 64, -1, 0, 1),      # the generic kernel on the small sizes
+])
+def test_cholesky_update_matches_numpy(hip_lib, handle, Ms, K, MsB, srow0, tile):
+    """S -= P P' on the lower triangle (columns < MsB), as the factorisation launches it."""
+    rng = np.random.default_rng(Ms + K)
+    P = rng.standard_normal((Ms, K))
+    S0 = rng.standard_normal((Ms, Ms))
+    S = S0.copy()
+    rc = hip_lib.asm_test_syrk_update(handle, _d(P), Ms, K, MsB, srow0, _d(S), tile)
+    assert rc == 0, hip_lib.asm_last_error(handle)
+    ref = S0 - P @ P.T
+    mask = np.tril(np.ones((Ms, Ms), bool))
+    if MsB >= 0:
+        mask[:, MsB:] = False
+    scale = np.abs(ref).max()
+    assert np.abs(S - ref)[mask].max() / scale < 1e-13
+    assert np.array_equal(S[~mask], S0[~mask])          # nothing outside the updated region is touched
+
+
 @pytest.mark.parametrize("N", [1, 17, 64, 65, 200, 513, 1000, 2500, 4700])
 def test_cholesky_and_solve(hip_lib, handle, N):
     rng = np.random.default_rng(N)
