@@ -541,9 +541,7 @@ struct Dev {
     }
     // block chain of one outer panel [K0, K1): 64-wide potrf / panel solve steps whose rank-64 updates stay inside a
     // 256-wide inner panel; the rest of the outer panel is updated once per inner panel with K = 256
-    // `before_first_update`: an event the chain's stream waits for before its first in-panel update (the part of the previous outer
-    // panel's update that covers this panel's columns beyond the first inner panel, see chol_launches)
-    void chol_chain(int Ms, double thr, int K0, int K1, bool beside_updates = false, hipEvent_t before_first_update = nullptr) {
+    void chol_chain(int Ms, double thr, int K0, int K1, bool beside_updates = false) {
         for (int I0 = K0; I0 < K1; I0 += CHOL_NBI) {
             const int I1 = std::min(I0 + CHOL_NBI, K1);
             if (h->fused_panel) {
@@ -552,7 +550,6 @@ struct Dev {
                 const int nrt = (Ms - I0 + ASM_NB - 1) / ASM_NB;
                 // grid: one workgroup per row tile while they all fit (77 KB of LDS: two per CU); measured: fewer workgroups with several
                 // tiles each lengthen every step (M = 11192: 16.7 ms with one tile per workgroup, 21.1 ms with three)
-                // (beside the trailing update as well: 2 / 4 / 8 tiles per workgroup there cost 45.4 -> 45.8 / 49.2 / 59.0 ms at M = 18637)
                 const int G = std::max(1, std::min(nrt, h->panel_wgs));
                 h->panel_epoch += 1;              // flags are "set" when they hold this launch's epoch: no reset between launches
                 if (h->panel_epoch == 0) h->panel_epoch = 1;
@@ -578,7 +575,6 @@ struct Dev {
             }
             if (I1 < K1 && I1 < Ms) {
                 int rem = Ms - I1;
-                if (before_first_update) { HIPCHK(hipStreamWaitEvent(cur, before_first_update, 0)); before_first_update = nullptr; }
                 launch_syrk(pick_tile(rem), h->d_S + I0, h->Mp, nullptr, I1, rem, I1 - I0, nullptr, nullptr, h->d_S, h->Mp, I1, 1, K1 - I1);
             }
         }
@@ -591,7 +587,7 @@ struct Dev {
         const int NBO = CHOL_NBO;
         const int nP = (Ms + NBO - 1) / NBO;
         const bool la = nP > 2 && !h->use_graphs;
-        while ((int)h->la_events.size() < 3 * nP + 3) {
+        while ((int)h->la_events.size() < 2 * nP + 2) {
             hipEvent_t e;
             HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             h->la_events.push_back(e);
@@ -604,33 +600,15 @@ struct Dev {
             const int rem = Ms - K1, wa = std::min(NBO, rem);            // next panel = first `wa` trailing columns
             hipEvent_t e_a = h->la_events[2 * p], e_c = h->la_events[2 * p + 1];
             cur = h->stream;
-            // (a) rows >= K1, columns of the next outer panel.  With look-ahead in two pieces: (a1) the columns of that panel's FIRST
-            // inner panel - all its first dataflow launch needs - and (a2) the rest, which runs beside that launch and is awaited before
-            // the chain's first in-panel update.  Once the trailing update no longer hides the chain (second half of a large
-            // factorisation) this takes 3/4 of (a) off the critical path of every outer panel.
-            const int wa1 = std::min(CHOL_NBI, wa);
-            if (la && wa > wa1) {
-                hipEvent_t e_a2 = h->la_events[2 * nP + 2 + p];
-                launch_syrk(pick_tile(rem), h->d_S + K0, h->Mp, nullptr, K1, rem, K1 - K0, nullptr, nullptr, h->d_S, h->Mp, K1, 1, wa1);
+            // (a) rows >= K1, columns of the next outer panel
+            launch_syrk(pick_tile(rem), h->d_S + K0, h->Mp, nullptr, K1, rem, K1 - K0, nullptr, nullptr, h->d_S, h->Mp, K1, 1, wa);
+            if (la) {
                 HIPCHK(hipEventRecord(e_a, h->stream));
-                launch_syrk(pick_tile(rem - wa1), h->d_S + K0, h->Mp, nullptr, K1 + wa1, rem - wa1, K1 - K0, nullptr, nullptr, h->d_S, h->Mp, K1 + wa1, 1,
-                            wa - wa1);
-                HIPCHK(hipEventRecord(e_a2, h->stream));
                 HIPCHK(hipStreamWaitEvent(h->stream2, e_a, 0));
                 cur = h->stream2;
-                chol_chain(Ms, thr, K1, std::min(K1 + NBO, Ms), true, e_a2);     // next panel's chain beside (a2) and (b)
+                chol_chain(Ms, thr, K1, std::min(K1 + NBO, Ms), true);     // next panel's chain beside (b)
                 HIPCHK(hipEventRecord(e_c, h->stream2));
                 cur = h->stream;
-            } else {
-                launch_syrk(pick_tile(rem), h->d_S + K0, h->Mp, nullptr, K1, rem, K1 - K0, nullptr, nullptr, h->d_S, h->Mp, K1, 1, wa);
-                if (la) {
-                    HIPCHK(hipEventRecord(e_a, h->stream));
-                    HIPCHK(hipStreamWaitEvent(h->stream2, e_a, 0));
-                    cur = h->stream2;
-                    chol_chain(Ms, thr, K1, std::min(K1 + NBO, Ms), true);     // next panel's chain beside (b)
-                    HIPCHK(hipEventRecord(e_c, h->stream2));
-                    cur = h->stream;
-                }
             }
             // (b) the rest of the trailing matrix
             const int rem2 = rem - wa;
