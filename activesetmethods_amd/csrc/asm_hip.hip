@@ -33,7 +33,12 @@ const int IPM_MAXIT = 60;
 const double JAM_PINF = 1e-6;    // below this a stagnating primal residual is rounding-level, not a jam (oracle/lp_solver.py)
 const int IPM_MCC = 2;           // Gondzio centrality correctors per iteration (oracle/lp_solver.py)
 const double MCC_DELTA = 0.3, MCC_BMIN = 0.1, MCC_BMAX = 10.0, MCC_GAMMA = 0.1;
-const int CHOL_NBI = 256, CHOL_NBO = 1024;   // inner / outer panel widths of the three-level Cholesky
+// inner / outer panel widths of the three-level Cholesky.  Inner = 512 = eight 64-wide steps per dataflow launch (ASM_PNL_NS) and ONE
+// K = 512 update of the rest of the outer panel; measured at M = 1024 / 1725 / 3889 / 11192 / 18637: 256 -> 0.603 / 1.093 / 2.79 / 14.7 /
+// 44.95 ms, 512 -> 0.583 / 1.062 / 2.60 / 14.0 / 43.95 ms, 768 -> 0.674 / 1.226 / 2.96 / 15.0 / 45.0 ms, 1024 -> 0.847 / 1.365 / 3.24 /
+// 15.7 / 46.4 ms (wider: the rank-64 updates inside the launch grow onto the critical path; narrower: more launches and more of the
+// poorly filled in-panel updates)
+const int CHOL_NBI = 512, CHOL_NBO = 1024;
 // column (Sherman-Morrison-Woodbury) form of the Newton system for restoration LPs (oracle/lp_solver.py: COL_*)
 const int COL_MIN_M = 64, COL_MAX_CG = 6;
 const double COL_MAX_RATIO = 0.8, COL_FIXED = 1e200;
@@ -540,12 +545,12 @@ struct Dev {
         h->stats.nfact += 1;
     }
     // block chain of one outer panel [K0, K1): 64-wide potrf / panel solve steps whose rank-64 updates stay inside a
-    // 256-wide inner panel; the rest of the outer panel is updated once per inner panel with K = 256
+    // 512-wide inner panel; the rest of the outer panel is updated once per inner panel with K = 512
     void chol_chain(int Ms, double thr, int K0, int K1, bool beside_updates = false) {
         for (int I0 = K0; I0 < K1; I0 += CHOL_NBI) {
             const int I1 = std::min(I0 + CHOL_NBI, K1);
             if (h->fused_panel) {
-                // the <= 4 steps of this inner panel in one dataflow launch (k_chol_panel): row tiles are owned by workgroups,
+                // the <= 8 steps of this inner panel in one dataflow launch (k_chol_panel): row tiles are owned by workgroups,
                 // diagonal-block factors and the panel tiles other workgroups need travel through release / acquire flags
                 const int nrt = (Ms - I0 + ASM_NB - 1) / ASM_NB;
                 // grid: one workgroup per row tile while they all fit (77 KB of LDS: two per CU); measured: fewer workgroups with several
@@ -1724,10 +1729,10 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     dmalloc(&h->d_partial, (int64_t)ASM_TMAXCHUNKS * h->ldn);
     dmalloc(&h->d_idx, h->Mp);
     dmalloc(&h->d_Linv, (h->Mp / ASM_NB + 1) * ASM_NB * ASM_NB);
-    dmalloc(&h->d_pflags, 32);
+    dmalloc(&h->d_pflags, ASM_PNL_NS * (ASM_PNL_NS + 1));
     dmalloc(&h->d_ptmo, 4);
     HIPCHK(hipMemsetAsync(h->d_ptmo, 0, 4 * sizeof(unsigned), h->stream));
-    HIPCHK(hipMemsetAsync(h->d_pflags, 0, 32 * sizeof(unsigned), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_pflags, 0, ASM_PNL_NS * (ASM_PNL_NS + 1) * sizeof(unsigned), h->stream));
     h->wb = h->M > 1536 ? 1024 : 512;      // wide-block width of the triangular solves (k_wtrsv_*<WB>)
     if (h->M >= RED_MIN_M) {
         dmalloc(&h->d_idxI, h->Mp); dmalloc(&h->d_rdI, h->Mp); dmalloc(&h->d_rce, h->Mp); dmalloc(&h->d_rze, h->Mp); dmalloc(&h->d_sdiag, h->Mp);

@@ -809,14 +809,14 @@ __global__ __launch_bounds__(256) void k_panel_update64(double* __restrict__ S, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Fused inner panel of the Cholesky: the 64-wide steps of one inner panel [I0, I1) (<= 4 steps: diagonal-block
+// Fused inner panel of the Cholesky: the 64-wide steps of one inner panel [I0, I1) (<= ASM_PNL_NS = 8 steps: diagonal-block
 // factorisation, panel solve, rank-64 update of the panel's remaining columns) in ONE launch, as a dataflow over
 // 64-row tiles instead of three dependent launches per step.  Row tile rt (rows I0 + 64 rt ...) belongs to workgroup
 // rt mod G for the whole launch, so a tile's own history needs no synchronisation; what crosses workgroups is published
 // with an agent-scope release and consumed behind a relaxed poll + ONE agent-scope acquire (cdna_hip_programming.md,
 // Guideline 16):
 //     flags[k]              the factor / inverse of diagonal block k (written by the owner of row tile k)
-//     flags[4 + 4 k + tj]   the solved panel tile X(tj, step k) of a later diagonal row tile tj (the right operand of the
+//     flags[NS + NS k + tj] the solved panel tile X(tj, step k) of a later diagonal row tile tj (the right operand of the
 //                           rank-64 update of column tile tj)
 // The owner of row tile k+1 factors diagonal block k+1 as soon as that tile has its step-k update (look-ahead): the
 // critical path of a step is  panel solve + update of ONE tile + the 64 x 64 factorisation, everything else overlaps.
@@ -847,6 +847,7 @@ __device__ __forceinline__ void pnl_wait(unsigned* flag, unsigned epoch, unsigne
     __syncthreads();
 }
 #define ASM_PNL_LDS (2 * ASM_NB * ASM_XP + 4 * 16 * 17 + 2 * ASM_NB)
+#define ASM_PNL_NS 8        // most 64-wide steps of one panel launch (flag words: NS for the diagonal blocks + NS * NS for the panel tiles)
 // Register budget: two wavefronts per SIMD = 256 registers per lane, AGPRs included.  The panel kernel runs beside k_syrk_upd
 // (256 per wavefront, two per SIMD): a panel wavefront must fit into the slot ONE retiring update wavefront frees.  Left to
 // itself the compiler takes 256 VGPRs + 56 AGPRs (occupancy 1 is allowed for a 256-thread kernel), such a wavefront fits
@@ -935,7 +936,7 @@ __device__ __forceinline__ void chol_panel_body(double* __restrict__ sm, double*
                     }
                 }
             QSTAMP(k == 1 && rt == 2);
-            if (rt < nsteps) pnl_publish(flags + 4 + 4 * k + rt, epoch);      // a later diagonal row tile: its X is an operand for others
+            if (rt < nsteps) pnl_publish(flags + ASM_PNL_NS + ASM_PNL_NS * k + rt, epoch);      // a later diagonal row tile: its X is an operand for others
             else __syncthreads();
             QSTAMP(k == 1 && rt == 2);
             // ---- rank-64 update of the panel's remaining column tiles tj = k+1 .. min(rt, nsteps-1)
@@ -944,7 +945,7 @@ __device__ __forceinline__ void chol_panel_body(double* __restrict__ sm, double*
                 const int c0 = I0 + tj * ASM_NB, c_end = min(c0 + ASM_NB, min(I1, Ms));
                 const double* Pb = B0;
                 if (tj != rt) {
-                    pnl_wait(flags + 4 + 4 * k + tj, epoch, tmo);
+                    pnl_wait(flags + ASM_PNL_NS + ASM_PNL_NS * k + tj, epoch, tmo);
                     {
                         double tv[ASM_NB * ASM_NB / 256];
 #pragma unroll
