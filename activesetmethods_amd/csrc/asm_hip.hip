@@ -1536,7 +1536,18 @@ struct Solver {
             // the partition is not optimal as it stands: bulk corrections from the iterate's projection
             as_copy_sets(0, 3);
             bool okr = eqp_loop(d_pref, P.y, 2);
-            if (okr) { hint.prefer_ref = true; h->stats.path = 9; return ASM_OPTIMAL; }
+            if (okr) {
+                // the corrected working set passes the LP optimality test, i.e. it describes a face of optimal points: return that
+                // face's canonical pair (a function of the discrete set) rather than the projection of the iterate onto it
+                // (oracle: solve_scaled).  face_polish leaves the projection in place when its own stages do not succeed.
+                hint.prefer_ref = true;
+                if (final_sets != 3) as_copy_sets(3, final_sets);
+                const int eqp_sets = final_sets;
+                const int how2 = face_polish();
+                if (how2 == 0) final_sets = eqp_sets;
+                h->stats.path = how2 == 2 ? 4 : 9;
+                return ASM_OPTIMAL;
+            }
             hint.prefer_ref = false;
             if (prefer_ref) {                               // the least-norm polish has not been tried on this LP yet
                 as_copy_sets(0, 3);

@@ -1037,6 +1037,12 @@ def solve_scaled(lp, warm=None, stats=None, hint=None):
         ok, p, s, y, sets = eqp_loop(lp, sets0, np.clip(ip.p, lp.lb, lp.ub), ip.y, 2, stats)
         if ok:
             hint['prefer_ref'] = True
+            # the corrected working set passes the LP optimality test, i.e. it describes a face of optimal points: return that
+            # face's canonical pair (a function of the discrete set) rather than the projection of the iterate onto it
+            how, p2, s2, y2, sets2 = face_polish(lp, sets, np.clip(ip.p, lp.lb, lp.ub), ip.y, stats)
+            if how == 'face':
+                stats['path'] = 'ipm+face'
+                return OPTIMAL, p2, s2, y2, sets2
             stats['path'] = 'ipm+ref'
             return OPTIMAL, p, s, y, sets
         hint['prefer_ref'] = False
