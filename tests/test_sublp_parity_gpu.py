@@ -342,3 +342,25 @@ def test_lp_entry_for_an_moi_optimizer(seed, infeasible):
         assert rel_err(s, flat) < 1e-12
     assert np.array_equal(bs, opt.active_set()[1])
     opt.close(); opt2.close()
+
+
+@pytest.mark.parametrize("seed,infeasible", [(71, False), (72, True)])
+def test_scalar_readback_paths_agree(seed, infeasible, monkeypatch):
+    """The interior-point loop reads its scalar block either from host-mapped memory the reduction kernels write themselves (default:
+    the host spins on a sequence word) or with hipMemcpyAsync + hipStreamSynchronize (ASM_HIP_SPIN=0).  Same kernels, same values:
+    the two paths must give bit-identical answers and statistics."""
+    sp = random_subproblem(seed, 60, 45, 0.4, 0.2, 4, infeasible=infeasible)
+    outs = []
+    for spin in ("1", "0"):
+        monkeypatch.setenv("ASM_HIP_SPIN", spin)           # read at asm_create
+        opt, h_out = hip_solve(sp)
+        if h_out[5] == 2:
+            opt, h_out = hip_solve(sp, True, opt)
+        st = opt.last_stats()
+        outs.append((h_out, st['ipm_iters'], st['nfact'], st['path']))
+        opt.close()
+    (a, ia, fa, pa), (b, ib, fb, pb) = outs
+    assert (ia, fa, pa) == (ib, fb, pb)
+    assert a[5] == b[5] == 1
+    for u, v in zip(a[:4], b[:4]):
+        assert np.array_equal(u, v)
