@@ -655,15 +655,18 @@ __device__ __forceinline__ void potrf64_body(double* __restrict__ D, double* __r
         }
         __syncthreads();
     }
-#pragma unroll
-    for (int e_it = 0; e_it < ASM_NB * ASM_NB / 256; ++e_it) {
-        const int e = tid + 256 * e_it;
-        int rr = e >> 6, c = e & 63;
-        if (rr < nb && c <= rr) S[(int64_t)(k0 + rr) * ldS + k0 + c] = D[rr * ASM_DP + c];
+    // ---- the factor goes back to S (wavefronts 0, 2, 3) while wavefront 1 inverts the last diagonal sub-block; then the inverse
+    // W = L^-1 by 16x16 blocks (diagonal blocks 0..2 were inverted beside the factorisation of their successors)
+    if (wv == 1) {
+        diag_inverse(48);
+    } else {
+        const int t3 = (wv == 0 ? 0 : wv - 1) * 64 + lane;          // 0..191
+        for (int e = t3; e < ASM_NB * ASM_NB; e += 192) {
+            int rr = e >> 6, c = e & 63;
+            if (rr < nb && c <= rr) S[(int64_t)(k0 + rr) * ldS + k0 + c] = D[rr * ASM_DP + c];
+        }
     }
     PSTAMP();
-    // ---- inverse W = L^-1 by 16x16 blocks (diagonal blocks 0..2 were inverted beside the factorisation of their successors)
-    if (wv == 1) diag_inverse(48);
     __syncthreads();
     PSTAMP();
     for (int dlev = 1; dlev < 4; ++dlev) {               // off-diagonal blocks (i, j = i - dlev), one wavefront per block,
