@@ -836,7 +836,7 @@ struct Solver {
         for (int64_t i = 0; i < M; ++i) nineq += lp.rtype[i] != 0;
         for (int64_t j = 0; j < n; ++j) nfree += lp.ub[j] > lp.lb[j];
         ip.ncomp = std::max<int64_t>(2 * nfree + lp.ns + nineq, 1);
-        ip.red_ok = lp.ns == 0 && M >= RED_MIN_M && h->sp_ok;
+        ip.red_ok = M >= RED_MIN_M && h->sp_ok;
         ip.col_ok = h->col_capable && lp.ns > 0 && M >= COL_MIN_M && (double)n <= COL_MAX_RATIO * (double)M;   // every row owns a slack (setup)
         ipm_upload_lp();
         P.ncomp = ip.ncomp;
@@ -1000,7 +1000,7 @@ struct Solver {
                     HIPCHK(hipStreamSynchronize(h->stream));
                     redE.clear(); redI.clear();
                     for (int64_t i = 0; i < lp.M; ++i) {
-                        if (lp.rtype[i] != 0 && tmpM[i] > RED_TAU * tmpM2[i]) redI.push_back((int)i);
+                        if (tmpM[i] > RED_TAU * tmpM2[i]) redI.push_back((int)i);
                         else redE.push_back((int)i);
                     }
                     use_red = (double)redI.size() >= RED_MIN_FRAC * (double)lp.M && !redE.empty();

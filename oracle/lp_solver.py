@@ -53,6 +53,11 @@ PCG_KAPPA = 1e-3     # Newton-system residual tolerance relative to the current 
 IPM_MCC = 2          # Gondzio multiple centrality correctors per iteration (a solve costs ~1/50 of a factorisation)
 MCC_DELTA, MCC_BMIN, MCC_BMAX, MCC_GAMMA = 0.3, 0.1, 10.0, 0.1
 IPM_RHO_P = 1e-8     # primal proximal regularisation of the Newton system (bounds Theta^-1 for effectively free variables)
+NS_MIN_E = 64         # null-space form (normal phase): fewest hard equality rows, largest null-space dimension relative to M,
+NS_MAX_RATIO = 0.3    # pivot thresholds of the basis-column selection (first one that yields a full basis), pivot threshold
+NS_SEL_THR = (1e-2, 1e-4, 1e-7, 1e-10)    # for re-using the previous LP's basis columns, CG steps per solve beyond which the LP
+NS_WARM_THR = 1e-6    # returns to the row form
+NS_MAX_CG = 2
 CHOL_NB = 64
 PIV_BIG = 1e128
 
@@ -178,12 +183,90 @@ def farkas_margin(lp, y):
     return float(yn @ lp.r - lhs_max)
 
 
+class NullSpace:
+    """Equality elimination for the normal-phase LP (no slack columns): the rows E with rtype 0 hold with equality at every
+    Newton step, so steps live in  p = pbar + Z u  with  Z  an orthonormal basis of  null(A_EF)  (F = columns with ub > lb;
+    A_EF = the E rows with the fixed columns zeroed).  At the ACOPF sizes null(A_EF) is small (case1354pegase-sized: 10.7k
+    equality rows, n = 11.2k, dimension ~ 500) and the Newton matrix of an interior-point iteration shrinks from M x M to k x k.
+
+      S0 = A_EF A_EF'            factored ONCE per LP (guarded Cholesky: a dependent equality row is dropped)
+      P  = I_F - A_EF' S0^-1 A_EF  projector onto null(A_EF) inside the free columns
+      J  = k columns with  P[:, J]  of full rank: the previous LP's J when P[J, J] still factors with pivots above
+           NS_WARM_THR (the retained basis - what a simplex code keeps between solves, slp.jl:38-40), else selected by a
+           guarded Cholesky of P in index order (a column whose pivot falls below the threshold is skipped; thresholds
+           NS_SEL_THR are tried in turn until exactly k columns remain)
+      Zt = L_J^-1 P[J, :]        (k x n, orthonormal rows, zero in the fixed columns;  L_J L_J' = P[J, J])
+      GI = A_I Z                 (inequality rows in the reduced coordinates)
+    `valid` is False when no full basis is found (the caller keeps the row form)."""
+
+    def __init__(self, lp, warm_J=None):
+        A, n = lp.A, lp.n
+        self.E = np.nonzero(lp.rtype == 0)[0]
+        self.I = np.nonzero(lp.rtype != 0)[0]
+        self.Fm = (lp.ub > lp.lb).astype(float)
+        nE, nF = len(self.E), int(self.Fm.sum())
+        self.valid = False
+        self.J = None
+        self.nfact = 0
+        self.cold = False
+        AEF = A[self.E] * self.Fm
+        self.AEF = AEF
+        S0 = AEF @ AEF.T
+        idx = np.arange(nE)
+        d0 = S0[idx, idx].copy()
+        self.L0 = chol_guard(S0, d0, 1e-10)
+        self.nfact += 1
+        dropped = np.diag(self.L0) >= 0.5 * PIV_BIG
+        self.k = k = nF - (nE - int(dropped.sum()))
+        if k < 1 or k > 1.5 * NS_MAX_RATIO * lp.M + 8:
+            return
+        ones = np.ones(n)
+
+        def basis_from(J):
+            """Orthonormal basis from the columns J of P, or None when P[J, J] has a pivot below NS_WARM_THR."""
+            W = chol_solve(self.L0, AEF[:, J])                       # S0^-1 a_j   (nE x k)
+            PJ = -(W.T @ AEF)                                       # P[J, :] = E_J' - W' A_EF
+            PJ[np.arange(len(J)), J] += 1.0
+            PJ *= self.Fm
+            T = np.tril(PJ[:, J])
+            LJ = _chol_guard_loop(T + np.tril(T, -1).T, np.ones(len(J)), NS_WARM_THR)
+            self.nfact += 1
+            if (np.diag(LJ) >= 0.5 * PIV_BIG).any():
+                return None
+            return solve_triangular(LJ, PJ, lower=True)
+
+        Zt = None
+        if warm_J is not None and len(warm_J) == k and np.all(self.Fm[warm_J] > 0):
+            J = np.asarray(warm_J, np.int64)
+            Zt = basis_from(J)
+        if Zt is None:
+            self.cold = True
+            Y = solve_triangular(self.L0, AEF, lower=True)           # L0^-1 A_EF  (nE x n)
+            T = -(Y.T @ Y)
+            T[np.arange(n), np.arange(n)] += self.Fm
+            self.nfact += 1
+            for thr in NS_SEL_THR:
+                LT = _chol_guard_loop(T, ones, thr)
+                J = np.nonzero(np.diag(LT) < 0.5 * PIV_BIG)[0]
+                if len(J) == k:
+                    Zt = basis_from(J)
+                    if Zt is not None:
+                        break
+            if Zt is None:
+                return
+        self.J = J
+        self.Zt = Zt                                                # k x n
+        self.AI = A[self.I] * self.Fm
+        self.GI = self.AI @ Zt.T                                    # |I| x k
+        self.valid = True
+
+
 class IPM:
     """Mehrotra predictor-corrector + Gondzio multiple centrality correctors, separate primal / dual step
     lengths, Schur (row) form.
     Resumable: `run(tol, max_more)` continues from the current iterate."""
 
-    def __init__(self, lp):
+    def __init__(self, lp, ns_J=None):
         self.lp = lp
         M, n, ns = lp.M, lp.n, lp.ns
         self.ineq = lp.rtype != 0
@@ -216,9 +299,17 @@ class IPM:
         self.col_iters = 0
         # reduced row form: normal phase of large problems with a sparse matrix only (the selection and the extra CG steps
         # cost more than they save on small or dense ones)
-        self.red_ok = bool(ns == 0 and M >= RED_MIN_M and np.count_nonzero(lp.A) * 16 <= M * n)
+        self.red_ok = bool(M >= RED_MIN_M and np.count_nonzero(lp.A) * 16 <= M * n)
         self.red_off = False
         self.red_iters = 0
+        # null-space form (class NullSpace): normal phase, many hard equality rows, small null space
+        nE = int((lp.rtype == 0).sum())
+        nF = int(free.sum())
+        self.ns_ok = bool(ns == 0 and nE >= NS_MIN_E and nF - nE <= NS_MAX_RATIO * M)
+        self.ns_off = False
+        self.ns_iters = 0
+        self.ns = None
+        self.ns_J = ns_J              # basis columns retained from the previous LP of the phase (in), of this LP (out)
 
     def measures(self):
         lp, ineq, sg, free = self.lp, self.ineq, self.sg, self.free
@@ -271,7 +362,45 @@ class IPM:
             # Woodbury  S^-1 = D^-1 - D^-1 A K^-1 A' D^-1  with  K = Th + A' D^-1 A  (n x n instead of M x M).  Used as the
             # CG preconditioner while it is accurate; once active rows drive D_ii towards 0 the CG step count rises and the
             # rest of the LP goes back to the row form.
-            use_col = self.col_ok and not self.col_off
+            use_ns = False
+            if self.ns_ok and not self.ns_off:
+                if self.ns is None:
+                    self.ns = NullSpace(lp, self.ns_J)
+                    self.ns_fact = self.ns.nfact
+                    self.ns_J = self.ns.J
+                    if not self.ns.valid:
+                        self.ns_off = True
+                use_ns = not self.ns_off
+            if use_ns:
+                # Null-space form: with the equality rows eliminated ( dp = dpbar + Z du,  A_EF dpbar = r_E ) and the inequality
+                # rows condensed ( dy_I = D_I^-1 (r_I - A_I dp) ) the Newton system  S dy = r  becomes the k x k system
+                #   N du = Z'(A_I' D_I^-1 r_I - K dpbar),   N = Z' K Z,   K = Th + A_I' D_I^-1 A_I,
+                # and  dy_E = S0^-1 A_EF (K dp - A_I' D_I^-1 r_I)  recovers the equality multipliers: two solves with the factor
+                # of S0 = A_EF A_EF' (made once per LP) and one with the factor of N per Newton solve.
+                self.ns_iters += 1
+                nsp = self.ns
+                thF = (muL / tL + muU / tU + IPM_RHO_P) * nsp.Fm
+                dinvI = 1.0 / dS[nsp.I]
+                Nm = (nsp.Zt * thF) @ nsp.Zt.T + (nsp.GI.T * dinvI) @ nsp.GI
+                kdx = np.arange(nsp.k)
+                nd0 = Nm[kdx, kdx].copy()
+                Nm[kdx, kdx] += 1e-13 * nd0 + 1e-30
+                LN = chol_guard(Nm, nd0)
+                AIF = nsp.AI
+
+                def precond(r):
+                    dpb = nsp.AEF.T @ chol_solve(nsp.L0, r[nsp.E])
+                    hI = AIF.T @ (dinvI * r[nsp.I])
+                    Kdpb = thF * dpb + AIF.T @ (dinvI * (AIF @ dpb))
+                    du = chol_solve(LN, nsp.Zt @ (hI - Kdpb))
+                    dpF = dpb + nsp.Zt.T @ du
+                    dyI = dinvI * (r[nsp.I] - AIF @ dpF)
+                    KdpF = thF * dpF + AIF.T @ (dinvI * (AIF @ dpF))
+                    dy = np.empty(M)
+                    dy[nsp.E] = chol_solve(nsp.L0, nsp.AEF @ (KdpF - hI))
+                    dy[nsp.I] = dyI
+                    return dy
+            use_col = (not use_ns) and self.col_ok and not self.col_off
             if use_col:
                 self.col_iters += 1
                 dinv = 1.0 / dS
@@ -290,14 +419,15 @@ class IPM:
             # Schur diagonal (D_ii > RED_TAU * s_ii, s_ii = sum_j A_ij^2 / Th_j) is almost decoupled from the rest - it is
             # left out of the factor and preconditioned by its diagonal alone; the CG on the full system restores the coupling.
             use_red = False
-            if not use_col and self.red_ok and not self.red_off:
+            if not use_col and not use_ns and self.red_ok and not self.red_off:
                 sdiag = (A * A) @ thp_inv
-                drop = ineq & (dS > RED_TAU * sdiag)
+                drop = dS > RED_TAU * sdiag
                 use_red = RED_MIN_FRAC * M <= int(drop.sum()) < M
-            if use_col:
+            if use_col or use_ns:
                 pass
             elif use_red:
                 self.red_iters += 1
+                self.__dict__.setdefault('red_sizes', []).append(int((~drop).sum()))
                 E = np.nonzero(~drop)[0]
                 Idx = np.nonzero(drop)[0]
                 SE = dsyrk(1.0, A[E] * np.sqrt(thp_inv), lower=True)
@@ -414,6 +544,10 @@ class IPM:
                     break
                 dp, ds, dg, dy, dmuL, dmuU, dmus, dpi = cand
                 ap, ad = ap2, ad2
+            self.last_cg = (cg_max[0], cg_fail[0])
+            if use_ns and cg_fail[0]:
+                self.ns_off = True                  # the reduced system lost its accuracy: redo the iteration in row form
+                continue
             if use_col and cg_fail[0]:
                 # the column-form preconditioner has lost its accuracy (active rows drove D_ii to ~0): drop this
                 # iteration's directions and redo the iteration in row form
@@ -434,6 +568,8 @@ class IPM:
             self.mus = mus + b * dmus
             self.pi = pi + b * dpi
             self.y = np.where(ineq, sg * self.pi, self.y + b * dy)
+            if use_ns and cg_max[0] > NS_MAX_CG:
+                self.ns_off = True
             if use_col and cg_max[0] > COL_MAX_CG:
                 self.col_off = True
             if use_red and cg_max[0] > RED_MAX_CG:
@@ -987,7 +1123,7 @@ def solve_scaled(lp, warm=None, stats=None, hint=None):
             hint['warm_skip'] = 2 ** hint['warm_fail'] - 1          # 1, 3, 7 solves
             hint['stable'] = False
     prefer_ref = bool(hint.get('prefer_ref', False))
-    ip = IPM(lp)
+    ip = IPM(lp, hint.get('ns_J'))
     sets0 = None
     for stage, (tol, more) in enumerate(IPM_STAGES):
         st = ip.run(tol, more)
@@ -995,6 +1131,8 @@ def solve_scaled(lp, warm=None, stats=None, hint=None):
         stats['ipm_iters'] = ip.iters
         stats['col_iters'] = ip.col_iters
         stats['red_iters'] = ip.red_iters
+        stats['ns_iters'] = ip.ns_iters
+        hint['ns_J'] = ip.ns_J
         if st == INFEASIBLE:
             stats['path'] = 'ipm-infeasible'
             return INFEASIBLE, None, None, None, None
