@@ -9,6 +9,7 @@
 #include "asm_kernels.hip.h"
 #include "asm_ipm_kernels.hip.h"
 #include "asm_as_kernels.hip.h"
+#include "asm_ns_kernels.hip.h"
 #include "asm_eval_kernels.hip.h"
 #include "../../include/asm_hip.h"
 
@@ -45,6 +46,10 @@ const double COL_MAX_RATIO = 0.8, COL_FIXED = 1e200;
 // reduced row form of the normal-phase Newton system, large sparse problems only (oracle/lp_solver.py: RED_*)
 const int RED_MIN_M = 4096, RED_MAX_CG = 10;
 const double RED_TAU = 100.0, RED_MIN_FRAC = 0.1;
+// null-space form of the normal-phase Newton system (oracle/lp_solver.py: NS_*)
+const int NS_MIN_E = 64;
+const double NS_MAX_RATIO = 0.3, NS_WARM_THR = 1e-6, NS_BIG = 0.5e128, NS_DERR = 0.1;
+const double NS_SEL_THR[4] = {1e-2, 1e-4, 1e-7, 1e-10};
 const int PCG_MAXIT = 20;       // conjugate-gradient steps per Newton solve (preconditioner = the Cholesky factor)
 const double PCG_KAPPA = 1e-3;  // Newton-system residual tolerance relative to the current primal residual
 const double IPM_RHO_P = 1e-8;   // primal proximal regularisation of the Newton system
@@ -86,12 +91,20 @@ struct SolveHint {
     int warm_fail = 0, warm_skip = 1;     // the first re-solve of a phase is not attempted
     bool stable = false;                  // the last two LPs of the phase ended on the same active sets
     bool prefer_ref = false;
+    std::vector<int> ns_J;                // basis columns of the null-space form retained from the previous LP of the phase
 };
 
 struct TimedRegion {
     hipEvent_t a, b;
     int kind;
     hipStream_t stream;     // the stream the timed launches go to (the look-ahead stream has its own regions)
+};
+
+// one Cholesky factor with the explicit inverses the substitution kernels use (the null-space form keeps two besides the main one)
+struct FacBuf {
+    double *S = nullptr, *Linv = nullptr, *Binv = nullptr, *BinvT = nullptr;
+    int64_t ld = 0;
+    int wb = 512;                   // wide-block width of its substitution kernels
 };
 
 }  // namespace
@@ -146,6 +159,14 @@ struct asm_handle {
     bool nz_valid = false;
     int nz_T = 0, nz_pitch = 0;
     double nz_fraction = 1.0;       // executed share of the (tile pair, k-chunk) products of the Schur build
+    // ---- null-space form of the interior-point Newton system (asm_ns_kernels.hip.h; oracle: class NullSpace)
+    bool ns_cap = false;            // the LP skeleton qualifies (sparse pattern, enough hard equality rows, small null space)
+    int ns_nE = 0, ns_nI = 0, ns_nEp = 0, ns_nIp = 0, ns_kcap = 0;
+    int64_t ns_ldg = 0;
+    int *d_nsEidx = nullptr, *d_nsEpos = nullptr, *d_nsIidx = nullptr, *d_nsIpos = nullptr, *d_nsJ = nullptr, *d_nscnt = nullptr;
+    FacBuf ns_f0, ns_fN;            // factors of S0 = A_EF A_EF' (per LP) and of the k x k reduced matrix (per iteration)
+    double *d_nsLt = nullptr, *d_nsR = nullptr, *d_nsX = nullptr, *d_nsG = nullptr, *d_nsth = nullptr, *d_nsFm = nullptr, *d_nsv = nullptr, *d_nsYt = nullptr, *d_nsN0 = nullptr;
+    std::vector<void*> ns_bufs;     // everything above, for release
     double* d_ipm = nullptr;        // arena of the device-resident interior-point state
     int* d_ipm_i = nullptr;
     double* d_as = nullptr;         // arena of the device-resident active-set machinery (asm_as_kernels.hip.h)
@@ -189,8 +210,6 @@ struct asm_handle {
     asm_kernel_stats kstats;
     std::vector<TimedRegion> regions;
     std::vector<hipEvent_t> event_pool;
-    std::map<std::pair<int, int>, hipGraphExec_t> graphs;   // (kind, Ms) -> captured launch sequence
-    bool use_graphs = false;
     bool fused_panel = true;        // Cholesky inner panels as one dataflow launch (k_chol_panel) instead of three launches per 64-wide step
     int panel_wgs = 240;            // its grid bound: every workgroup must be able to become resident
     int num_cus = 256;              // compute units of the device (hipDeviceProp_t::multiProcessorCount)
@@ -202,6 +221,28 @@ struct asm_handle {
 
 namespace {
 
+template <class T>
+void dmalloc(T** p, int64_t count) {
+    HIPCHK(hipMalloc((void**)p, std::max<int64_t>(count, 1) * sizeof(T)));
+}
+
+double* ns_dalloc(asm_handle* h, int64_t count) {
+    double* d = nullptr;
+    dmalloc(&d, count);
+    h->ns_bufs.push_back((void*)d);
+    HIPCHK(hipMemsetAsync(d, 0, std::max<int64_t>(count, 1) * sizeof(double), h->stream));
+    return d;
+}
+// buffers of one Cholesky factor of order <= N (pitch = N rounded up to 32) with the block inverses of the substitution kernels
+void ns_alloc_factor(asm_handle* h, FacBuf& f, int64_t N) {
+    f.ld = round_up(std::max<int64_t>(N, 1), 32);
+    f.wb = (f.ld <= 1024 || f.ld > 1536) ? 1024 : 512;      // one wide block (= the whole inverse) when the factor fits into it
+    f.S = ns_dalloc(h, f.ld * f.ld);
+    f.Linv = ns_dalloc(h, (f.ld / ASM_NB + 1) * ASM_NB * ASM_NB);
+    f.Binv = ns_dalloc(h, (f.ld / f.wb + 1) * (int64_t)f.wb * f.wb);
+    f.BinvT = ns_dalloc(h, (f.ld / f.wb + 1) * (int64_t)f.wb * f.wb);
+}
+
 // =====================================================================================================
 // device helpers
 // =====================================================================================================
@@ -209,7 +250,14 @@ struct Dev {
     asm_handle* h;
     hipStream_t cur;                 // stream the factorisation kernels are launched on (h->stream, or the look-ahead stream)
     double* solve_w = nullptr;       // buffer the wide-block substitution runs in (default d_vecM2)
-    explicit Dev(asm_handle* hh) : h(hh), cur(hh->stream) {}
+    // the factor the Cholesky / substitution launches work on: matrix (lower triangle, pitch fld), inverses of its 64-wide diagonal
+    // blocks, explicit inverses of its wide diagonal blocks and their transposes.  Default: the handle's main buffers.
+    double *fS, *fLinv, *fBinv, *fBinvT;
+    int64_t fld;
+    int fwb;
+    explicit Dev(asm_handle* hh) : h(hh), cur(hh->stream) { use_main(); }
+    void use_main() { fS = h->d_S; fld = h->Mp; fLinv = h->d_Linv; fBinv = h->d_Binv; fBinvT = h->d_BinvT; fwb = h->wb; }
+    void use_factor(const FacBuf& f) { fS = f.S; fld = f.ld; fLinv = f.Linv; fBinv = f.Binv; fBinvT = f.BinvT; fwb = f.wb; }
 
     hipEvent_t get_event() {
         if (!h->event_pool.empty()) {
@@ -357,6 +405,49 @@ struct Dev {
         launch_syrk(T, h->d_Ah, h->ldn, idx_dev, 0, Ms, (int)h->ldn, theta_dev, diag_dev, h->d_S, h->Mp, 0, 0, -1, skip ? nz2 : nullptr, nch, frac);
         end(id);
     }
+    // S[0:Ms,0:Ms] (lower, pitch ldS) = Ah[idx,:] diag(theta) Ah[idx,:]'  into an arbitrary buffer (null-space form: S0 = A_EF A_EF')
+    void syrk_gathered_into(const int* idx_dev, int Ms, const double* theta_dev, double* S, int64_t ldS) {
+        const int nch = (int)(h->ldn / ASM_KC);
+        const int T = pick_tile(Ms), TS = 32 * T;
+        const int nt = (Ms + TS - 1) / TS;
+        const bool skip = h->nz_valid && nt > 0;
+        unsigned char* nz2 = h->d_nz + h->nz_half;
+        double frac = 1.0;
+        if (skip) {
+            hipLaunchKernelGGL(k_tile_nzflags, dim3((unsigned)nt, (unsigned)((nch + 7) / 8)), dim3(256), 0, h->stream, h->d_Ah, h->ldn, (int64_t)Ms, TS, nch,
+                               nz2, nch, idx_dev);
+            frac = executed_fraction(nz2, nt, nch);
+        }
+        int id = begin(ASM_K_SYRK, frac * (double)Ms * (Ms + 1) * h->ldn, 8.0 * (Ms * (double)h->ldn + 0.5 * Ms * (double)Ms));
+        launch_syrk(T, h->d_Ah, h->ldn, idx_dev, 0, Ms, (int)h->ldn, theta_dev, nullptr, S, ldS, 0, 0, -1, skip ? nz2 : nullptr, nch, frac);
+        end(id);
+    }
+    // C = (C0) -/+ A B'  on the matrix cores (k_gemm_nt); K a multiple of 32
+    void gemm_nt(const double* A, int64_t lda, const double* B, int64_t ldb, const double* C0, int64_t ldc0, double* C, int64_t ldc, int Ma, int Mb, int K, int mode) {
+        if (Ma <= 0 || Mb <= 0) return;
+        int id = begin(ASM_K_TRSV, 2.0 * Ma * (double)Mb * K, 8.0 * ((double)(Ma + Mb) * K + (double)Ma * Mb));
+        hipLaunchKernelGGL(k_gemm_nt, dim3((unsigned)((Mb + 63) / 64), (unsigned)((Ma + 63) / 64)), dim3(256), 0, h->stream, A, lda, B, ldb, C0, ldc0, C, ldc, Ma, Mb, K, mode);
+        end(id);
+    }
+    // Rows of R (nrhs x ldr, zero beyond column Ms) are right-hand sides of  L x = r  (forward) and then  L' x = z  (backward) with the
+    // CURRENT factor (fS, its wide-block inverses) and its transposed copy Lt (same pitch).  Block substitution over the wide
+    // blocks: an update  R_blk -= X[:, done] L[blk, done]'  and a product with the explicit inverse of the diagonal block, both on the
+    // matrix cores.  Forward: R -> X.  Backward (if Lt): X -> R.  The solution ends in R (backward) or X (forward only).
+    void trsm_rows(double* R, double* X, int64_t ldr, int nrhs, int Ms, const double* Lt) {
+        const int WB = fwb;
+        const int nB = (Ms + WB - 1) / WB;
+        for (int B = 0; B < nB; ++B) {
+            const int b0 = B * WB, wv = std::min(WB, Ms - b0), Kb = (int)round_up(wv, 32);
+            if (b0 > 0) gemm_nt(X, ldr, fS + (int64_t)b0 * fld, fld, R + b0, ldr, R + b0, ldr, nrhs, wv, b0, 1);
+            gemm_nt(R + b0, ldr, fBinv + (int64_t)B * WB * WB, WB, nullptr, 0, X + b0, ldr, nrhs, wv, Kb, 0);
+        }
+        if (!Lt) return;
+        for (int B = nB - 1; B >= 0; --B) {
+            const int b0 = B * WB, wv = std::min(WB, Ms - b0), b1 = b0 + wv, Kb = (int)round_up(wv, 32);
+            if (b1 < Ms) gemm_nt(R + b1, ldr, Lt + (int64_t)b0 * fld + b1, fld, X + b0, ldr, X + b0, ldr, nrhs, wv, (int)round_up(Ms - b1, 32), 1);
+            gemm_nt(X + b0, ldr, fBinvT + (int64_t)B * WB * WB, WB, nullptr, 0, R + b0, ldr, nrhs, wv, Kb, 0);
+        }
+    }
     // out[i] = sum_j Ah_ij^2 thinv_j   (sparse patterns only)
     void schur_diag(const double* thinv_dev, double* out_dev) {
         const double* v = sparse_vals(h->d_Ah);
@@ -427,7 +518,7 @@ struct Dev {
         if (out_dev != rhs_dev) HIPCHK(hipMemcpyAsync(out_dev, rhs_dev, Ms * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         int id = begin(ASM_K_TRSV, 2.0 * Ms * (double)Ms, 8.0 * Ms * (double)Ms);
         solve_w = out_dev;
-        run_sequence(3, Ms, false, [&] { solve_launches(Ms); });
+        solve_launches(Ms);
         solve_w = h->d_vecM2;
         end(id);
     }
@@ -453,7 +544,7 @@ struct Dev {
         double fl = (MsB == Ms && ntj == 0) ? (double)Ms * (Ms + 1) * K : 2.0 * ((double)Ms * MsB - 0.5 * (double)MsB * MsB) * K;
         if (nz) fl *= nzfrac >= 0.0 ? nzfrac : h->nz_fraction;
         // timed on the stream it is launched on (HIP events see only their own stream)
-        int kid = h->use_graphs ? -1 : begin(ASM_K_SYRK_KERNEL, fl, 8.0 * ((double)(Ms + MsB) * K + (double)Ms * MsB), cur);
+        int kid = begin(ASM_K_SYRK_KERNEL, fl, 8.0 * ((double)(Ms + MsB) * K + (double)Ms * MsB), cur);
         struct EndGuard { Dev* d; int id; ~EndGuard() { d->end(id); } } guard_{this, kid};
         // ASM_SYRK_UPD=0: the Cholesky updates through the generic kernel (ablation: what the dedicated kernel is worth)
         static const bool use_upd = [] { const char* v = std::getenv("ASM_SYRK_UPD"); return !(v && v[0] == '0'); }();
@@ -497,50 +588,27 @@ struct Dev {
         end(id);
     }
     void diag_prepare(int Ms, int mode, double rel, double absv) {
-        hipLaunchKernelGGL(k_diag_prepare, dim3(1), dim3(1024), 0, h->stream, h->d_S, h->Mp, Ms, h->d_diag0, mode, rel, absv);
+        hipLaunchKernelGGL(k_diag_prepare, dim3(1), dim3(1024), 0, h->stream, fS, fld, Ms, h->d_diag0, mode, rel, absv);
     }
-    // in-place blocked right-looking Cholesky of S[0:Ms,0:Ms] (lower)
-    // Replays a captured launch sequence (hipGraph) for the sizes that recur every IPM iteration; the
-    // sequence is static for a given (kind, Ms), so host launch latency is paid once.
-    template <class F>
-    void run_sequence(int kind, int Ms, bool cacheable, F&& launches) {
-        if (!h->use_graphs || !cacheable) { launches(); return; }
-        auto key = std::make_pair(kind, Ms);
-        auto it = h->graphs.find(key);
-        if (it == h->graphs.end()) {
-            hipGraph_t g = nullptr;
-            hipGraphExec_t ex = nullptr;
-            HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-            launches();
-            HIPCHK(hipStreamEndCapture(h->stream, &g));
-            HIPCHK(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
-            HIPCHK(hipGraphDestroy(g));
-            it = h->graphs.emplace(key, ex).first;
-        }
-        HIPCHK(hipGraphLaunch(it->second, h->stream));
-    }
-
     template <int WB>
     void trtri_launches(int Ms) {
         constexpr int WSUB = WB / ASM_NB;
         const unsigned nW = (unsigned)((Ms + WB - 1) / WB);
-        hipLaunchKernelGGL((k_trtri_init<WB>), dim3(nW, WSUB * WSUB), dim3(256), 0, h->stream, h->d_Linv, Ms, h->d_Binv);
+        hipLaunchKernelGGL((k_trtri_init<WB>), dim3(nW, WSUB * WSUB), dim3(256), 0, h->stream, fLinv, Ms, fBinv);
         for (int hh = 1; hh < WSUB; hh *= 2)
             for (int stage = 0; stage < 2; ++stage)
                 hipLaunchKernelGGL((k_trtri_level<WB>), dim3(nW, (unsigned)(WSUB / (2 * hh)), (unsigned)(hh * hh)), dim3(256), 0, h->stream,
-                                   h->d_S, h->Mp, Ms, h->d_Binv, h->d_BinvT, hh, stage);
-        hipLaunchKernelGGL((k_transpose_wb<WB>), dim3(nW, WSUB * WSUB), dim3(256), 0, h->stream, h->d_Binv, h->d_BinvT);
+                                   fS, fld, Ms, fBinv, fBinvT, hh, stage);
+        hipLaunchKernelGGL((k_transpose_wb<WB>), dim3(nW, WSUB * WSUB), dim3(256), 0, h->stream, fBinv, fBinvT);
     }
     void chol(int Ms, double thr = 1e-14) {
         if (Ms <= 0) return;
         int id = begin(ASM_K_CHOL, (double)Ms * Ms * Ms / 3.0, 8.0 * 1.5 * Ms * (double)Ms);
-        run_sequence(thr == 1e-14 ? 1 : 2, Ms, Ms == (int)h->M, [&] {
-            chol_launches(Ms, thr);
-            // explicit inverses of the wide diagonal blocks by divide and conquer over the 64-wide sub-blocks: diagonal
-            // blocks from k_potrf_diag, then log2 levels of two launches each (the scratch T uses the buffer of the
-            // transposed copy, which is written afterwards)
-            if (h->wb == 1024) trtri_launches<1024>(Ms); else trtri_launches<512>(Ms);
-        });
+        chol_launches(Ms, thr);
+        // explicit inverses of the wide diagonal blocks by divide and conquer over the 64-wide sub-blocks: diagonal
+        // blocks from k_potrf_diag, then log2 levels of two launches each (the scratch T uses the buffer of the
+        // transposed copy, which is written afterwards)
+        if (fwb == 1024) trtri_launches<1024>(Ms); else trtri_launches<512>(Ms);
         end(id);
         h->stats.nfact += 1;
     }
@@ -560,27 +628,27 @@ struct Dev {
                 if (h->panel_epoch == 0) h->panel_epoch = 1;
                 // beside the trailing update the register-capped build must be used (its wavefronts have to fit into freed update slots)
                 if (beside_updates)
-                    hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)G), dim3(256), 0, cur, h->d_S, h->Mp, I0, std::min(I1, Ms), Ms, (const double*)h->d_diag0, thr,
-                                       h->d_Linv, h->d_pflags, h->d_ptmo, h->panel_epoch);
+                    hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)G), dim3(256), 0, cur, fS, fld, I0, std::min(I1, Ms), Ms, (const double*)h->d_diag0, thr,
+                                       fLinv, h->d_pflags, h->d_ptmo, h->panel_epoch);
                 else
-                    hipLaunchKernelGGL(k_chol_panel_solo, dim3((unsigned)G), dim3(256), 0, cur, h->d_S, h->Mp, I0, std::min(I1, Ms), Ms, (const double*)h->d_diag0, thr,
-                                       h->d_Linv, h->d_pflags, h->d_ptmo, h->panel_epoch);
+                    hipLaunchKernelGGL(k_chol_panel_solo, dim3((unsigned)G), dim3(256), 0, cur, fS, fld, I0, std::min(I1, Ms), Ms, (const double*)h->d_diag0, thr,
+                                       fLinv, h->d_pflags, h->d_ptmo, h->panel_epoch);
             } else
             for (int k0 = I0; k0 < I1; k0 += ASM_NB) {
                 int nb = std::min(ASM_NB, Ms - k0);
-                hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, cur, h->d_S, h->Mp, k0, nb, h->d_diag0, thr, h->d_Linv);
+                hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, cur, fS, fld, k0, nb, h->d_diag0, thr, fLinv);
                 int k1 = k0 + nb;
                 if (k1 < Ms) {
                     int rem = Ms - k1;
-                    hipLaunchKernelGGL(k_trsm_panel, dim3((unsigned)((rem + 63) / 64)), dim3(256), 0, cur, h->d_S, h->Mp, k0, nb, Ms, h->d_Linv);
+                    hipLaunchKernelGGL(k_trsm_panel, dim3((unsigned)((rem + 63) / 64)), dim3(256), 0, cur, fS, fld, k0, nb, Ms, fLinv);
                     if (k1 < I1)   // update the remaining columns of this inner panel only (rank 64: dedicated 64 x 64-tile kernel)
                         hipLaunchKernelGGL(k_panel_update64, dim3((unsigned)((rem + 63) / 64), (unsigned)((std::min(I1, Ms) - k1 + 63) / 64)), dim3(256), 0,
-                                           cur, h->d_S, h->Mp, k0, k1, std::min(I1, Ms), Ms);
+                                           cur, fS, fld, k0, k1, std::min(I1, Ms), Ms);
                 }
             }
             if (I1 < K1 && I1 < Ms) {
                 int rem = Ms - I1;
-                launch_syrk(pick_tile(rem), h->d_S + I0, h->Mp, nullptr, I1, rem, I1 - I0, nullptr, nullptr, h->d_S, h->Mp, I1, 1, K1 - I1);
+                launch_syrk(pick_tile(rem), fS + I0, fld, nullptr, I1, rem, I1 - I0, nullptr, nullptr, fS, fld, I1, 1, K1 - I1);
             }
         }
     }
@@ -591,7 +659,7 @@ struct Dev {
         // stream beside (b), so the latency-bound chain hides under the MFMA-bound update.
         const int NBO = CHOL_NBO;
         const int nP = (Ms + NBO - 1) / NBO;
-        const bool la = nP > 2 && !h->use_graphs;
+        const bool la = nP > 2;
         while ((int)h->la_events.size() < 2 * nP + 2) {
             hipEvent_t e;
             HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -606,7 +674,7 @@ struct Dev {
             hipEvent_t e_a = h->la_events[2 * p], e_c = h->la_events[2 * p + 1];
             cur = h->stream;
             // (a) rows >= K1, columns of the next outer panel
-            launch_syrk(pick_tile(rem), h->d_S + K0, h->Mp, nullptr, K1, rem, K1 - K0, nullptr, nullptr, h->d_S, h->Mp, K1, 1, wa);
+            launch_syrk(pick_tile(rem), fS + K0, fld, nullptr, K1, rem, K1 - K0, nullptr, nullptr, fS, fld, K1, 1, wa);
             if (la) {
                 HIPCHK(hipEventRecord(e_a, h->stream));
                 HIPCHK(hipStreamWaitEvent(h->stream2, e_a, 0));
@@ -618,7 +686,7 @@ struct Dev {
             // (b) the rest of the trailing matrix
             const int rem2 = rem - wa;
             if (rem2 > 0)
-                launch_syrk(pick_tile(rem2), h->d_S + K0, h->Mp, nullptr, K1 + wa, rem2, K1 - K0, nullptr, nullptr, h->d_S, h->Mp, K1 + wa, 1);
+                launch_syrk(pick_tile(rem2), fS + K0, fld, nullptr, K1 + wa, rem2, K1 - K0, nullptr, nullptr, fS, fld, K1 + wa, 1);
             if (la) HIPCHK(hipStreamWaitEvent(h->stream, e_c, 0));
             else chol_chain(Ms, thr, K1, std::min(K1 + NBO, Ms));
         }
@@ -628,12 +696,12 @@ struct Dev {
     void chol_solve(const double* rhs, double* out, int Ms) {
         h2d(h->d_vecM2, rhs, Ms, Ms);
         int id = begin(ASM_K_TRSV, 2.0 * Ms * (double)Ms, 8.0 * Ms * (double)Ms);
-        run_sequence(3, Ms, Ms == (int)h->M, [&] { solve_launches(Ms); });
+        solve_launches(Ms);
         end(id);
         d2h(out, h->d_vecM2, Ms);
     }
     void solve_launches(int Ms) {
-        if (h->wb == 1024) solve_launches_wb<1024>(Ms); else solve_launches_wb<512>(Ms);
+        if (fwb == 1024) solve_launches_wb<1024>(Ms); else solve_launches_wb<512>(Ms);
     }
     template <int WB>
     void solve_launches_wb(int Ms) {
@@ -643,10 +711,10 @@ struct Dev {
         const int nB = (Ms + WB - 1) / WB;
         for (int B = 0; B < nB; ++B) {
             int b1 = std::min((B + 1) * WB, Ms);
-            hipLaunchKernelGGL((k_wtrsv_fwd_diag<WB>), dim3(WB / 4), dim3(256), 0, h->stream, h->d_Binv, B, Ms, w, z);
+            hipLaunchKernelGGL((k_wtrsv_fwd_diag<WB>), dim3(WB / 4), dim3(256), 0, h->stream, fBinv, B, Ms, w, z);
             int rem = Ms - b1;
             if (rem > 0)
-                hipLaunchKernelGGL((k_wtrsv_fwd_panel<WB>), dim3((unsigned)((rem + 31) / 32)), dim3(256), 0, h->stream, h->d_S, h->Mp, B, Ms, z, w);
+                hipLaunchKernelGGL((k_wtrsv_fwd_panel<WB>), dim3((unsigned)((rem + 31) / 32)), dim3(256), 0, h->stream, fS, fld, B, Ms, z, w);
         }
         for (int B = nB - 1; B >= 0; --B) {
             int b1 = std::min((B + 1) * WB, Ms);
@@ -654,10 +722,10 @@ struct Dev {
             int np = 0;
             if (rem > 0) {
                 np = (rem + ASM_WBROWS - 1) / ASM_WBROWS;
-                hipLaunchKernelGGL((k_wtrsv_bwd_panel<WB>), dim3((unsigned)np), dim3(256), 0, h->stream, h->d_S, h->Mp, B, Ms, w, h->d_wpart);
+                hipLaunchKernelGGL((k_wtrsv_bwd_panel<WB>), dim3((unsigned)np), dim3(256), 0, h->stream, fS, fld, B, Ms, w, h->d_wpart);
             }
             hipLaunchKernelGGL((k_wtrsv_bwd_reduce<WB>), dim3(WB / ASM_NB), dim3(256), 0, h->stream, B, Ms, z, h->d_wpart, np, h->d_wt);
-            hipLaunchKernelGGL((k_wtrsv_bwd_diag<WB>), dim3(WB / 4), dim3(256), 0, h->stream, h->d_BinvT, B, Ms, h->d_wt, w);
+            hipLaunchKernelGGL((k_wtrsv_bwd_diag<WB>), dim3(WB / 4), dim3(256), 0, h->stream, fBinvT, B, Ms, h->d_wt, w);
         }
     }
     void assemble() {
@@ -748,6 +816,8 @@ struct Solver {
         int col_iters = 0;
         bool red_ok = false, red_off = false;     // reduced row form (normal phase, large sparse problems)
         int red_iters = 0;
+        bool ns_ok = false, ns_off = false, ns_ready = false;   // null-space form (normal phase, many hard equality rows)
+        int ns_iters = 0, ns_k = 0;
         int iters = 0;
         int status = ASM_OTHER;
         double mu = 0, pinf = 0, dinf = 0, gap = 0, ymax = 0, rpmax = 0;
@@ -837,6 +907,11 @@ struct Solver {
         for (int64_t j = 0; j < n; ++j) nfree += lp.ub[j] > lp.lb[j];
         ip.ncomp = std::max<int64_t>(2 * nfree + lp.ns + nineq, 1);
         ip.red_ok = M >= RED_MIN_M && h->sp_ok;
+        {
+            int64_t nE = 0;
+            for (int64_t i = 0; i < M; ++i) nE += lp.rtype[i] == 0;
+            ip.ns_ok = h->ns_cap && lp.ns == 0 && nE >= NS_MIN_E && (double)(nfree - nE) <= NS_MAX_RATIO * (double)M;
+        }
         ip.col_ok = h->col_capable && lp.ns > 0 && M >= COL_MIN_M && (double)n <= COL_MAX_RATIO * (double)M;   // every row owns a slack (setup)
         ipm_upload_lp();
         P.ncomp = ip.ncomp;
@@ -888,6 +963,215 @@ struct Solver {
         for (int64_t j = 0; j < lp.n; ++j) lhs += std::max(rho[j] * lp.lb[j], rho[j] * lp.ub[j]);
         for (int64_t i = 0; i < lp.M; ++i) ynr += yn[i] * lp.r[i];
         return ynr - lhs;
+    }
+
+    // ------------------------------------------------------------ null-space form (oracle: class NullSpace / IPM.run use_ns)
+    bool use_ns = false, ns_was_cold = false;
+    SolveHint* cur_hint = nullptr;
+    NsIdx nsX() const { NsIdx X; X.Eidx = h->d_nsEidx; X.Epos = h->d_nsEpos; X.Iidx = h->d_nsIidx; X.Ipos = h->d_nsIpos; X.nE = h->ns_nE; X.nI = h->ns_nI; return X; }
+    int ns_read_cnt() {
+        int v = 0;
+        HIPCHK(hipMemcpyAsync(&v, h->d_nscnt, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return v;
+    }
+    // buffers sized by the null-space dimension: right-hand-side blocks R, X (k x nEp), Gt = [Zt | GI'] (k x ldg), the k x k factor
+    void ns_reserve(int k) {
+        if (k <= h->ns_kcap) return;
+        if (h->ns_kcap > 0) throw HipError("null-space form: dimension grew beyond the reserved buffers");      // (caller falls back; see ns_setup)
+        const int cap = (int)round_up(k + k / 4 + 64, 64);
+        h->d_nsR = ns_dalloc(h, (int64_t)cap * h->ns_nEp);
+        h->d_nsX = ns_dalloc(h, (int64_t)cap * h->ns_nEp);
+        h->d_nsG = ns_dalloc(h, (int64_t)cap * h->ns_ldg);
+        ns_alloc_factor(h, h->ns_fN, cap);
+        h->d_nsN0 = ns_dalloc(h, h->ns_fN.ld * h->ns_fN.ld);
+        int* dj = nullptr;
+        dmalloc(&dj, cap);
+        h->ns_bufs.push_back((void*)dj);
+        h->d_nsJ = dj;
+        h->ns_kcap = cap;
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    // Orthonormal basis from the columns J of the projector P (oracle: NullSpace.basis_from): W = S0^-1 A_EF[:, J] by block
+    // substitution with all k right-hand sides at once, P[J, :] = E_J' - W' A_EF, L_J L_J' = P[J, J] (guard: pivot <= NS_WARM_THR
+    // -> not a basis), Zt = L_J^-1 P[J, :], GI' = (A_I Z)'.  The factor of S0 must be current in h->ns_f0.
+    bool ns_basis_from(const std::vector<int>& J) {
+        const int k = (int)J.size(), nE = h->ns_nE;
+        const NsIdx X = nsX();
+        const double* vals = dev.sparse_vals(h->d_Ah);
+        HIPCHK(hipMemcpyAsync(h->d_nsJ, J.data(), k * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        hipLaunchKernelGGL(k_ns_rhs_cols, dim3((unsigned)k), dim3(256), 0, h->stream, h->d_sc_ptr, h->d_sc_row, h->d_sc_pos, vals, X, (const int*)h->d_nsJ,
+                           (const double*)h->d_nsFm, h->d_nsR, (int64_t)h->ns_nEp);
+        dev.use_factor(h->ns_f0);
+        dev.trsm_rows(h->d_nsR, h->d_nsX, h->ns_nEp, k, nE, h->d_nsLt);
+        hipLaunchKernelGGL(k_ns_pj, dim3((unsigned)((h->ldn + 255) / 256), (unsigned)k), dim3(256), 0, h->stream, h->d_sc_ptr, h->d_sc_row, h->d_sc_pos, vals, X,
+                           (const int*)h->d_nsJ, (const double*)h->d_nsFm, (const double*)h->d_nsR, (int64_t)h->ns_nEp, h->d_nsG, h->ns_ldg, lp.n, h->ldn);
+        dev.use_factor(h->ns_fN);
+        hipLaunchKernelGGL(k_ns_gather_t, dim3((unsigned)((k + 255) / 256), (unsigned)k), dim3(256), 0, h->stream, (const double*)h->d_nsG, h->ns_ldg, (const int*)h->d_nsJ, k,
+                           h->ns_fN.S, h->ns_fN.ld);
+        hipLaunchKernelGGL(k_ns_fill, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, h->stream, h->d_diag0, 1.0, (int64_t)k);
+        dev.chol(k, NS_WARM_THR);
+        hipLaunchKernelGGL(k_ns_count_big, dim3(1), dim3(1024), 0, h->stream, (const double*)h->ns_fN.S, h->ns_fN.ld, k, NS_BIG, h->d_nscnt);
+        const int bad = ns_read_cnt();
+        dev.use_main();
+        if (bad > 0) return false;
+        hipLaunchKernelGGL(k_ns_ortho, dim3((unsigned)((h->ldn + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->ns_fN.S, h->ns_fN.ld, k, h->d_nsG, h->ns_ldg, h->ldn);
+        hipLaunchKernelGGL(k_ns_gi, dim3((unsigned)((h->ns_nIp + 255) / 256), (unsigned)k), dim3(256), 0, h->stream, h->d_sp_ptr, h->d_sp_col, vals, X,
+                           (const double*)h->d_nsG, h->ns_ldg, h->d_nsG + h->ldn, h->ns_nIp);
+        return true;
+    }
+    // Per LP (oracle: NullSpace.__init__): factor S0, null-space dimension, basis columns (retained ones, else a guarded Cholesky of
+    // P in index order), orthonormal basis.  False: the LP keeps the row form.
+    bool ns_setup() {
+        const int nE = h->ns_nE;
+        const int64_t n = lp.n;
+        const NsIdx X = nsX();
+        int64_t nF = 0;
+        for (int64_t j = 0; j < n; ++j) nF += lp.ub[j] > lp.lb[j];
+        {
+            vec fm(h->ldn, 0.0);
+            for (int64_t j = 0; j < n; ++j) fm[j] = lp.ub[j] > lp.lb[j] ? 1.0 : 0.0;
+            HIPCHK(hipMemcpyAsync(h->d_nsFm, fm.data(), h->ldn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
+        dev.use_factor(h->ns_f0);
+        dev.syrk_gathered_into(h->d_nsEidx, nE, h->d_nsFm, h->ns_f0.S, h->ns_f0.ld);
+        dev.diag_prepare(nE, 1, 0.0, 0.0);
+        dev.chol(nE, 1e-10);
+        hipLaunchKernelGGL(k_ns_count_big, dim3(1), dim3(1024), 0, h->stream, (const double*)h->ns_f0.S, h->ns_f0.ld, nE, NS_BIG, h->d_nscnt);
+        const int dropped = ns_read_cnt();
+        dev.use_main();
+        const int64_t k = nF - (nE - dropped);
+        if (k < 1 || (double)k > 1.5 * NS_MAX_RATIO * (double)lp.M + 8.0) return false;
+        if (k > h->ns_kcap && h->ns_kcap > 0) return false;
+        ns_reserve((int)k);
+        hipLaunchKernelGGL(k_transpose_dense, dim3((unsigned)((nE + 63) / 64), (unsigned)((nE + 63) / 64)), dim3(256), 0, h->stream, (const double*)h->ns_f0.S, h->ns_f0.ld,
+                           (int64_t)nE, (int64_t)nE, h->d_nsLt, h->ns_f0.ld);
+        std::vector<int>& J = cur_hint->ns_J;
+        bool have = false;
+        ns_was_cold = false;
+        if ((int64_t)J.size() == k) {
+            bool free_all = true;
+            for (int j : J) free_all = free_all && j >= 0 && j < n && lp.ub[j] > lp.lb[j];
+            if (free_all) have = ns_basis_from(J);
+        }
+        if (!have) {
+            ns_was_cold = true;
+            // cold selection: Y = L0^-1 A_EF for ALL columns (forward substitution only), T = I_F - Y'Y in the main matrix buffer,
+            // guarded Cholesky of T in index order with the absolute thresholds NS_SEL_THR in turn until exactly k columns are kept
+            if (!h->d_nsYt) h->d_nsYt = ns_dalloc(h, (int64_t)h->ldn * h->ns_nEp + (int64_t)h->ldn * h->ns_nEp);
+            double* Yr = h->d_nsYt;                                  // right-hand sides, then garbage
+            double* Yt = h->d_nsYt + (int64_t)h->ldn * h->ns_nEp;   // L0^-1 a_j as rows
+            const double* vals = dev.sparse_vals(h->d_Ah);
+            hipLaunchKernelGGL(k_ns_rhs_cols, dim3((unsigned)n), dim3(256), 0, h->stream, h->d_sc_ptr, h->d_sc_row, h->d_sc_pos, vals, X, (const int*)nullptr,
+                               (const double*)h->d_nsFm, Yr, (int64_t)h->ns_nEp);
+            dev.use_factor(h->ns_f0);
+            dev.trsm_rows(Yr, Yt, h->ns_nEp, (int)n, nE, nullptr);
+            dev.use_main();
+            std::vector<double> dg(n);
+            for (int a = 0; a < 4 && !have; ++a) {
+                hipLaunchKernelGGL(k_ns_set_diag, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, h->stream, h->d_S, h->Mp, (int)n, (const double*)h->d_nsFm);
+                dev.launch_syrk(Dev::pick_tile(n), Yt, h->ns_nEp, nullptr, 0, (int)n, h->ns_nEp, nullptr, nullptr, h->d_S, h->Mp, 0, 1);
+                hipLaunchKernelGGL(k_ns_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_diag0, 1.0, n);
+                dev.chol((int)n, NS_SEL_THR[a]);
+                hipLaunchKernelGGL(k_ns_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->d_S, h->Mp, (int)n, h->d_vecN);
+                HIPCHK(hipMemcpyAsync(dg.data(), h->d_vecN, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipStreamSynchronize(h->stream));
+                std::vector<int> Jc;
+                for (int64_t j = 0; j < n; ++j)
+                    if (dg[j] < NS_BIG) Jc.push_back((int)j);
+                if ((int64_t)Jc.size() != k) continue;
+                if (ns_basis_from(Jc)) { J = Jc; have = true; }
+            }
+        }
+        if (!have) { J.clear(); return false; }
+        ip.ns_k = (int)k;
+        return true;
+    }
+    double* nsv(int which) const {      // work vectors: 0..4 n-sized, 5..7 M-sized, 8..9 E-sized, 10..13 k-sized (k <= n)
+        if (which < 5) return h->d_nsv + (int64_t)which * h->ldn;
+        if (which < 8) return h->d_nsv + 5 * h->ldn + (int64_t)(which - 5) * h->Mp;
+        if (which < 10) return h->d_nsv + 5 * h->ldn + 3 * h->Mp + (int64_t)(which - 8) * h->ns_nEp;
+        return h->d_nsv + 5 * h->ldn + 3 * h->Mp + 2 * h->ns_nEp + (int64_t)(which - 10) * h->ldn;
+    }
+    // Per iteration (oracle: IPM.run, use_ns branch): reduced matrix N = Zt Th Zt' + GI' D_I^-1 GI (an unregularised copy is kept for the
+    // refinement sweep), its factor, dpbar = A_EF' S0^-1 (-rp_E) and K dpbar (shared by predictor and corrector)
+    void ns_iter_setup() {
+        const int k = ip.ns_k, nE = h->ns_nE;
+        const int64_t M = lp.M, ldn = h->ldn;
+        const NsIdx X = nsX();
+        const unsigned gM = (unsigned)((M + 255) / 256), gN = (unsigned)((ldn + 255) / 256), gE = (unsigned)((nE + 255) / 256);
+        double *dpb = nsv(0), *kdpb = nsv(1), *atw = nsv(4), *yM = nsv(5), *aM = nsv(6), *rE = nsv(8), *tE = nsv(9);
+        const double* th = h->d_nsth;
+        const double* thI = h->d_nsth + ldn;
+        hipLaunchKernelGGL(k_ns_theta, dim3((unsigned)((std::max<int64_t>(ldn, h->ns_nIp) + 255) / 256)), dim3(256), 0, h->stream, P, X, IPM_RHO_P, h->d_nsth, ldn, h->ns_nIp);
+        dev.use_factor(h->ns_fN);
+        int id = dev.begin(ASM_K_SYRK, (double)k * (k + 1) * h->ns_ldg, 8.0 * (k * (double)h->ns_ldg + 0.5 * k * (double)k));
+        dev.launch_syrk(Dev::pick_tile(k), h->d_nsG, h->ns_ldg, nullptr, 0, k, (int)h->ns_ldg, h->d_nsth, nullptr, h->ns_fN.S, h->ns_fN.ld, 0, 0);
+        dev.end(id);
+        hipLaunchKernelGGL(k_ns_copy_lower, dim3((unsigned)((k + 255) / 256), (unsigned)k), dim3(256), 0, h->stream, (const double*)h->ns_fN.S, h->ns_fN.ld, h->d_nsN0, h->ns_fN.ld, k);
+        dev.diag_prepare(k, 0, 1e-13, 1e-30);
+        dev.chol(k);
+        hipLaunchKernelGGL(k_ns_gather_e, dim3(gE), dim3(256), 0, h->stream, X, (const double*)P.rp, -1.0, rE);
+        dev.use_factor(h->ns_f0);
+        dev.chol_solve_dev(rE, tE, nE);
+        dev.use_main();
+        hipLaunchKernelGGL(k_ns_rowvec_e, dim3(gM), dim3(256), 0, h->stream, X, (const double*)tE, yM, M);
+        dev.gemv_t_dev(h->d_Ah, yM, dpb);
+        hipLaunchKernelGGL(k_ns_mask, dim3(gN), dim3(256), 0, h->stream, dpb, th, ldn);
+        dev.gemv_n_dev(h->d_Ah, dpb, aM);
+        hipLaunchKernelGGL(k_ns_wm, dim3(gM), dim3(256), 0, h->stream, X, thI, (const double*)aM, yM, M);
+        dev.gemv_t_dev(h->d_Ah, yM, atw);
+        hipLaunchKernelGGL(k_ns_kx, dim3(gN), dim3(256), 0, h->stream, th, (const double*)dpb, (const double*)atw, (const double*)nullptr, kdpb, ldn);
+    }
+    // One Newton solve in null-space form (oracle: IPM.run, solve_ns): mode 0 affine, 1 Mehrotra corrector on `base`.  want_dy: recover the
+    // multipliers of the equality rows (one solve with the factor of S0) and record the dual-equation error of the step in SC_NSERR.
+    void ns_newton(int mode, const IpmDir& base, IpmDir& D, bool want_dy) {
+        const int k = ip.ns_k, nE = h->ns_nE;
+        const int64_t M = lp.M, n = lp.n, ldn = h->ldn;
+        const NsIdx X = nsX();
+        const unsigned g = grid_all(), gM = (unsigned)((M + 255) / 256), gN = (unsigned)((ldn + 255) / 256), gE = (unsigned)((nE + 255) / 256), gK = (unsigned)((k + 255) / 256);
+        double *dpb = nsv(0), *kdpb = nsv(1), *ht = nsv(2), *v = nsv(3), *atw = nsv(4), *yM = nsv(5), *aM = nsv(6), *bI = nsv(7), *rE = nsv(8), *tE = nsv(9);
+        double *ru = nsv(10), *du = nsv(11), *rr = nsv(12), *dd = nsv(13);
+        const double* th = h->d_nsth;
+        const double* thI = h->d_nsth + ldn;
+        const double res = 1.0;
+        hipLaunchKernelGGL(k_ipm_rhs1, dim3(g), dim3(256), 0, h->stream, P, base, mode, 0.0, 0.0, MCC_BMIN, MCC_BMAX);
+        hipLaunchKernelGGL(k_ns_bi, dim3(gM), dim3(256), 0, h->stream, P, X, thI, res, bI, yM);
+        dev.gemv_t_dev(h->d_Ah, yM, atw);
+        hipLaunchKernelGGL(k_ns_ht, dim3(gN), dim3(256), 0, h->stream, th, (const double*)P.hp, (const double*)atw, (const double*)kdpb, res, ht, v, n, ldn);
+        hipLaunchKernelGGL(k_gemv_n, dim3((unsigned)((k + 3) / 4)), dim3(256), 0, h->stream, (const double*)h->d_nsG, h->ns_ldg, (const double*)v, ru, (int64_t)k, ldn);
+        dev.use_factor(h->ns_fN);
+        dev.chol_solve_dev(ru, du, k);
+        hipLaunchKernelGGL(k_ns_symv_res, dim3((unsigned)((k + 3) / 4)), dim3(256), 0, h->stream, (const double*)h->d_nsN0, h->ns_fN.ld, k, (const double*)du, (const double*)ru, rr);
+        dev.chol_solve_dev(rr, dd, k);
+        dev.use_main();
+        hipLaunchKernelGGL(k_ns_add, dim3(gK), dim3(256), 0, h->stream, (const double*)du, (const double*)dd, du, (int64_t)k);
+        ns_gemv_t_dense(du, k, v);
+        hipLaunchKernelGGL(k_ns_dp, dim3(gN), dim3(256), 0, h->stream, P, D, th, (const double*)dpb, res, (const double*)v, ldn);
+        dev.gemv_n_dev(h->d_Ah, D.dp, aM);
+        hipLaunchKernelGGL(k_ns_rows, dim3(gM), dim3(256), 0, h->stream, P, D, X, thI, (const double*)bI, (const double*)aM, yM);
+        if (!want_dy) return;
+        dev.gemv_t_dev(h->d_Ah, yM, atw);
+        hipLaunchKernelGGL(k_ns_kx, dim3(gN), dim3(256), 0, h->stream, th, (const double*)D.dp, (const double*)atw, (const double*)ht, v, ldn);
+        dev.gemv_n_dev(h->d_Ah, v, aM);
+        hipLaunchKernelGGL(k_ns_gather_e, dim3(gE), dim3(256), 0, h->stream, X, (const double*)aM, 1.0, rE);
+        dev.use_factor(h->ns_f0);
+        dev.chol_solve_dev(rE, tE, nE);
+        dev.use_main();
+        hipLaunchKernelGGL(k_ns_scatter_e, dim3(gE), dim3(256), 0, h->stream, X, (const double*)tE, D.dy);
+        dev.gemv_t_dev(h->d_Ah, D.dy, atw);
+        hipLaunchKernelGGL(k_ns_err, dim3(1), dim3(1024), 0, h->stream, th, (const double*)D.dp, (const double*)atw, (const double*)P.hp, n, P.scal + SC_NSERR);
+    }
+    // out[n] = Zt' u   (Zt dense, k rows of pitch ldg)
+    void ns_gemv_t_dense(const double* u, int k, double* out) {
+        int64_t R = std::min<int64_t>((k + 31) / 32, ASM_TMAXCHUNKS);
+        int64_t chunk = (k + R - 1) / R;
+        R = (k + chunk - 1) / chunk;
+        hipLaunchKernelGGL(k_gemv_t_stage1, dim3((unsigned)((h->ldn + 255) / 256), (unsigned)R), dim3(256), 0, h->stream, (const double*)h->d_nsG, h->ns_ldg, u,
+                           h->d_partial, (int64_t)k, h->ldn, chunk);
+        hipLaunchKernelGGL(k_gemv_t_stage2, dim3((unsigned)((h->ldn + 255) / 256)), dim3(256), 0, h->stream, h->d_partial, out, R, h->ldn);
     }
 
     bool use_red = false;     // reduced row form: factor of the rows redE, diagonal on the rows redI
@@ -983,8 +1267,26 @@ struct Solver {
             // column form (oracle: IPM.run): K = Th + Ah' D^-1 Ah (n x n) while its Sherman-Morrison-Woodbury preconditioner
             // keeps the CG short, the row form S = Ah Th^-1 Ah' + D (M x M) otherwise
             use_red = false;
-            use_col = ip.col_ok && !ip.col_off;
-            if (use_col) {
+            // null-space form (oracle: IPM.run): set up once per LP, k x k factorisation per iteration
+            use_ns = false;
+            if (ip.ns_ok && !ip.ns_off) {
+                if (!ip.ns_ready) {
+                    ip.ns_ready = true;
+                    const size_t had = cur_hint ? cur_hint->ns_J.size() : 0;
+                    const double t0 = now_ms();
+                    const bool okn = cur_hint && ns_setup();
+                    if (!okn) ip.ns_off = true;
+                    h->stats.ns_dim = okn ? ip.ns_k : 0;
+                    h->stats.ns_cold = (okn && (had == 0 || ns_was_cold)) ? 1 : 0;
+                    if (h->verbose) std::fprintf(stderr, "[asm] null-space set-up: %s, k = %d, %s basis columns, %.2f ms\n", okn ? "ok" : "not usable", ip.ns_k, ns_was_cold ? "fresh" : "retained", now_ms() - t0);
+                }
+                use_ns = !ip.ns_off;
+            }
+            use_col = !use_ns && ip.col_ok && !ip.col_off;
+            if (use_ns) {
+                ip.ns_iters += 1;
+                ns_iter_setup();
+            } else if (use_col) {
                 ip.col_iters += 1;
                 hipLaunchKernelGGL(k_ipm_col_prep, dim3(grid_all()), dim3(256), 0, h->stream, P, IPM_RHO_P, COL_FIXED, h->d_cdinv, h->d_cth);
                 dev.syrk_col(h->d_cdinv, h->d_cth);
@@ -1029,16 +1331,16 @@ struct Solver {
             done += 1;
             cg_max = 0;
             cg_fail = false;
-            ipm_solve(0, dirA, dirA);
+            if (use_ns) ns_newton(0, dirA, dirA, false); else ipm_solve(0, dirA, dirA);
             hipLaunchKernelGGL(k_ipm_steps, dim3(1), dim3(1024), 0, h->stream, P, dirA, 0u);
             hipLaunchKernelGGL(k_ipm_muaff, dim3(1), dim3(1024), 0, h->stream, P, dirA);
-            ipm_solve(1, dirA, dirC);
+            if (use_ns) ns_newton(1, dirA, dirC, true); else ipm_solve(1, dirA, dirC);
             unsigned pub = pub_next();
             hipLaunchKernelGGL(k_ipm_steps, dim3(1), dim3(1024), 0, h->stream, P, dirC, pub);
             read_scal(pub);
             double ap = h->h_scal[SC_AP], ad = h->h_scal[SC_AD];
             // Gondzio multiple centrality correctors (oracle: IPM.run): dirA is free again and receives the candidate
-            for (int kc = 0; kc < IPM_MCC; ++kc) {
+            for (int kc = 0; kc < (use_ns ? 0 : IPM_MCC); ++kc) {      // (no correctors in null-space form: a Newton solve costs more than the factorisation there)
                     if (std::min(ap, ad) >= 0.9) break;
                 const double tp = std::min(1.0, ap + MCC_DELTA), td = std::min(1.0, ad + MCC_DELTA);
                 ipm_solve(2, dirC, dirA, tp, td);
@@ -1052,6 +1354,10 @@ struct Solver {
                 ap = ap2; ad = ad2;
             }
             if (h->verbose) std::fprintf(stderr, "[asm]     ap %.3e ad %.3e  cg steps so far %lld\n", ap, ad, (long long)h->stats_pcg);
+            if (use_ns && h->h_scal[SC_NSERR] / lp.scale_q > NS_DERR * std::max(tol, ip.dinf)) {
+                ip.ns_off = true;          // the reduced system lost its accuracy: redo the iteration in row form (oracle: IPM.run)
+                continue;
+            }
             if (use_col && cg_fail) {      // column-form preconditioner lost its accuracy: redo this iteration in row form (oracle: IPM.run)
                 ip.col_off = true;
                 continue;
@@ -1467,6 +1773,7 @@ struct Solver {
         const int64_t n = lp.n, M = lp.M, ns = lp.ns;
         h->stats.path = -1;
         h->stats.polished = 1;
+        cur_hint = &hint;
         ipm_upload_lp();
         as_begin_lp();
         if (warm && warm->valid && (int64_t)warm->rowst.size() == M && (int64_t)warm->bst.size() == n && (int64_t)warm->sst.size() == ns) {
@@ -1495,6 +1802,7 @@ struct Solver {
             t_ipm += now_ms() - t0;
             h->stats.ipm_iters = ip.iters;
             h->stats.col_iters = ip.col_iters;
+            h->stats.ns_iters = ip.ns_iters;
             h->stats.ipm_pinf = ip.pinf; h->stats.ipm_dinf = ip.dinf; h->stats.ipm_gap = ip.gap;
             if (st == ASM_INFEASIBLE) { h->stats.path = 6; return ASM_INFEASIBLE; }
             if (st == ASM_OTHER && stage == 0) {
@@ -1575,8 +1883,6 @@ int row_kind(double lb, double ub) {
 }
 
 void free_device(asm_handle* h) {
-    for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
-    h->graphs.clear();
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(h->d_perm); F(h->d_ustart); F(h->d_uoff); F(h->d_adjoff);
     F(h->d_dE); F(h->d_J); F(h->d_Ah); F(h->d_S); F(h->d_c); F(h->d_rho); F(h->d_theta); F(h->d_diag); F(h->d_diag0);
@@ -1597,6 +1903,12 @@ void free_device(asm_handle* h) {
     h->d_ipm = nullptr; h->d_ipm_i = nullptr; h->h_scal = nullptr; h->h_seq = nullptr; h->d_hscal = nullptr; h->d_hseq = nullptr;
     F(h->d_pflags); F(h->d_ptmo);
     h->d_pflags = h->d_ptmo = nullptr;
+    for (void* q : h->ns_bufs) F(q);
+    h->ns_bufs.clear();
+    h->ns_cap = false; h->ns_kcap = 0;
+    h->d_nsEidx = h->d_nsEpos = h->d_nsIidx = h->d_nsIpos = h->d_nsJ = h->d_nscnt = nullptr;
+    h->ns_f0 = FacBuf(); h->ns_fN = FacBuf();
+    h->d_nsLt = h->d_nsR = h->d_nsX = h->d_nsG = h->d_nsth = h->d_nsFm = h->d_nsv = h->d_nsYt = h->d_nsN0 = nullptr;
     F(h->d_as); F(h->d_as_i);
     if (h->h_ascnt) (void)hipHostFree(h->h_ascnt);
     if (h->h_asscal) (void)hipHostFree(h->h_asscal);
@@ -1624,11 +1936,6 @@ void check_panel_timeout(asm_handle* h) {
     unsigned tmo = 0;
     HIPCHK(hipMemcpy(&tmo, h->d_ptmo, sizeof(unsigned), hipMemcpyDeviceToHost));
     if (tmo != 0) throw HipError("k_chol_panel: a workgroup timed out waiting for a producer (grid not resident?)");
-}
-
-template <class T>
-void dmalloc(T** p, int64_t count) {
-    HIPCHK(hipMalloc((void**)p, std::max<int64_t>(count, 1) * sizeof(T)));
 }
 
 void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j_row, const int64_t* j_col, const double* c_lb,
@@ -1766,8 +2073,8 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     }
     dmalloc(&h->d_Binv, (h->Mp / h->wb + 1) * (int64_t)h->wb * h->wb);
     dmalloc(&h->d_BinvT, (h->Mp / h->wb + 1) * (int64_t)h->wb * h->wb);
-    dmalloc(&h->d_wpart, (h->Mp / ASM_WBROWS + 2) * (int64_t)h->wb);
-    dmalloc(&h->d_wt, h->wb);
+    dmalloc(&h->d_wpart, (h->Mp / ASM_WBROWS + 2) * (int64_t)1024);
+    dmalloc(&h->d_wt, 1024);
     h->nz_half = (h->Mp / 32 + 1) * (h->ldn / ASM_KC + 1);
     dmalloc(&h->d_nz, 2 * h->nz_half);
     if (h->sp_nnz > 0) {
@@ -1814,6 +2121,38 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
         dmalloc(&h->d_nsu, FACE_STEPS + 8);
         dmalloc(&h->d_nsdots, FACE_STEPS + 8);
         HIPCHK(hipHostMalloc((void**)&h->h_nsdots, (FACE_STEPS + 8) * sizeof(double)));
+    }
+    // null-space form of the normal-phase Newton system: static part (index lists, factor of S0, work vectors); the buffers
+    // sized by the null-space dimension k are allocated by the first LP that uses the form (Solver::ns_reserve)
+    {
+        int nE = 0;
+        for (int64_t i = 0; i < h->M; ++i) nE += h->rtype[i] == 0;
+        h->ns_cap = h->sp_ok && nE >= NS_MIN_E && (double)(n - nE) <= NS_MAX_RATIO * (double)h->M && n <= h->Mp && h->M < (int64_t)1 << 30;
+        if (h->ns_cap) {
+            h->ns_nE = nE; h->ns_nI = (int)(h->M - nE);
+            h->ns_nEp = (int)round_up(nE, 32); h->ns_nIp = (int)round_up(std::max(h->ns_nI, 1), 32);
+            h->ns_ldg = h->ldn + h->ns_nIp;
+            std::vector<int> eidx, epos(h->M, -1), iidx, ipos(h->M, -1);
+            for (int64_t i = 0; i < h->M; ++i) {
+                if (h->rtype[i] == 0) { epos[i] = (int)eidx.size(); eidx.push_back((int)i); }
+                else { ipos[i] = (int)iidx.size(); iidx.push_back((int)i); }
+            }
+            auto ialloc = [&](const std::vector<int>& v, int64_t cnt) {
+                int* d = nullptr;
+                dmalloc(&d, cnt);
+                h->ns_bufs.push_back((void*)d);
+                HIPCHK(hipMemset(d, 0, std::max<int64_t>(cnt, 1) * sizeof(int)));
+                if (!v.empty()) HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
+                return d;
+            };
+            h->d_nsEidx = ialloc(eidx, nE); h->d_nsEpos = ialloc(epos, h->M); h->d_nsIidx = ialloc(iidx, h->ns_nI); h->d_nsIpos = ialloc(ipos, h->M);
+            h->d_nscnt = ialloc({}, 16);
+            ns_alloc_factor(h, h->ns_f0, h->ns_nEp);
+            h->d_nsLt = ns_dalloc(h, (int64_t)h->ns_nEp * h->ns_nEp);
+            h->d_nsth = ns_dalloc(h, h->ns_ldg);
+            h->d_nsFm = ns_dalloc(h, h->ldn);
+            h->d_nsv = ns_dalloc(h, 9 * h->ldn + 3 * h->Mp + 2 * h->ns_nEp);
+        }
     }
     h->pin_len = std::max(std::max(h->ldn, h->Mp), h->nsp);
     HIPCHK(hipHostMalloc((void**)&h->h_pin, 2 * h->pin_len * sizeof(double)));
@@ -2114,8 +2453,6 @@ int asm_create(int device, asm_handle** out) {
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 16) { h->num_cus = prop.multiProcessorCount; h->panel_wgs = 2 * prop.multiProcessorCount - 32; }
         if (const char* pw = std::getenv("ASM_PANEL_WGS")) h->panel_wgs = std::max(1, std::atoi(pw));
     }
-    const char* gr = std::getenv("ASM_HIP_GRAPHS");
-    h->use_graphs = gr && gr[0] == '1';      // opt-in: no measured gain on this ROCm build, and rocprofv3 crashes on captured streams
     *out = h;
     return ASM_OK;
 }

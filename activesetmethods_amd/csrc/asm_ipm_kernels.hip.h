@@ -23,7 +23,7 @@ struct IpmPtrs {
 struct IpmDir {
     double *dp, *ds, *dg, *dy, *dmuL, *dmuU, *dmus, *dpi;
 };
-enum { SC_PINF = 0, SC_DINF, SC_MU, SC_YMAX, SC_AP, SC_AD, SC_SM, SC_EMAX, SC_RMAX, SC_RZ, SC_RPMAX, SC_RZ0, SC_STOP, SC_COUNT };
+enum { SC_PINF = 0, SC_DINF, SC_MU, SC_YMAX, SC_AP, SC_AD, SC_SM, SC_EMAX, SC_RMAX, SC_RZ, SC_RPMAX, SC_RZ0, SC_STOP, SC_NSERR, SC_COUNT };   // SC_NSERR: dual-equation error of a null-space Newton step
 
 // Hand the scalar block to the host without a copy command or a stream synchronisation: the single workgroup that has just written
 // P.scal stores the block into host-mapped memory, fences at system scope and sets the sequence word the host is spinning on

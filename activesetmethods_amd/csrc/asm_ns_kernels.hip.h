@@ -1,0 +1,370 @@
+// Null-space (equality-elimination) form of the interior-point Newton system - oracle/lp_solver.py: class NullSpace and the
+// `use_ns` branch of IPM.run.  Normal-phase LPs of the ACOPF configurations carry ~n hard equality rows E (case1354pegase-sized:
+// 10.7k of them for n = 11.2k variables): Newton steps live in  p = pbar + Z u  with Z an orthonormal basis of null(A_EF)
+// (dimension k ~ 500), so the matrix factored in every interior-point iteration is k x k instead of M x M.  Per LP:
+//   S0 = A_EF A_EF'  (existing Schur-build + Cholesky kernels), W = S0^-1 A_EF[:, J] for the k retained basis columns J
+//   (multi-right-hand-side triangular solves = k_gemm_nt on the matrix cores against the explicit inverses of the wide
+//   diagonal blocks), P[J, :] = E_J' - W' A_EF (k_ns_pj), L_J L_J' = P[J, J], Zt = L_J^-1 P[J, :] (k_ns_ortho), GI' = (A_I Z)'.
+// Vector layouts: Zt and GI' share one buffer Gt (k rows, pitch ldg = ldn + nIp) so that N = Gt diag(theta~) Gt' is one
+// rank-K launch of the existing k_syrk.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ---------------------------------------------------------------------------------------------------
+// C[a,b] = (C0 ? C0[a,b] : 0) -/+ sum_k A[a,k] B[b,k]      a < Ma, b < Mb, K a multiple of 32 (operands zero-padded along k)
+//   mode 0:  C  = A B'          mode 1:  C = C0 - A B'   (C0 may alias C: every tile is read and written by one workgroup)
+// 64 x 64 tile per 256-thread workgroup (four wavefronts as 2 x 2, each 32 x 32 = 2 x 2 MFMA tiles of 16 x 16), 32-deep k-chunks
+// double-buffered in LDS through registers - the generic k_syrk<2, 4, 32, 1> with two operand matrices and a full rectangle.
+// Used by the multi-right-hand-side triangular solves (rows of A = right-hand sides, rows of B = rows of the factor / of the
+// explicit inverse of a wide diagonal block).
+__global__ __launch_bounds__(256) void k_gemm_nt(const double* __restrict__ A, int64_t lda, const double* __restrict__ B, int64_t ldb,
+                                                 const double* C0, int64_t ldc0, double* C, int64_t ldc, int Ma, int Mb, int K, int mode) {
+    constexpr int TS = 64, KC = 32, PITCH = KC + 2;
+    __shared__ __attribute__((aligned(16))) double As[2][TS * PITCH];
+    __shared__ __attribute__((aligned(16))) double Bs[2][TS * PITCH];
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    v4f64 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+            if (mode != 0 && C0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = bi * TS + wr * 32 + i * 16 + (lane >> 4) + 4 * r;
+                    const int col = bj * TS + wc * 32 + j * 16 + (lane & 15);
+                    const double v = C0[(int64_t)min(row, Ma - 1) * ldc0 + min(col, Mb - 1)];
+                    acc[i][j][r] = (row < Ma && col < Mb) ? v : 0.0;
+                }
+            }
+        }
+    const double asign = mode != 0 ? -1.0 : 1.0;
+    // staging: 64 rows x 32 doubles per operand; thread moves 2 doubles per pass, 16 threads per row, 16 rows per pass, 4 passes
+    const int lr = tid >> 4, lk = (tid & 15) * 2;
+    const double* arow[4];
+    const double* brow[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int r = ps * 16 + lr;
+        const int ga = bi * TS + r, gb = bj * TS + r;
+        arow[ps] = ga < Ma ? A + (int64_t)ga * lda : nullptr;
+        brow[ps] = gb < Mb ? B + (int64_t)gb * ldb : nullptr;
+    }
+    double2 ra[4], rb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            ra[ps] = arow[ps] ? *reinterpret_cast<const double2*>(arow[ps] + k0 + lk) : make_double2(0.0, 0.0);
+            rb[ps] = brow[ps] ? *reinterpret_cast<const double2*>(brow[ps] + k0 + lk) : make_double2(0.0, 0.0);
+        }
+    };
+    auto lstore = [&](int st) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int r = ps * 16 + lr;
+            *reinterpret_cast<double2*>(&As[st][r * PITCH + lk]) = make_double2(asign * ra[ps].x, asign * ra[ps].y);
+            *reinterpret_cast<double2*>(&Bs[st][r * PITCH + lk]) = rb[ps];
+        }
+    };
+    const int nchunks = K / KC;
+    if (nchunks > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int st = c & 1;
+        if (c + 1 < nchunks) gload((c + 1) * KC);
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 4) {
+            double af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = As[st][(wr * 32 + i * 16 + (lane & 15)) * PITCH + kk + (lane >> 4)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = Bs[st][(wc * 32 + j * 16 + (lane & 15)) * PITCH + kk + (lane >> 4)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (c + 1 < nchunks) lstore(st ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = bi * TS + wr * 32 + i * 16 + (lane >> 4) + 4 * r;
+                const int col = bj * TS + wc * 32 + j * 16 + (lane & 15);
+                if (row < Ma && col < Mb) C[(int64_t)row * ldc + col] = acc[i][j][r];
+            }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// index lists of the hard equality rows E / inequality rows I (static per LP skeleton): epos[i] = position in E or -1,
+// ipos[i] = position in I or -1
+struct NsIdx {
+    const int *Eidx, *Epos, *Iidx, *Ipos;
+    int nE, nI;
+};
+
+// R[c, :] = column J[c] of A_EF on the rows E (dense row of length ldr, zero elsewhere).  One workgroup per right-hand side.
+__global__ __launch_bounds__(256) void k_ns_rhs_cols(const int* __restrict__ cptr, const int* __restrict__ crow, const int* __restrict__ cpos,
+                                                     const double* __restrict__ vals, NsIdx X, const int* __restrict__ J, const double* __restrict__ Fm,
+                                                     double* __restrict__ R, int64_t ldr) {
+    const int c = blockIdx.x;
+    double* row = R + (int64_t)c * ldr;
+    for (int64_t e = threadIdx.x; e < ldr; e += 256) row[e] = 0.0;
+    __syncthreads();
+    const int j = J ? J[c] : c;
+    if (Fm[j] == 0.0) return;
+    for (int k = cptr[j] + threadIdx.x; k < cptr[j + 1]; k += 256) {
+        const int ep = X.Epos[crow[k]];
+        if (ep >= 0) row[ep] = vals[cpos[k]];
+    }
+}
+
+// PJ[c, j] = Fm_j (delta(j, J[c]) - sum_{i in E, A_ij != 0} W[c, epos(i)] A_ij)      (rows of the projector P)
+__global__ __launch_bounds__(256) void k_ns_pj(const int* __restrict__ cptr, const int* __restrict__ crow, const int* __restrict__ cpos,
+                                               const double* __restrict__ vals, NsIdx X, const int* __restrict__ J, const double* __restrict__ Fm,
+                                               const double* __restrict__ W, int64_t ldw, double* __restrict__ PJ, int64_t ldp, int64_t n, int64_t ldn) {
+    const int c = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= ldn) return;
+    double v = 0.0;
+    if (j < n && Fm[j] != 0.0) {
+        const double* w = W + (int64_t)c * ldw;
+        double acc = 0.0;
+        for (int k = cptr[j]; k < cptr[j + 1]; ++k) {
+            const int ep = X.Epos[crow[k]];
+            if (ep >= 0) acc += w[ep] * vals[cpos[k]];
+        }
+        v = (j == J[c] ? 1.0 : 0.0) - acc;
+    }
+    PJ[(int64_t)c * ldp + j] = v;
+}
+
+// T[c, d] = PJ[c, J[d]]  (d <= c; the lower triangle of P[J, J]) into the factor buffer of the small system
+__global__ __launch_bounds__(256) void k_ns_gather_t(const double* __restrict__ PJ, int64_t ldp, const int* __restrict__ J, int k,
+                                                     double* __restrict__ T, int64_t ldt) {
+    const int c = blockIdx.y;
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d <= c && d < k) T[(int64_t)c * ldt + d] = PJ[(int64_t)c * ldp + J[d]];
+}
+
+// v[i] = val for i < len
+__global__ __launch_bounds__(256) void k_ns_fill(double* __restrict__ v, double val, int64_t len) {
+    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < len) v[t] = val;
+}
+
+// d[i] = S[i, i]
+__global__ __launch_bounds__(256) void k_ns_diag(const double* __restrict__ S, int64_t ld, int N, double* __restrict__ d) {
+    int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < N) d[t] = S[(int64_t)t * ld + t];
+}
+
+// lower triangle of S[0:N, 0:N] := diag(dvec) (strictly lower part zero); dvec == nullptr: zero diagonal as well
+__global__ __launch_bounds__(256) void k_ns_set_diag(double* __restrict__ S, int64_t ld, int N, const double* __restrict__ dvec) {
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j <= i && j < N) S[(int64_t)i * ld + j] = (j == i && dvec) ? dvec[i] : 0.0;
+}
+
+// cnt[0] = number of guarded pivots (diagonal entries of the factor >= big): one workgroup
+__global__ __launch_bounds__(1024) void k_ns_count_big(const double* __restrict__ S, int64_t ld, int N, double big, int* __restrict__ cnt) {
+    __shared__ int sh[16];
+    int c = 0;
+    for (int i = threadIdx.x; i < N; i += 1024) c += S[(int64_t)i * ld + i] >= big ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int k = 0; k < 16; ++k) t += sh[k];
+        cnt[0] = t;
+    }
+}
+
+// In place  Zt = L^-1 PJ  (forward substitution down the k rows, one thread per column; L = k x k lower factor, pitch ldl).
+// The rows already finished are read back from Zt itself (coalesced across the workgroup, L2 resident); the row of L is
+// staged in LDS 64 entries at a time.
+__global__ __launch_bounds__(256) void k_ns_ortho(const double* __restrict__ L, int64_t ldl, int k, double* __restrict__ Zt, int64_t ldz, int64_t ncols) {
+    __shared__ double lrow[64];
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = j < ncols;
+    for (int c = 0; c < k; ++c) {
+        double acc = live ? Zt[(int64_t)c * ldz + j] : 0.0;
+        for (int d0 = 0; d0 < c; d0 += 64) {
+            const int nd = min(64, c - d0);
+            __syncthreads();
+            if ((int)threadIdx.x < nd) lrow[threadIdx.x] = L[(int64_t)c * ldl + d0 + threadIdx.x];
+            __syncthreads();
+            if (live)
+                for (int d = 0; d < nd; ++d) acc -= lrow[d] * Zt[(int64_t)(d0 + d) * ldz + j];
+        }
+        if (live) Zt[(int64_t)c * ldz + j] = acc / L[(int64_t)c * ldl + c];
+        __threadfence_block();
+    }
+}
+
+// GIt[c, ipos] = sum_{j in row i} A_ij Zt[c, j]   for the inequality rows i = Iidx[ipos]   (Zt is zero in the fixed columns)
+__global__ __launch_bounds__(256) void k_ns_gi(const int* __restrict__ rptr, const int* __restrict__ rcol, const double* __restrict__ vals, NsIdx X,
+                                               const double* __restrict__ Zt, int64_t ldz, double* __restrict__ GIt, int nIp) {
+    const int c = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= nIp) return;
+    double acc = 0.0;
+    if (t < X.nI) {
+        const int i = X.Iidx[t];
+        const double* z = Zt + (int64_t)c * ldz;
+        for (int k = rptr[i]; k < rptr[i + 1]; ++k) acc += vals[k] * z[rcol[k]];
+    }
+    GIt[(int64_t)c * ldz + t] = acc;
+}
+
+// theta~ = [ (muL/tL + muU/tU + rho) Fm  (n, zero padded to ldn) | 1/dS on the inequality rows (nI, zero padded to nIp) ]
+__global__ __launch_bounds__(256) void k_ns_theta(IpmPtrs P, NsIdx X, double rho_p, double* __restrict__ th, int64_t ldn, int nIp) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < ldn) {
+        double v = 0.0;
+        if (t < P.n && P.ub[t] > P.lb[t]) v = P.muL[t] / P.tL[t] + P.muU[t] / P.tU[t] + rho_p;
+        th[t] = v;
+    }
+    if (t < nIp) th[ldn + t] = t < X.nI ? 1.0 / P.dS[X.Iidx[t]] : 0.0;
+}
+
+// ---- vector kernels of the null-space Newton solve (oracle: IPM.run, solve_ns).  thI = theta~ + ldn = D_I^-1 by position in I.
+// out[e] = scale * r[Eidx[e]]
+__global__ __launch_bounds__(256) void k_ns_gather_e(NsIdx X, const double* __restrict__ r, double scale, double* __restrict__ out) {
+    int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < X.nE) out[t] = scale * r[X.Eidx[t]];
+}
+// yM[i] = tE[epos] on the equality rows, zero on the inequality rows
+__global__ __launch_bounds__(256) void k_ns_rowvec_e(NsIdx X, const double* __restrict__ tE, double* __restrict__ yM, int64_t M) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const int ep = X.Epos[i];
+    yM[i] = ep >= 0 ? tE[ep] : 0.0;
+}
+// inequality rows: bI = -res rp + sg rcg / pi,  yM = D_I^-1 bI ; equality rows: both zero
+__global__ __launch_bounds__(256) void k_ns_bi(IpmPtrs P, NsIdx X, const double* __restrict__ thI, double res, double* __restrict__ bI, double* __restrict__ yM) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.M) return;
+    const int ip = X.Ipos[i];
+    double b = 0.0, y = 0.0;
+    if (ip >= 0) {
+        b = -res * P.rp[i] + (double)P.rtype[i] * P.rcg[i] / P.pi[i];
+        y = thI[ip] * b;
+    }
+    bI[i] = b;
+    yM[i] = y;
+}
+// wM[i] = D_I^-1 aM[i] on the inequality rows, zero on the equality rows
+__global__ __launch_bounds__(256) void k_ns_wm(NsIdx X, const double* __restrict__ thI, const double* __restrict__ aM, double* __restrict__ wM, int64_t M) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const int ip = X.Ipos[i];
+    wM[i] = ip >= 0 ? thI[ip] * aM[i] : 0.0;
+}
+// free columns (th != 0):  out = th x + atw - (h ? h : 0) ; fixed / padded columns: 0       (K x - h,  K = Th + A_I' D_I^-1 A_I)
+__global__ __launch_bounds__(256) void k_ns_kx(const double* __restrict__ th, const double* __restrict__ x, const double* __restrict__ atw,
+                                               const double* __restrict__ h, double* __restrict__ out, int64_t ldn) {
+    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= ldn) return;
+    const double t = th[j];
+    out[j] = t != 0.0 ? t * x[j] + atw[j] - (h ? h[j] : 0.0) : 0.0;
+}
+// x[j] = 0 on the fixed / padded columns (th == 0)
+__global__ __launch_bounds__(256) void k_ns_mask(double* __restrict__ x, const double* __restrict__ th, int64_t ldn) {
+    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < ldn && th[j] == 0.0) x[j] = 0.0;
+}
+// h~ = hp + A_I' D_I^-1 bI on the free columns (zero elsewhere) ;  v = h~ - res K dpbar
+__global__ __launch_bounds__(256) void k_ns_ht(const double* __restrict__ th, const double* __restrict__ hp, const double* __restrict__ atw,
+                                               const double* __restrict__ kdpb, double res, double* __restrict__ ht, double* __restrict__ v, int64_t n, int64_t ldn) {
+    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= ldn) return;
+    double h = 0.0, o = 0.0;
+    if (j < n && th[j] != 0.0) {
+        h = hp[j] + atw[j];
+        o = h - res * kdpb[j];
+    }
+    ht[j] = h;
+    v[j] = o;
+}
+// out = rhs - N0 x  with N0 symmetric, lower triangle stored (pitch ld): one wavefront per row
+__global__ __launch_bounds__(256) void k_ns_symv_res(const double* __restrict__ N0, int64_t ld, int k, const double* __restrict__ x, const double* __restrict__ rhs,
+                                                     double* __restrict__ out) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= k) return;
+    double acc = 0.0;
+    for (int j = lane; j <= i; j += 64) acc = fma(N0[(int64_t)i * ld + j], x[j], acc);
+    for (int j = i + 1 + lane; j < k; j += 64) acc = fma(N0[(int64_t)j * ld + i], x[j], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) out[i] = rhs[i] - acc;
+}
+// lower triangle copy  dst[i, j] = src[i, j], j <= i < k
+__global__ __launch_bounds__(256) void k_ns_copy_lower(const double* __restrict__ src, int64_t lds_, double* __restrict__ dst, int64_t ldd, int k) {
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j <= i && j < k) dst[(int64_t)i * ldd + j] = src[(int64_t)i * lds_ + j];
+}
+// x = a + b
+__global__ __launch_bounds__(256) void k_ns_add(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ x, int64_t len) {
+    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < len) x[j] = a[j] + b[j];
+}
+// dp = res dpbar + Z du on the free columns, with the bound multipliers' directions (k_ipm_dir's column part)
+__global__ __launch_bounds__(256) void k_ns_dp(IpmPtrs P, IpmDir D, const double* __restrict__ th, const double* __restrict__ dpb, double res,
+                                               const double* __restrict__ zu, int64_t ldn) {
+    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= ldn) return;
+    double dp = 0.0, dL = 0.0, dU = 0.0;
+    if (t < P.n && th[t] != 0.0) {
+        dp = res * dpb[t] + zu[t];
+        dL = (P.rcL[t] - P.muL[t] * dp) / P.tL[t];
+        dU = (P.rcU[t] + P.muU[t] * dp) / P.tU[t];
+    }
+    D.dp[t] = dp;
+    if (t < P.n) { D.dmuL[t] = dL; D.dmuU[t] = dU; }
+}
+// inequality rows: dy = D_I^-1 (bI - aM), dpi = sg dy, dg = (rcg - g dpi)/pi, wM = D_I^-1 aM ; equality rows: dy = dpi = dg = wM = 0
+__global__ __launch_bounds__(256) void k_ns_rows(IpmPtrs P, IpmDir D, NsIdx X, const double* __restrict__ thI, const double* __restrict__ bI,
+                                                 const double* __restrict__ aM, double* __restrict__ wM) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.M) return;
+    const int ip = X.Ipos[i];
+    double dy = 0.0, dpi = 0.0, dg = 0.0, w = 0.0;
+    if (ip >= 0) {
+        dy = thI[ip] * (bI[i] - aM[i]);
+        dpi = (double)P.rtype[i] * dy;
+        dg = (P.rcg[i] - P.g[i] * dpi) / P.pi[i];
+        w = thI[ip] * aM[i];
+    }
+    D.dy[i] = dy;
+    D.dpi[i] = dpi;
+    D.dg[i] = dg;
+    wM[i] = w;
+}
+// out[Eidx[e]] = tE[e]
+__global__ __launch_bounds__(256) void k_ns_scatter_e(NsIdx X, const double* __restrict__ tE, double* __restrict__ out) {
+    int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < X.nE) out[X.Eidx[t]] = tE[t];
+}
+// slot[0] = max_j |th_j dp_j - aty_j - hp_j| over the free columns: the dual-equation error of the step (one workgroup)
+__global__ __launch_bounds__(1024) void k_ns_err(const double* __restrict__ th, const double* __restrict__ dp, const double* __restrict__ aty,
+                                                 const double* __restrict__ hp, int64_t n, double* __restrict__ slot) {
+    __shared__ double sh[16];
+    double m = 0.0;
+    for (int64_t j = threadIdx.x; j < n; j += 1024)
+        if (th[j] != 0.0) m = fmax(m, fabs(th[j] * dp[j] - aty[j] - hp[j]));
+    m = blk_reduce_max(m, sh);
+    if (threadIdx.x == 0) slot[0] = m;
+}

@@ -109,6 +109,9 @@ typedef struct {
     int32_t eqp;           /* active-set (EQP) solves */
     int32_t M, n, ns;      /* LP rows, columns, slack columns */
     int32_t col_iters;     /* interior-point iterations that factored the n x n column form (restoration LPs) */
+    int32_t ns_iters;      /* interior-point iterations that factored the k x k null-space form (normal-phase LPs with many equality rows) */
+    int32_t ns_dim;        /* k = dimension of null(A_EF) when that form was set up, else 0 */
+    int32_t ns_cold;       /* 1: the basis columns were selected from scratch in this LP (0: the previous LP's columns were re-used) */
     double  ipm_pinf, ipm_dinf, ipm_gap;
     double  kkt_pr, kkt_du;
     double  wall_ms;       /* host wall time of the solve */

@@ -55,9 +55,9 @@ MCC_DELTA, MCC_BMIN, MCC_BMAX, MCC_GAMMA = 0.3, 0.1, 10.0, 0.1
 IPM_RHO_P = 1e-8     # primal proximal regularisation of the Newton system (bounds Theta^-1 for effectively free variables)
 NS_MIN_E = 64         # null-space form (normal phase): fewest hard equality rows, largest null-space dimension relative to M,
 NS_MAX_RATIO = 0.3    # pivot thresholds of the basis-column selection (first one that yields a full basis), pivot threshold
-NS_SEL_THR = (1e-2, 1e-4, 1e-7, 1e-10)    # for re-using the previous LP's basis columns, CG steps per solve beyond which the LP
-NS_WARM_THR = 1e-6    # returns to the row form
-NS_MAX_CG = 2
+NS_SEL_THR = (1e-2, 1e-4, 1e-7, 1e-10)    # for re-using the previous LP's basis columns,
+NS_WARM_THR = 1e-6    # share of the stage tolerance / of the current dual infeasibility the dual-equation error of a step may
+NS_DERR = 0.1         # reach before the LP returns to the row form
 CHOL_NB = 64
 PIV_BIG = 1e128
 
@@ -305,7 +305,7 @@ class IPM:
         # null-space form (class NullSpace): normal phase, many hard equality rows, small null space
         nE = int((lp.rtype == 0).sum())
         nF = int(free.sum())
-        self.ns_ok = bool(ns == 0 and nE >= NS_MIN_E and nF - nE <= NS_MAX_RATIO * M)
+        self.ns_ok = bool(ns == 0 and nE >= NS_MIN_E and nF - nE <= NS_MAX_RATIO * M and n <= M and np.count_nonzero(lp.A) * 16 <= M * n)
         self.ns_off = False
         self.ns_iters = 0
         self.ns = None
@@ -372,34 +372,31 @@ class IPM:
                         self.ns_off = True
                 use_ns = not self.ns_off
             if use_ns:
-                # Null-space form: with the equality rows eliminated ( dp = dpbar + Z du,  A_EF dpbar = r_E ) and the inequality
-                # rows condensed ( dy_I = D_I^-1 (r_I - A_I dp) ) the Newton system  S dy = r  becomes the k x k system
-                #   N du = Z'(A_I' D_I^-1 r_I - K dpbar),   N = Z' K Z,   K = Th + A_I' D_I^-1 A_I,
-                # and  dy_E = S0^-1 A_EF (K dp - A_I' D_I^-1 r_I)  recovers the equality multipliers: two solves with the factor
-                # of S0 = A_EF A_EF' (made once per LP) and one with the factor of N per Newton solve.
+                # Null-space form.  The Newton system in the unknowns (dp, dy):
+                #   Th dp - A'dy = hp,    A_E dp = b_E,    A_I dp + D_I dy_I = b_I
+                # is solved with the equality rows eliminated ( dp = dpbar + Z du,  A_EF dpbar = b_E ) and the inequality rows
+                # condensed ( dy_I = D_I^-1 (b_I - A_I dp) ):
+                #   N du = Z'(h~ - K dpbar),   N = Z'K Z (k x k),  K = Th + A_I' D_I^-1 A_I,  h~ = hp + A_I' D_I^-1 b_I,
+                #   dy_E = S0^-1 A_EF (K dp - h~)      (least-squares multipliers of the equality rows).
+                # The primal equations hold to rounding by construction; all inexactness sits in the dual equation, where the
+                # next iteration's right-hand side picks it up (its size is monitored: `ns_err`).  Per iteration: one factorisation
+                # of N, two solves with the factor of S0 = A_EF A_EF' (dpbar for the residual of the equality rows, shared by
+                # predictor and corrector; dy_E of the final direction) - no Gondzio correctors in this form (a Newton solve
+                # costs more than the factorisation here).
                 self.ns_iters += 1
                 nsp = self.ns
                 thF = (muL / tL + muU / tU + IPM_RHO_P) * nsp.Fm
                 dinvI = 1.0 / dS[nsp.I]
-                Nm = (nsp.Zt * thF) @ nsp.Zt.T + (nsp.GI.T * dinvI) @ nsp.GI
+                Nm0 = (nsp.Zt * thF) @ nsp.Zt.T + (nsp.GI.T * dinvI) @ nsp.GI
+                Nm = Nm0.copy()
                 kdx = np.arange(nsp.k)
                 nd0 = Nm[kdx, kdx].copy()
                 Nm[kdx, kdx] += 1e-13 * nd0 + 1e-30
                 LN = chol_guard(Nm, nd0)
                 AIF = nsp.AI
-
-                def precond(r):
-                    dpb = nsp.AEF.T @ chol_solve(nsp.L0, r[nsp.E])
-                    hI = AIF.T @ (dinvI * r[nsp.I])
-                    Kdpb = thF * dpb + AIF.T @ (dinvI * (AIF @ dpb))
-                    du = chol_solve(LN, nsp.Zt @ (hI - Kdpb))
-                    dpF = dpb + nsp.Zt.T @ du
-                    dyI = dinvI * (r[nsp.I] - AIF @ dpF)
-                    KdpF = thF * dpF + AIF.T @ (dinvI * (AIF @ dpF))
-                    dy = np.empty(M)
-                    dy[nsp.E] = chol_solve(nsp.L0, nsp.AEF @ (KdpF - hI))
-                    dy[nsp.I] = dyI
-                    return dy
+                dpb1 = nsp.AEF.T @ chol_solve(nsp.L0, -rp[nsp.E])
+                sgI, piI = sg[nsp.I], pi[nsp.I]
+                ns_err = [0.0]
             use_col = (not use_ns) and self.col_ok and not self.col_off
             if use_col:
                 self.col_iters += 1
@@ -507,24 +504,48 @@ class IPM:
                 dg = np.where(ineq, (rcg - g * dpi) / np.where(ineq, pi, 1.0), 0.0)
                 return dp, ds, dg, dy, dmuL, dmuU, dmus, dpi
 
+            def solve_ns(rcL, rcU, rcs, rcg, res=1.0, want_dy=True):
+                hp = np.where(free, -res * rdp + rcL / tL - rcU / tU, 0.0)
+                bI = -res * rp[nsp.I] + sgI * rcg[nsp.I] / piI
+                dpb = res * dpb1
+                ht = hp + AIF.T @ (dinvI * bI)
+                rhs_u = nsp.Zt @ (ht - (thF * dpb + AIF.T @ (dinvI * (AIF @ dpb))))
+                du = chol_solve(LN, rhs_u)
+                du = du + chol_solve(LN, rhs_u - Nm0 @ du)      # one refinement sweep on the unregularised reduced matrix
+                dp = dpb + nsp.Zt.T @ du
+                dy = np.zeros(M)
+                dy[nsp.I] = dinvI * (bI - AIF @ dp)
+                if want_dy:
+                    gE = thF * dp + AIF.T @ (dinvI * (AIF @ dp)) - ht
+                    dy[nsp.E] = chol_solve(nsp.L0, nsp.AEF @ gE)
+                    ns_err[0] = float(np.abs(nsp.Fm * (thF * dp - A.T @ dy - hp)).max(initial=0.0))
+                dmuL = np.where(free, (rcL - muL * dp) / tL, 0.0)
+                dmuU = np.where(free, (rcU + muU * dp) / tU, 0.0)
+                dpi = np.where(ineq, sg * dy, 0.0)
+                dg = np.where(ineq, (rcg - g * dpi) / np.where(ineq, pi, 1.0), 0.0)
+                return dp, np.zeros(0), dg, dy, dmuL, dmuU, np.zeros(0), dpi
+
             def steps(dp, ds, dg, dmuL, dmuU, dmus, dpi):
                 ap = min(_maxstep(tL, dp, free), _maxstep(tU, -dp, free), _maxstep(ts, ds, allk), _maxstep(g, dg, ineq))
                 ad = min(_maxstep(muL, dmuL, free), _maxstep(muU, dmuU, free), _maxstep(mus, dmus, allk), _maxstep(pi, dpi, ineq))
                 return ap, ad
 
             # predictor (affine scaling)
-            dp, ds, dg, dy, dmuL, dmuU, dmus, dpi = solve(-tL * muL, -tU * muU, -ts * mus, -g * pi)
+            if use_ns:
+                dp, ds, dg, dy, dmuL, dmuU, dmus, dpi = solve_ns(-tL * muL, -tU * muU, -ts * mus, -g * pi, 1.0, False)
+            else:
+                dp, ds, dg, dy, dmuL, dmuU, dmus, dpi = solve(-tL * muL, -tU * muU, -ts * mus, -g * pi)
             ap, ad = steps(dp, ds, dg, dmuL, dmuU, dmus, dpi)
             mu_aff = ((tL + ap * dp)[free] @ (muL + ad * dmuL)[free] + (tU - ap * dp)[free] @ (muU + ad * dmuU)[free]
                       + (ts + ap * ds) @ (mus + ad * dmus) + (g + ap * dg)[ineq] @ (pi + ad * dpi)[ineq]) / self.ncomp
             sig = (mu_aff / mu) ** 3 if mu > 0 else 0.0
             sm = sig * mu
             # corrector
-            dp, ds, dg, dy, dmuL, dmuU, dmus, dpi = solve(sm - tL * muL - dp * dmuL, sm - tU * muU + dp * dmuU,
-                                                          sm - ts * mus - ds * dmus, sm - g * pi - dg * dpi)
+            dp, ds, dg, dy, dmuL, dmuU, dmus, dpi = (solve_ns if use_ns else solve)(sm - tL * muL - dp * dmuL, sm - tU * muU + dp * dmuU,
+                                                                                   sm - ts * mus - ds * dmus, sm - g * pi - dg * dpi)
             eta = 0.995 if mu >= 1.0 else min(max(0.995, 1.0 - mu / self.scale_q), 0.999999)
             ap, ad = steps(dp, ds, dg, dmuL, dmuU, dmus, dpi)
-            for _kc in range(IPM_MCC):                    # Gondzio multiple centrality correctors
+            for _kc in range(0 if use_ns else IPM_MCC):   # Gondzio multiple centrality correctors
                 if min(ap, ad) >= 0.9:
                     break
                 tp, td = min(1.0, ap + MCC_DELTA), min(1.0, ad + MCC_DELTA)
@@ -545,7 +566,7 @@ class IPM:
                 dp, ds, dg, dy, dmuL, dmuU, dmus, dpi = cand
                 ap, ad = ap2, ad2
             self.last_cg = (cg_max[0], cg_fail[0])
-            if use_ns and cg_fail[0]:
+            if use_ns and ns_err[0] / self.scale_q > NS_DERR * max(tol, dinf):
                 self.ns_off = True                  # the reduced system lost its accuracy: redo the iteration in row form
                 continue
             if use_col and cg_fail[0]:
@@ -568,8 +589,6 @@ class IPM:
             self.mus = mus + b * dmus
             self.pi = pi + b * dpi
             self.y = np.where(ineq, sg * self.pi, self.y + b * dy)
-            if use_ns and cg_max[0] > NS_MAX_CG:
-                self.ns_off = True
             if use_col and cg_max[0] > COL_MAX_CG:
                 self.col_off = True
             if use_red and cg_max[0] > RED_MAX_CG:
