@@ -48,7 +48,7 @@ const int RED_MIN_M = 4096, RED_MAX_CG = 10;
 const double RED_TAU = 100.0, RED_MIN_FRAC = 0.1;
 // null-space form of the normal-phase Newton system (oracle/lp_solver.py: NS_*)
 const int NS_MIN_E = 64;
-const double NS_MAX_RATIO = 0.3, NS_WARM_THR = 1e-6, NS_BIG = 0.5e128, NS_DERR = 0.1;
+const double NS_MAX_RATIO = 0.3, NS_WARM_THR = 1e-6, NS_ZWARM_THR = 0.25, NS_BIG = 0.5e128, NS_DERR = 0.1;
 const double NS_SEL_THR[4] = {1e-2, 1e-4, 1e-7, 1e-10};
 const int PCG_MAXIT = 20;       // conjugate-gradient steps per Newton solve (preconditioner = the Cholesky factor)
 const double PCG_KAPPA = 1e-3;  // Newton-system residual tolerance relative to the current primal residual
@@ -165,7 +165,12 @@ struct asm_handle {
     int64_t ns_ldg = 0;
     int *d_nsEidx = nullptr, *d_nsEpos = nullptr, *d_nsIidx = nullptr, *d_nsIpos = nullptr, *d_nsJ = nullptr, *d_nscnt = nullptr;
     FacBuf ns_f0, ns_fN;            // factors of S0 = A_EF A_EF' (per LP) and of the k x k reduced matrix (per iteration)
-    double *d_nsLt = nullptr, *d_nsR = nullptr, *d_nsX = nullptr, *d_nsG = nullptr, *d_nsth = nullptr, *d_nsFm = nullptr, *d_nsv = nullptr, *d_nsYt = nullptr, *d_nsN0 = nullptr;
+    double *d_nsLt = nullptr, *d_nsR = nullptr, *d_nsX = nullptr, *d_nsG = nullptr, *d_nsth = nullptr, *d_nsFm = nullptr, *d_nsv = nullptr, *d_nsYt = nullptr, *d_nsN0 = nullptr, *d_nsZT = nullptr;
+    FacBuf ns_fC;                   // factor of the Gram matrix of the active constraints in reduced coordinates (active-set solves)
+    int ns_ccap = 0;                // most constraints it is sized for
+    int ns_Zk = 0;                  // rows of the orthonormal basis of the previous LP still resident in d_nsG (0: none)
+    int *d_nsqi = nullptr;          // sel | bpos | rpos | cnt
+    double *d_nsq = nullptr;        // Csel | d, u, lam, v, w | pbar, tbar, u0, qh
     std::vector<void*> ns_bufs;     // everything above, for release
     double* d_ipm = nullptr;        // arena of the device-resident interior-point state
     int* d_ipm_i = nullptr;
@@ -430,22 +435,23 @@ struct Dev {
         end(id);
     }
     // Rows of R (nrhs x ldr, zero beyond column Ms) are right-hand sides of  L x = r  (forward) and then  L' x = z  (backward) with the
-    // CURRENT factor (fS, its wide-block inverses) and its transposed copy Lt (same pitch).  Block substitution over the wide
-    // blocks: an update  R_blk -= X[:, done] L[blk, done]'  and a product with the explicit inverse of the diagonal block, both on the
+    // CURRENT factor (fS, its wide-block inverses) and its transposed copy Lt (same pitch).  Right-looking block substitution over the
+    // wide blocks: the block's solution is a product with the explicit inverse of the diagonal block, then ONE update of all the
+    // remaining columns  R[:, rest] -= X_blk L[rest, blk]'  (K = the block width, every tile of the remainder in parallel) - both on the
     // matrix cores.  Forward: R -> X.  Backward (if Lt): X -> R.  The solution ends in R (backward) or X (forward only).
     void trsm_rows(double* R, double* X, int64_t ldr, int nrhs, int Ms, const double* Lt) {
         const int WB = fwb;
         const int nB = (Ms + WB - 1) / WB;
         for (int B = 0; B < nB; ++B) {
-            const int b0 = B * WB, wv = std::min(WB, Ms - b0), Kb = (int)round_up(wv, 32);
-            if (b0 > 0) gemm_nt(X, ldr, fS + (int64_t)b0 * fld, fld, R + b0, ldr, R + b0, ldr, nrhs, wv, b0, 1);
+            const int b0 = B * WB, wv = std::min(WB, Ms - b0), b1 = b0 + wv, Kb = (int)round_up(wv, 32);
             gemm_nt(R + b0, ldr, fBinv + (int64_t)B * WB * WB, WB, nullptr, 0, X + b0, ldr, nrhs, wv, Kb, 0);
+            if (b1 < Ms) gemm_nt(X + b0, ldr, fS + (int64_t)b1 * fld + b0, fld, R + b1, ldr, R + b1, ldr, nrhs, Ms - b1, Kb, 1);
         }
         if (!Lt) return;
         for (int B = nB - 1; B >= 0; --B) {
-            const int b0 = B * WB, wv = std::min(WB, Ms - b0), b1 = b0 + wv, Kb = (int)round_up(wv, 32);
-            if (b1 < Ms) gemm_nt(R + b1, ldr, Lt + (int64_t)b0 * fld + b1, fld, X + b0, ldr, X + b0, ldr, nrhs, wv, (int)round_up(Ms - b1, 32), 1);
+            const int b0 = B * WB, wv = std::min(WB, Ms - b0), Kb = (int)round_up(wv, 32);
             gemm_nt(X + b0, ldr, fBinvT + (int64_t)B * WB * WB, WB, nullptr, 0, R + b0, ldr, nrhs, wv, Kb, 0);
+            if (b0 > 0) gemm_nt(R + b0, ldr, Lt + b0, fld, X, ldr, X, ldr, nrhs, b0, Kb, 1);
         }
     }
     // out[i] = sum_j Ah_ij^2 thinv_j   (sparse patterns only)
@@ -907,11 +913,9 @@ struct Solver {
         for (int64_t j = 0; j < n; ++j) nfree += lp.ub[j] > lp.lb[j];
         ip.ncomp = std::max<int64_t>(2 * nfree + lp.ns + nineq, 1);
         ip.red_ok = M >= RED_MIN_M && h->sp_ok;
-        {
-            int64_t nE = 0;
-            for (int64_t i = 0; i < M; ++i) nE += lp.rtype[i] == 0;
-            ip.ns_ok = h->ns_cap && lp.ns == 0 && nE >= NS_MIN_E && (double)(nfree - nE) <= NS_MAX_RATIO * (double)M;
-        }
+        ip.ns_ok = ns_lp && lp.ns == 0;      // basis made by solve_scaled before the warm attempt
+        ip.ns_ready = true;
+        ip.ns_k = ns_k;
         ip.col_ok = h->col_capable && lp.ns > 0 && M >= COL_MIN_M && (double)n <= COL_MAX_RATIO * (double)M;   // every row owns a slack (setup)
         ipm_upload_lp();
         P.ncomp = ip.ncomp;
@@ -967,6 +971,8 @@ struct Solver {
 
     // ------------------------------------------------------------ null-space form (oracle: class NullSpace / IPM.run use_ns)
     bool use_ns = false, ns_was_cold = false;
+    bool ns_lp = false;       // this LP has a valid null-space basis (set up before the warm attempt: the active-set solves use it too)
+    int ns_k = 0;
     SolveHint* cur_hint = nullptr;
     NsIdx nsX() const { NsIdx X; X.Eidx = h->d_nsEidx; X.Epos = h->d_nsEpos; X.Iidx = h->d_nsIidx; X.Ipos = h->d_nsIpos; X.nE = h->ns_nE; X.nI = h->ns_nI; return X; }
     int ns_read_cnt() {
@@ -985,12 +991,61 @@ struct Solver {
         h->d_nsG = ns_dalloc(h, (int64_t)cap * h->ns_ldg);
         ns_alloc_factor(h, h->ns_fN, cap);
         h->d_nsN0 = ns_dalloc(h, h->ns_fN.ld * h->ns_fN.ld);
+        h->d_nsZT = ns_dalloc(h, h->ldn * h->ns_fN.ld);        // transposed copy of the basis rows (right operand of the orthonormalisation product)
         int* dj = nullptr;
         dmalloc(&dj, cap);
         h->ns_bufs.push_back((void*)dj);
         h->d_nsJ = dj;
         h->ns_kcap = cap;
+        // active-set solves in reduced coordinates: up to 2 cap constraints (an over-determined working set has more than k)
+        h->ns_ccap = (int)std::min<int64_t>(2 * cap, h->Mp);
+        ns_alloc_factor(h, h->ns_fC, h->ns_ccap);
+        int* qi = nullptr;
+        dmalloc(&qi, (int64_t)h->ns_ccap + h->ldn + h->ns_nIp + 16);
+        h->ns_bufs.push_back((void*)qi);
+        h->d_nsqi = qi;
+        h->d_nsq = ns_dalloc(h, (int64_t)h->ns_ccap * h->ns_fN.ld + 5 * (int64_t)h->ns_ccap + h->ldn + h->Mp + 2 * h->ns_fN.ld + 64);
         HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    // In place  Zt = L^-1 Zt  with the k x k factor just made in h->ns_fN.  When the factor fits into one wide block the explicit inverse of
+    // that block IS L^-1: one transpose + one product on the matrix cores (the rows are n long); otherwise forward substitution per column.
+    void ns_ortho(int k) {
+        if (k <= h->ns_fN.wb) {
+            const int kp = (int)round_up(k, 32);
+            hipLaunchKernelGGL(k_transpose_dense, dim3((unsigned)((h->ldn + 63) / 64), (unsigned)((k + 63) / 64)), dim3(256), 0, h->stream, (const double*)h->d_nsG, h->ns_ldg,
+                               (int64_t)k, h->ldn, h->d_nsZT, h->ns_fN.ld);
+            dev.gemm_nt(h->ns_fN.Binv, h->ns_fN.wb, h->d_nsZT, h->ns_fN.ld, nullptr, 0, h->d_nsG, h->ns_ldg, k, (int)h->ldn, kp, 0);
+        } else {
+            hipLaunchKernelGGL(k_ns_ortho, dim3((unsigned)((h->ldn + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->ns_fN.S, h->ns_fN.ld, k, h->d_nsG, h->ns_ldg, h->ldn);
+        }
+    }
+    // The k rows in d_nsG (an approximate or an outdated basis) projected onto null(A_EF) of THIS LP and orthonormalised with their own
+    // Gram matrix (pivot guard `thr`, absolute), then GI' = (A_I Z)'.  Used as the second pass of ns_basis_from and, with the previous
+    // LP's basis, as the whole set-up (oracle: NullSpace.__init__, warm_Z).  The factor of S0 must be current in h->ns_f0.
+    bool ns_reproject(int k, double thr) {
+        const int nE = h->ns_nE;
+        const NsIdx X = nsX();
+        const double* vals = dev.sparse_vals(h->d_Ah);
+        // second pass (oracle: NullSpace.basis_from): project the rows once more and orthonormalise with their own Gram matrix (~ I) -
+        // the columns picked in index order can be badly conditioned, and the active-set solves need A_EF Z = 0 to 1e-13
+        hipLaunchKernelGGL(k_ns_rows_e, dim3((unsigned)((h->ns_nEp + 255) / 256), (unsigned)k), dim3(256), 0, h->stream, h->d_sp_ptr, h->d_sp_col, vals, X,
+                           (const double*)h->d_nsFm, (const double*)h->d_nsG, h->ns_ldg, h->d_nsR, (int64_t)h->ns_nEp);
+        dev.use_factor(h->ns_f0);
+        dev.trsm_rows(h->d_nsR, h->d_nsX, h->ns_nEp, k, nE, h->d_nsLt);
+        hipLaunchKernelGGL(k_ns_pj, dim3((unsigned)((h->ldn + 255) / 256), (unsigned)k), dim3(256), 0, h->stream, h->d_sc_ptr, h->d_sc_row, h->d_sc_pos, vals, X,
+                           (const int*)h->d_nsJ, (const double*)h->d_nsFm, (const double*)h->d_nsR, (int64_t)h->ns_nEp, h->d_nsG, h->ns_ldg, lp.n, h->ldn, 1);
+        dev.use_factor(h->ns_fN);
+        dev.launch_syrk(Dev::pick_tile(k), h->d_nsG, h->ns_ldg, nullptr, 0, k, (int)h->ldn, nullptr, nullptr, h->ns_fN.S, h->ns_fN.ld, 0, 0);
+        hipLaunchKernelGGL(k_ns_fill, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, h->stream, h->d_diag0, 1.0, (int64_t)k);
+        dev.chol(k, thr);
+        hipLaunchKernelGGL(k_ns_count_big, dim3(1), dim3(1024), 0, h->stream, (const double*)h->ns_fN.S, h->ns_fN.ld, k, NS_BIG, h->d_nscnt);
+        const int bad2 = ns_read_cnt();
+        dev.use_main();
+        if (bad2 > 0) return false;
+        ns_ortho(k);
+        hipLaunchKernelGGL(k_ns_gi, dim3((unsigned)((h->ns_nIp + 255) / 256), (unsigned)k), dim3(256), 0, h->stream, h->d_sp_ptr, h->d_sp_col, vals, X,
+                           (const double*)h->d_nsG, h->ns_ldg, h->d_nsG + h->ldn, h->ns_nIp);
+        return true;
     }
     // Orthonormal basis from the columns J of the projector P (oracle: NullSpace.basis_from): W = S0^-1 A_EF[:, J] by block
     // substitution with all k right-hand sides at once, P[J, :] = E_J' - W' A_EF, L_J L_J' = P[J, J] (guard: pivot <= NS_WARM_THR
@@ -1006,7 +1061,7 @@ struct Solver {
         dev.use_factor(h->ns_f0);
         dev.trsm_rows(h->d_nsR, h->d_nsX, h->ns_nEp, k, nE, h->d_nsLt);
         hipLaunchKernelGGL(k_ns_pj, dim3((unsigned)((h->ldn + 255) / 256), (unsigned)k), dim3(256), 0, h->stream, h->d_sc_ptr, h->d_sc_row, h->d_sc_pos, vals, X,
-                           (const int*)h->d_nsJ, (const double*)h->d_nsFm, (const double*)h->d_nsR, (int64_t)h->ns_nEp, h->d_nsG, h->ns_ldg, lp.n, h->ldn);
+                           (const int*)h->d_nsJ, (const double*)h->d_nsFm, (const double*)h->d_nsR, (int64_t)h->ns_nEp, h->d_nsG, h->ns_ldg, lp.n, h->ldn, 0);
         dev.use_factor(h->ns_fN);
         hipLaunchKernelGGL(k_ns_gather_t, dim3((unsigned)((k + 255) / 256), (unsigned)k), dim3(256), 0, h->stream, (const double*)h->d_nsG, h->ns_ldg, (const int*)h->d_nsJ, k,
                            h->ns_fN.S, h->ns_fN.ld);
@@ -1016,10 +1071,8 @@ struct Solver {
         const int bad = ns_read_cnt();
         dev.use_main();
         if (bad > 0) return false;
-        hipLaunchKernelGGL(k_ns_ortho, dim3((unsigned)((h->ldn + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->ns_fN.S, h->ns_fN.ld, k, h->d_nsG, h->ns_ldg, h->ldn);
-        hipLaunchKernelGGL(k_ns_gi, dim3((unsigned)((h->ns_nIp + 255) / 256), (unsigned)k), dim3(256), 0, h->stream, h->d_sp_ptr, h->d_sp_col, vals, X,
-                           (const double*)h->d_nsG, h->ns_ldg, h->d_nsG + h->ldn, h->ns_nIp);
-        return true;
+        ns_ortho(k);
+        return ns_reproject(k, NS_WARM_THR);
     }
     // Per LP (oracle: NullSpace.__init__): factor S0, null-space dimension, basis columns (retained ones, else a guarded Cholesky of
     // P in index order), orthonormal basis.  False: the LP keeps the row form.
@@ -1051,7 +1104,9 @@ struct Solver {
         std::vector<int>& J = cur_hint->ns_J;
         bool have = false;
         ns_was_cold = false;
-        if ((int64_t)J.size() == k) {
+        if (h->ns_Zk == (int)k) have = ns_reproject((int)k, NS_ZWARM_THR);      // the previous LP's basis, one projection pass
+        h->ns_Zk = 0;
+        if (!have && (int64_t)J.size() == k) {
             bool free_all = true;
             for (int j : J) free_all = free_all && j >= 0 && j < n && lp.ub[j] > lp.lb[j];
             if (free_all) have = ns_basis_from(J);
@@ -1086,7 +1141,8 @@ struct Solver {
             }
         }
         if (!have) { J.clear(); return false; }
-        ip.ns_k = (int)k;
+        ns_k = (int)k;
+        h->ns_Zk = (int)k;
         return true;
     }
     double* nsv(int which) const {      // work vectors: 0..4 n-sized, 5..7 M-sized, 8..9 E-sized, 10..13 k-sized (k <= n)
@@ -1094,6 +1150,113 @@ struct Solver {
         if (which < 8) return h->d_nsv + 5 * h->ldn + (int64_t)(which - 5) * h->Mp;
         if (which < 10) return h->d_nsv + 5 * h->ldn + 3 * h->Mp + (int64_t)(which - 8) * h->ns_nEp;
         return h->d_nsv + 5 * h->ldn + 3 * h->Mp + 2 * h->ns_nEp + (int64_t)(which - 10) * h->ldn;
+    }
+    // oracle: ns_applicable
+    bool ns_applicable() const {
+        if (!h->ns_cap || lp.ns != 0) return false;
+        int64_t nE = 0, nF = 0;
+        for (int64_t i = 0; i < lp.M; ++i) nE += lp.rtype[i] == 0;
+        for (int64_t j = 0; j < lp.n; ++j) nF += lp.ub[j] > lp.lb[j];
+        return nE >= NS_MIN_E && (double)(nF - nE) <= NS_MAX_RATIO * (double)lp.M;
+    }
+    NsEq nsq() const {
+        NsEq Q;
+        int* qi = h->d_nsqi;
+        Q.sel = qi; Q.bpos = qi + h->ns_ccap; Q.rpos = Q.bpos + h->ldn; Q.cnt = Q.rpos + h->ns_nIp;
+        double* b = h->d_nsq;
+        Q.ldc = h->ns_fN.ld;
+        Q.Csel = b; b += (int64_t)h->ns_ccap * Q.ldc;
+        Q.d = b; b += h->ns_ccap; Q.lam = b; b += h->ns_ccap; Q.v = b; b += h->ns_ccap; Q.w = b; b += h->ns_ccap; Q.u = b; b += h->ns_ccap;
+        Q.pbar = b; b += h->ldn; Q.tbar = b; b += h->Mp; Q.u0 = b; b += Q.ldc; Q.qh = b;
+        return Q;
+    }
+    // dense products with the gathered constraint matrix Csel (nact rows of pitch ldc)
+    void nsq_gemv_n(const NsEq& Q, int nact, const double* x, double* out) {
+        hipLaunchKernelGGL(k_gemv_n, dim3((unsigned)((nact + 3) / 4)), dim3(256), 0, h->stream, (const double*)Q.Csel, Q.ldc, x, out, (int64_t)nact, Q.ldc);
+    }
+    void nsq_gemv_t(const NsEq& Q, int nact, const double* y, double* out) {
+        int64_t R = std::min<int64_t>((nact + 31) / 32, ASM_TMAXCHUNKS);
+        int64_t chunk = (nact + R - 1) / R;
+        R = (nact + chunk - 1) / chunk;
+        hipLaunchKernelGGL(k_gemv_t_stage1, dim3((unsigned)((Q.ldc + 255) / 256), (unsigned)R), dim3(256), 0, h->stream, (const double*)Q.Csel, Q.ldc, y, h->d_partial, (int64_t)nact, Q.ldc, chunk);
+        hipLaunchKernelGGL(k_gemv_t_stage2, dim3((unsigned)((Q.ldc + 255) / 256)), dim3(256), 0, h->stream, h->d_partial, out, R, Q.ldc);
+    }
+    // per LP (oracle: eqp_ns, the part that does not depend on the working set): pbar, A pbar, u0 = Z'(p_ref - pbar), Z'q
+    void ns_lp_vectors() {
+        const int k = ns_k, nE = h->ns_nE;
+        const int64_t M = lp.M, ldn = h->ldn;
+        const NsIdx X = nsX();
+        const NsEq Q = nsq();
+        const unsigned gM = (unsigned)((M + 255) / 256), gN = (unsigned)((ldn + 255) / 256), gE = (unsigned)((nE + 255) / 256);
+        double *pfix = nsv(0), *x = nsv(1), *vz = nsv(2), *yM = nsv(5), *aM = nsv(6), *rE = nsv(8), *tE = nsv(9);
+        hipLaunchKernelGGL(k_nseq_pfix, dim3(gN), dim3(256), 0, h->stream, A, pfix, ldn);
+        dev.gemv_n_dev(h->d_Ah, pfix, aM);
+        hipLaunchKernelGGL(k_nseq_be, dim3(gE), dim3(256), 0, h->stream, A, X, (const double*)aM, rE);
+        dev.use_factor(h->ns_f0);
+        dev.chol_solve_dev(rE, tE, nE);
+        dev.use_main();
+        hipLaunchKernelGGL(k_ns_rowvec_e, dim3(gM), dim3(256), 0, h->stream, X, (const double*)tE, yM, M);
+        dev.gemv_t_dev(h->d_Ah, yM, x);
+        hipLaunchKernelGGL(k_nseq_pbar, dim3(gN), dim3(256), 0, h->stream, A, (const double*)pfix, (const double*)x, (const double*)d_zero, Q.pbar, vz, ldn);
+        dev.gemv_n_dev(h->d_Ah, Q.pbar, Q.tbar);
+        HIPCHK(hipMemsetAsync(Q.u0, 0, 2 * Q.ldc * sizeof(double), h->stream));      // u0 and qh (contiguous)
+        hipLaunchKernelGGL(k_gemv_n, dim3((unsigned)((k + 3) / 4)), dim3(256), 0, h->stream, (const double*)h->d_nsG, h->ns_ldg, (const double*)vz, Q.u0, (int64_t)k, ldn);
+        hipLaunchKernelGGL(k_gemv_n, dim3((unsigned)((k + 3) / 4)), dim3(256), 0, h->stream, (const double*)h->d_nsG, h->ns_ldg, (const double*)A.q, Q.qh, (int64_t)k, ldn);
+    }
+    // Equality-constrained solve on the working set `cur` in reduced coordinates (oracle: eqp_ns).  Leaves p, y, t = Ah p, tN = Ah' y
+    // for the tail kernel like as_solve.  False: more active constraints than the buffers hold (the caller uses as_solve).
+    bool as_solve_ns(const AsSets& cur) {
+        const int k = ns_k, nE = h->ns_nE;
+        const int64_t M = lp.M, n = lp.n, ldn = h->ldn;
+        const NsIdx X = nsX();
+        const NsEq Q = nsq();
+        const unsigned gM = (unsigned)((M + 255) / 256), gN = (unsigned)((ldn + 255) / 256), gE = (unsigned)((nE + 255) / 256);
+        hipLaunchKernelGGL(k_nseq_setup, dim3(1), dim3(1024), 0, h->stream, A, cur, X, Q, ldn);
+        int cnt[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(cnt, Q.cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        const int nact = cnt[1];
+        if (nact > h->ns_ccap) return false;
+        const unsigned gC = (unsigned)((Q.ldc + 255) / 256), gA = (unsigned)((nact + 255) / 256);
+        double *t1 = nsv(12), *t2 = nsv(13);
+        HIPCHK(hipMemcpyAsync(Q.u, Q.u0, Q.ldc * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemsetAsync(Q.lam, 0, (size_t)h->ns_ccap * sizeof(double), h->stream));
+        if (nact > 0) {
+            hipLaunchKernelGGL(k_nseq_gather, dim3(gC, (unsigned)nact), dim3(256), 0, h->stream, A, cur, X, Q, (const double*)h->d_nsG, h->ns_ldg, k, ldn);
+            dev.use_factor(h->ns_fC);
+            dev.launch_syrk(Dev::pick_tile(nact), Q.Csel, Q.ldc, nullptr, 0, nact, (int)Q.ldc, nullptr, nullptr, h->ns_fC.S, h->ns_fC.ld, 0, 0);
+            dev.diag_prepare(nact, 1, 0.0, 0.0);
+            dev.chol(nact, 1e-10);
+            for (int sw = 0; sw < 3; ++sw) {
+                nsq_gemv_n(Q, nact, Q.u, Q.v);                                                                           // C u
+                hipLaunchKernelGGL(k_nseq_sub, dim3(gA), dim3(256), 0, h->stream, (const double*)Q.d, (const double*)Q.v, Q.v, (int64_t)nact);
+                dev.chol_solve_dev(Q.v, Q.w, nact);
+                nsq_gemv_t(Q, nact, Q.w, t1);
+                hipLaunchKernelGGL(k_ns_add, dim3(gC), dim3(256), 0, h->stream, (const double*)Q.u, (const double*)t1, Q.u, Q.ldc);
+                nsq_gemv_t(Q, nact, Q.lam, t1);                                                                          // C' lam
+                hipLaunchKernelGGL(k_nseq_sub, dim3(gC), dim3(256), 0, h->stream, (const double*)Q.qh, (const double*)t1, t2, Q.ldc);
+                nsq_gemv_n(Q, nact, t2, Q.v);
+                dev.chol_solve_dev(Q.v, Q.w, nact);
+                hipLaunchKernelGGL(k_ns_add, dim3(gA), dim3(256), 0, h->stream, (const double*)Q.lam, (const double*)Q.w, Q.lam, (int64_t)nact);
+            }
+            dev.use_main();
+        }
+        double *zu = nsv(3), *atw = nsv(4), *wN = nsv(2), *yM = nsv(5), *aM = nsv(6), *rE = nsv(8), *tE = nsv(9);
+        ns_gemv_t_dense(Q.u, k, zu);
+        hipLaunchKernelGGL(k_nseq_p, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, A, cur, Q, (const double*)zu, ldn);
+        hipLaunchKernelGGL(k_nseq_yi, dim3(gM), dim3(256), 0, h->stream, A, X, Q, yM);
+        dev.gemv_t_dev(h->d_Ah, yM, atw);
+        hipLaunchKernelGGL(k_nseq_w, dim3(gN), dim3(256), 0, h->stream, A, Q, (const double*)atw, wN, ldn);
+        dev.gemv_n_dev(h->d_Ah, wN, aM);
+        hipLaunchKernelGGL(k_ns_gather_e, dim3(gE), dim3(256), 0, h->stream, X, (const double*)aM, 1.0, rE);
+        dev.use_factor(h->ns_f0);
+        dev.chol_solve_dev(rE, tE, nE);
+        dev.use_main();
+        hipLaunchKernelGGL(k_nseq_y, dim3(gM), dim3(256), 0, h->stream, A, X, (const double*)yM, (const double*)tE);
+        dev.gemv_n_dev(h->d_Ah, A.p, A.t);
+        dev.gemv_t_dev(h->d_Ah, A.y, A.tN);
+        h->stats.eqp += 1;
+        return true;
     }
     // Per iteration (oracle: IPM.run, use_ns branch): reduced matrix N = Zt Th Zt' + GI' D_I^-1 GI (an unregularised copy is kept for the
     // refinement sweep), its factor, dpbar = A_EF' S0^-1 (-rp_E) and K dpbar (shared by predictor and corrector)
@@ -1270,16 +1433,6 @@ struct Solver {
             // null-space form (oracle: IPM.run): set up once per LP, k x k factorisation per iteration
             use_ns = false;
             if (ip.ns_ok && !ip.ns_off) {
-                if (!ip.ns_ready) {
-                    ip.ns_ready = true;
-                    const size_t had = cur_hint ? cur_hint->ns_J.size() : 0;
-                    const double t0 = now_ms();
-                    const bool okn = cur_hint && ns_setup();
-                    if (!okn) ip.ns_off = true;
-                    h->stats.ns_dim = okn ? ip.ns_k : 0;
-                    h->stats.ns_cold = (okn && (had == 0 || ns_was_cold)) ? 1 : 0;
-                    if (h->verbose) std::fprintf(stderr, "[asm] null-space set-up: %s, k = %d, %s basis columns, %.2f ms\n", okn ? "ok" : "not usable", ip.ns_k, ns_was_cold ? "fresh" : "retained", now_ms() - t0);
-                }
                 use_ns = !ip.ns_off;
             }
             use_col = !use_ns && ip.col_ok && !ip.col_off;
@@ -1524,7 +1677,7 @@ struct Solver {
         int cur = 0, nx = 1, prev = 2;
         bool have_prev = false;
         for (int k = 0; k <= rounds; ++k) {
-            as_solve(S_[cur], p_ref, y_ref, 0);
+            if (!(ns_lp && p_ref == d_zero && y_ref == nullptr && as_solve_ns(S_[cur]))) as_solve(S_[cur], p_ref, y_ref, 0);
             hipLaunchKernelGGL(k_as_finish, dim3(1), dim3(1024), 0, h->stream, A, S_[cur], S_[nx], S_[prev], have_prev ? 1 : 0, TOL_P, TOL_D);
             as_read();
             const double pr = h->h_asscal[AS_PR], du = h->h_asscal[AS_DU];
@@ -1776,6 +1929,23 @@ struct Solver {
         cur_hint = &hint;
         ipm_upload_lp();
         as_begin_lp();
+        // null-space basis of the equality rows (oracle: solve_scaled): made first, the active-set solves of the warm attempt and of the
+        // polish go through it as well as the interior-point iterations
+        ns_lp = false;
+        h->stats.ns_dim = 0;
+        h->stats.ns_cold = 0;
+        if (ns_applicable()) {
+            const size_t had = hint.ns_J.size();
+            const double t0 = now_ms();
+            ns_lp = ns_setup();
+            if (ns_lp) ns_lp_vectors();
+            h->stats.ns_dim = ns_lp ? ns_k : 0;
+            h->stats.ns_cold = (ns_lp && (had == 0 || ns_was_cold)) ? 1 : 0;
+            if (h->verbose) {
+                HIPCHK(hipStreamSynchronize(h->stream));
+                std::fprintf(stderr, "[asm] null-space set-up: %s, k = %d, %s basis columns, %.2f ms\n", ns_lp ? "ok" : "not usable", ns_k, ns_was_cold ? "fresh" : "retained", now_ms() - t0);
+            }
+        }
         if (warm && warm->valid && (int64_t)warm->rowst.size() == M && (int64_t)warm->bst.size() == n && (int64_t)warm->sst.size() == ns) {
             // attempt when the last two LPs ended on the same sets or the back-off has run out (oracle: solve_scaled)
             if (!hint.stable && hint.warm_skip > 0) {
@@ -1905,10 +2075,10 @@ void free_device(asm_handle* h) {
     h->d_pflags = h->d_ptmo = nullptr;
     for (void* q : h->ns_bufs) F(q);
     h->ns_bufs.clear();
-    h->ns_cap = false; h->ns_kcap = 0;
+    h->ns_cap = false; h->ns_kcap = 0; h->ns_ccap = 0; h->ns_Zk = 0; h->ns_fC = FacBuf(); h->d_nsqi = nullptr; h->d_nsq = nullptr;
     h->d_nsEidx = h->d_nsEpos = h->d_nsIidx = h->d_nsIpos = h->d_nsJ = h->d_nscnt = nullptr;
     h->ns_f0 = FacBuf(); h->ns_fN = FacBuf();
-    h->d_nsLt = h->d_nsR = h->d_nsX = h->d_nsG = h->d_nsth = h->d_nsFm = h->d_nsv = h->d_nsYt = h->d_nsN0 = nullptr;
+    h->d_nsLt = h->d_nsR = h->d_nsX = h->d_nsG = h->d_nsth = h->d_nsFm = h->d_nsv = h->d_nsYt = h->d_nsN0 = h->d_nsZT = nullptr;
     F(h->d_as); F(h->d_as_i);
     if (h->h_ascnt) (void)hipHostFree(h->h_ascnt);
     if (h->h_asscal) (void)hipHostFree(h->h_asscal);
@@ -2170,6 +2340,7 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     HIPCHK(hipStreamSynchronize(h->stream));
     h->warm[0] = ActiveSet(); h->warm[1] = ActiveSet(); h->last = ActiveSet();
     h->hint[0] = SolveHint(); h->hint[1] = SolveHint();
+    h->ns_Zk = 0;
     h->hint[1].prefer_ref = true;     // restoration LPs usually have a non-unique optimum (oracle/subproblem.py)
     std::memset(&h->stats, 0, sizeof(h->stats));
     h->setup_done = true;
@@ -2501,6 +2672,7 @@ int asm_sublp_set_bounds(asm_handle* h, const double* c_lb, const double* c_ub, 
         }
         h->warm[0] = ActiveSet(); h->warm[1] = ActiveSet(); h->last = ActiveSet();
         h->hint[0] = SolveHint(); h->hint[1] = SolveHint();
+        h->ns_Zk = 0;
         h->hint[1].prefer_ref = true;
         h->inputs_ready = false;
     });
@@ -2558,6 +2730,7 @@ int asm_sublp_reset_warm(asm_handle* h) {
     h->warm[1] = ActiveSet();
     h->hint[0] = SolveHint();
     h->hint[1] = SolveHint();
+    h->ns_Zk = 0;
     h->hint[1].prefer_ref = true;
     return ASM_OK;
 }

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_ns_rhs_cols(const int* __restrict__ cpt
 // PJ[c, j] = Fm_j (delta(j, J[c]) - sum_{i in E, A_ij != 0} W[c, epos(i)] A_ij)      (rows of the projector P)
 __global__ __launch_bounds__(256) void k_ns_pj(const int* __restrict__ cptr, const int* __restrict__ crow, const int* __restrict__ cpos,
                                                const double* __restrict__ vals, NsIdx X, const int* __restrict__ J, const double* __restrict__ Fm,
-                                               const double* __restrict__ W, int64_t ldw, double* __restrict__ PJ, int64_t ldp, int64_t n, int64_t ldn) {
+                                               const double* __restrict__ W, int64_t ldw, double* PJ, int64_t ldp, int64_t n, int64_t ldn, int second_pass) {
     const int c = blockIdx.y;
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= ldn) return;
@@ -145,9 +145,25 @@ __global__ __launch_bounds__(256) void k_ns_pj(const int* __restrict__ cptr, con
             const int ep = X.Epos[crow[k]];
             if (ep >= 0) acc += w[ep] * vals[cpos[k]];
         }
-        v = (j == J[c] ? 1.0 : 0.0) - acc;
+        // first pass: row J[c] of the projector; second pass: the row already in PJ projected once more (z - A_EF' S0^-1 A_EF z)
+        v = (second_pass ? PJ[(int64_t)c * ldp + j] : (j == J[c] ? 1.0 : 0.0)) - acc;
     }
     PJ[(int64_t)c * ldp + j] = v;
+}
+
+// R[c, e] = sum_j A[Eidx[e], j] Zt[c, j]   (the equality rows applied to the basis rows: right-hand sides of the second projection pass)
+__global__ __launch_bounds__(256) void k_ns_rows_e(const int* __restrict__ rptr, const int* __restrict__ rcol, const double* __restrict__ vals, NsIdx X,
+                                                   const double* __restrict__ Fm, const double* __restrict__ Zt, int64_t ldz, double* __restrict__ R, int64_t ldr) {
+    const int c = blockIdx.y;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= ldr) return;
+    double acc = 0.0;
+    if (t < X.nE) {
+        const int i = X.Eidx[t];
+        const double* z = Zt + (int64_t)c * ldz;
+        for (int k = rptr[i]; k < rptr[i + 1]; ++k) acc += vals[k] * Fm[rcol[k]] * z[rcol[k]];      // A_EF: fixed columns do not count
+    }
+    R[(int64_t)c * ldr + t] = acc;
 }
 
 // T[c, d] = PJ[c, J[d]]  (d <= c; the lower triangle of P[J, J]) into the factor buffer of the small system
@@ -367,4 +383,111 @@ __global__ __launch_bounds__(1024) void k_ns_err(const double* __restrict__ th, 
         if (th[j] != 0.0) m = fmax(m, fabs(th[j] * dp[j] - aty[j] - hp[j]));
     m = blk_reduce_max(m, sh);
     if (threadIdx.x == 0) slot[0] = m;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Active-set (equality-constrained) solves in the reduced coordinates - oracle/lp_solver.py: eqp_ns.
+// Working set of a normal-phase LP = the equality rows (always) + bound-active non-fixed variables B + active inequality rows Ia:
+// nact constraints C u = d on p = pbar + Z u, rows of C = columns sel[] of Gt (bounds: column j; rows: column ldn + ipos).
+struct NsEq {
+    int *sel, *bpos, *rpos, *cnt;     // constraint -> column of Gt ; variable -> constraint (-1) ; position in I -> constraint (-1) ; {nB, nact}
+    double *Csel, *d, *u, *lam, *v, *w, *pbar, *tbar, *u0, *qh;
+    int64_t ldc;                      // pitch of Csel (>= k, multiple of 32)
+};
+// ordered compaction of the working set (one workgroup): bounds by variable index, then inequality rows by index; ksoft := -1
+__global__ __launch_bounds__(1024) void k_nseq_setup(AsPtrs A, AsSets S, NsIdx X, NsEq Q, int64_t ldn) {
+    __shared__ int sh_cnt[16];
+    int base = 0;
+    for (int64_t j0 = 0; j0 < A.n; j0 += 1024) {
+        const int64_t j = j0 + threadIdx.x;
+        const bool f = j < A.n && S.bst[j] != 0 && A.ub[j] > A.lb[j];
+        const int pos = blk_compact_pos(f, base, sh_cnt);
+        if (j < A.n) Q.bpos[j] = f ? pos : -1;
+        if (f) Q.sel[pos] = (int)j;
+    }
+    const int nB = base;
+    for (int t0 = 0; t0 < X.nI; t0 += 1024) {
+        const int t = t0 + threadIdx.x;
+        const bool f = t < X.nI && S.rowst[X.Iidx[t]] == 1;
+        const int pos = blk_compact_pos(f, base, sh_cnt);
+        if (t < X.nI) Q.rpos[t] = f ? pos : -1;
+        if (f) Q.sel[pos] = (int)ldn + t;
+    }
+    for (int64_t i = threadIdx.x; i < A.M; i += 1024) A.ksoft[i] = -1;
+    if (threadIdx.x == 0) { Q.cnt[0] = nB; Q.cnt[1] = base; }
+}
+// Csel[a, c] = Gt[c, sel[a]]  (c < k; zero in the padding columns) and the right-hand side d[a]
+__global__ __launch_bounds__(256) void k_nseq_gather(AsPtrs A, AsSets S, NsIdx X, NsEq Q, const double* __restrict__ Gt, int64_t ldg, int k, int64_t ldn) {
+    const int a = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int col = Q.sel[a];
+    if (c < Q.ldc) Q.Csel[(int64_t)a * Q.ldc + c] = c < k ? Gt[(int64_t)c * ldg + col] : 0.0;
+    if (c == 0) {
+        double dv;
+        if (col < ldn) dv = (S.bst[col] < 0 ? A.lb[col] : A.ub[col]) - Q.pbar[col];
+        else { const int i = X.Iidx[col - ldn]; dv = A.r[i] - Q.tbar[i]; }
+        Q.d[a] = dv;
+    }
+}
+// pfix: fixed columns at their value, zero elsewhere
+__global__ __launch_bounds__(256) void k_nseq_pfix(AsPtrs A, double* __restrict__ pfix, int64_t ldn) {
+    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < ldn) pfix[j] = (j < A.n && !(A.ub[j] > A.lb[j])) ? A.lb[j] : 0.0;
+}
+// out[e] = r[Eidx[e]] - aM[Eidx[e]]
+__global__ __launch_bounds__(256) void k_nseq_be(AsPtrs A, NsIdx X, const double* __restrict__ aM, double* __restrict__ out) {
+    int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < X.nE) out[t] = A.r[X.Eidx[t]] - aM[X.Eidx[t]];
+}
+// pbar = pfix + (masked) x ;  vz = Fm (clip0 - pbar)   (input of u0 = Zt vz)
+__global__ __launch_bounds__(256) void k_nseq_pbar(AsPtrs A, const double* __restrict__ pfix, const double* __restrict__ x, const double* __restrict__ zero,
+                                                   double* __restrict__ pbar, double* __restrict__ vz, int64_t ldn) {
+    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= ldn) return;
+    const bool fr = j < A.n && A.ub[j] > A.lb[j];
+    const double pb = pfix[j] + (fr ? x[j] : 0.0);
+    pbar[j] = pb;
+    vz[j] = fr ? zero[j] - pb : 0.0;
+}
+// out = a - b  (len)
+__global__ __launch_bounds__(256) void k_nseq_sub(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out, int64_t len) {
+    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < len) out[t] = a[t] - b[t];
+}
+// p = pbar + Z u on the free columns, bound-active variables exactly on their bound, fixed columns at their value
+__global__ __launch_bounds__(256) void k_nseq_p(AsPtrs A, AsSets S, NsEq Q, const double* __restrict__ zu, int64_t ldn) {
+    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= A.n) return;
+    double v;
+    if (!(A.ub[j] > A.lb[j])) v = A.lb[j];
+    else if (Q.bpos[j] >= 0) v = S.bst[j] < 0 ? A.lb[j] : A.ub[j];
+    else v = Q.pbar[j] + zu[j];
+    A.p[j] = v;
+}
+// y on the inequality rows: the multiplier of the row's constraint (0 when inactive); zero on the equality rows
+__global__ __launch_bounds__(256) void k_nseq_yi(AsPtrs A, NsIdx X, NsEq Q, double* __restrict__ yM) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= A.M) return;
+    const int ip = X.Ipos[i];
+    double v = 0.0;
+    if (ip >= 0 && Q.rpos[ip] >= 0) v = Q.lam[Q.rpos[ip]];
+    yM[i] = v;
+}
+// w = Fm (q - A_Ia' y_Ia) - z_B
+__global__ __launch_bounds__(256) void k_nseq_w(AsPtrs A, NsEq Q, const double* __restrict__ atw, double* __restrict__ w, int64_t ldn) {
+    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= ldn) return;
+    double v = 0.0;
+    if (j < A.n && A.ub[j] > A.lb[j]) {
+        v = A.q[j] - atw[j];
+        if (Q.bpos[j] >= 0) v -= Q.lam[Q.bpos[j]];
+    }
+    w[j] = v;
+}
+// y = yM with the equality rows from tE
+__global__ __launch_bounds__(256) void k_nseq_y(AsPtrs A, NsIdx X, const double* __restrict__ yM, const double* __restrict__ tE) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= A.M) return;
+    const int ep = X.Epos[i];
+    A.y[i] = ep >= 0 ? tE[ep] : yM[i];
 }

@@ -66,14 +66,18 @@ HBM_PEAK_GBS = 8000.0
 WORKLOADS = {
     # name: (description, default algorithm, default steps, default warmup)
     "c4": dict(desc="ACOPF case1354pegase-sized synthetic grid (1354 bus / 260 gen / 1991 branch; BASELINE.json configs[3], "
-                    "the case the metric is quoted on; real case file not shipped with the reference), n=11192 m=18637",
-               algorithm="Line Search", steps=20, warmup=2),
+                    "the case the metric is quoted on; real case file not shipped with the reference), load scale 0.5 - the instance whose "
+                    "Line-Search SLP run terminates (status 0 after 76 iterations, all LPs in the normal phase), n=11192 m=18637",
+               algorithm="Line Search", steps=20, warmup=2, case="case1354pegase", load_scale=0.5),
+    "c4fr": dict(desc="the same grid at the nominal synthetic load (scale 1.0): the SLP run never leaves feasibility restoration - every "
+                      "timed step is a restoration LP (min sum of slacks, non-unique optimum); round-1/2 headline workload, n=11192 m=18637",
+                 algorithm="Line Search", steps=20, warmup=2, case="case1354pegase", load_scale=1.0),
     "c5": dict(desc="batch of scenario ACOPF, case300-sized synthetic grid (300 bus / 69 gen / 411 branch), load_scale 0.5, loads x U(0.9,1.1) per "
                     "scenario (BASELINE.json configs[4] has 512 scenarios over 8 GPUs = 64 per GPU; --scenarios-per-gpu sets the share), "
                     "n=2382 m=3889; one step = one complete scenario solve",
                algorithm="Line Search", steps=64, warmup=1),
     "c3": dict(desc="ACOPF case118-sized synthetic grid (118 bus / 54 gen / 186 branch; BASELINE.json configs[2]), n=1088 m=1725",
-               algorithm="Line Search", steps=10, warmup=2),
+               algorithm="Line Search", steps=10, warmup=2, case="case118", load_scale=1.0),
     "c2": dict(desc="synthetic dense NLP n=1000 m=500 (BASELINE.json configs[1])", algorithm="Trust Region", steps=20, warmup=3),
     "c2small": dict(desc="synthetic dense NLP n=200 m=100 (reduced; parity-test size)", algorithm="Trust Region", steps=20, warmup=3),
 }
@@ -147,9 +151,10 @@ def make_problem(name, device_eval=True):
     what --host-eval runs and what the CPU baselines evaluate with (the FunctionModel's own host evaluator is a term-by-term
     Python loop, fine as a checker, unfair as a baseline)."""
     from activesetmethods_amd import problems, acopf
-    if name in ("c3", "c4"):
-        case = acopf.synthetic_case("case1354pegase" if name == "c4" else "case118", 1)
-        label = "case1354pegase-sized" if name == "c4" else "case118-sized"
+    if name in ("c3", "c4", "c4fr"):
+        wl = WORKLOADS[name]
+        case = acopf.synthetic_case(wl["case"], 1, wl["load_scale"])
+        label = "%s-sized, load scale %g" % (wl["case"], wl["load_scale"])
         host = acopf.acopf_problem(case, label)
         return (acopf.function_model(case).to_problem(label) if device_eval else host), host
     n, m = (1000, 500) if name == "c2" else (200, 100)
@@ -424,7 +429,9 @@ def main():
 
     nfact = ks["chol"]["calls"]
     # HBM bytes per launch of the dominant kernel from the committed PMC passes (cannot be collected inside bench)
-    tpath = os.path.join(ROOT, "profiles", "r02_%s_pmc_traffic.json" % args.workload)
+    tpath = os.path.join(ROOT, "profiles", "r03_%s_pmc_traffic.json" % args.workload)
+    if not os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "r02_%s_pmc_traffic.json" % ("c4" if args.workload == "c4fr" else args.workload))
     if roof["bound"] == "mfma" and os.path.exists(tpath):
         tj = json.load(open(tpath))
         roof["traffic"] = tj["traffic_bytes_per_launch"]
@@ -451,6 +458,17 @@ def main():
         for r in timed:
             key = names.get(r["stats"]["path"], str(r["stats"]["path"])) + ("/fr" if r["fr"] else "")
             hist[key] = hist.get(key, 0) + 1
+        def _mean(v):
+            return (sum(v) / len(v)) if v else None
+        nm = [r for r in timed if not r["fr"]]
+        frs = [r for r in timed if r["fr"]]
+        out["phases"] = {      # restoration solves reported separately (LP wall time inside the library, per LP)
+            "normal_lps": len(nm), "restoration_lps": len(frs),
+            "lp_ms_normal": _mean([r["stats"]["wall_ms"] for r in nm]), "lp_ms_restoration": _mean([r["stats"]["wall_ms"] for r in frs]),
+            "ipm_iterations_per_lp": _mean([r["stats"]["ipm_iters"] for r in timed]),
+            "null_space_iterations_per_lp": _mean([r["stats"].get("ns_iters", 0) for r in timed]),
+            "null_space_dimension": max([r["stats"].get("ns_dim", 0) for r in timed], default=0),
+            "factorisations_per_lp_all_sizes": _mean([r["stats"]["nfact"] for r in timed])}
         out["lp_outcomes"] = {"paths": hist, "unpolished": sum(1 for r in timed if r["stats"]["polished"] != 1),
                               "status_other": sum(1 for r in timed if r["status"] not in (1, 2)),
                               "restoration_lps": sum(1 for r in timed if r["fr"]),

@@ -57,7 +57,8 @@ NS_MIN_E = 64         # null-space form (normal phase): fewest hard equality row
 NS_MAX_RATIO = 0.3    # pivot thresholds of the basis-column selection (first one that yields a full basis), pivot threshold
 NS_SEL_THR = (1e-2, 1e-4, 1e-7, 1e-10)    # for re-using the previous LP's basis columns,
 NS_WARM_THR = 1e-6    # share of the stage tolerance / of the current dual infeasibility the dual-equation error of a step may
-NS_DERR = 0.1         # reach before the LP returns to the row form
+NS_DERR = 0.1         # reach before the LP returns to the row form; smallest Gram pivot for re-using the previous LP's basis
+NS_ZWARM_THR = 0.25
 CHOL_NB = 64
 PIV_BIG = 1e128
 
@@ -191,7 +192,9 @@ class NullSpace:
 
       S0 = A_EF A_EF'            factored ONCE per LP (guarded Cholesky: a dependent equality row is dropped)
       P  = I_F - A_EF' S0^-1 A_EF  projector onto null(A_EF) inside the free columns
-      J  = k columns with  P[:, J]  of full rank: the previous LP's J when P[J, J] still factors with pivots above
+      J  = k columns with  P[:, J]  of full rank (only needed when the previous LP's basis Z cannot be re-used: Z_prev projected onto
+           this LP's null space and re-orthonormalised - accepted when its Gram matrix factors with pivots above NS_ZWARM_THR): the
+           previous LP's J when P[J, J] still factors with pivots above
            NS_WARM_THR (the retained basis - what a simplex code keeps between solves, slp.jl:38-40), else selected by a
            guarded Cholesky of P in index order (a column whose pivot falls below the threshold is skipped; thresholds
            NS_SEL_THR are tried in turn until exactly k columns remain)
@@ -199,7 +202,7 @@ class NullSpace:
       GI = A_I Z                 (inequality rows in the reduced coordinates)
     `valid` is False when no full basis is found (the caller keeps the row form)."""
 
-    def __init__(self, lp, warm_J=None):
+    def __init__(self, lp, warm_J=None, warm_Z=None):
         A, n = lp.A, lp.n
         self.E = np.nonzero(lp.rtype == 0)[0]
         self.I = np.nonzero(lp.rtype != 0)[0]
@@ -233,12 +236,34 @@ class NullSpace:
             self.nfact += 1
             if (np.diag(LJ) >= 0.5 * PIV_BIG).any():
                 return None
-            return solve_triangular(LJ, PJ, lower=True)
+            Z0 = solve_triangular(LJ, PJ, lower=True)
+            # second pass ("twice is enough"): the columns J picked in index order can be badly conditioned (cond(L_J) ~ 1e4), which
+            # leaves A_EF Z ~ 1e-10 and Z'Z - I ~ 1e-6 - fine for the interior-point steps, not for the active-set solves that must
+            # hold the equality rows to 1e-13.  Project the rows once more and orthonormalise with their own Gram matrix (~ I).
+            Z1 = (Z0 - chol_solve(self.L0, AEF @ Z0.T).T @ AEF) * self.Fm
+            G1 = np.tril(Z1 @ Z1.T)
+            L1 = _chol_guard_loop(G1 + np.tril(G1, -1).T, np.ones(len(J)), NS_WARM_THR)
+            self.nfact += 1
+            if (np.diag(L1) >= 0.5 * PIV_BIG).any():
+                return None
+            return solve_triangular(L1, Z1, lower=True)
 
         Zt = None
-        if warm_J is not None and len(warm_J) == k and np.all(self.Fm[warm_J] > 0):
-            J = np.asarray(warm_J, np.int64)
+        self.how = 'cold'
+        J = None if warm_J is None else np.asarray(warm_J, np.int64)
+        if warm_Z is not None and warm_Z.shape == (k, n):
+            # the previous LP's orthonormal basis, projected onto this LP's null space (one pass: its Gram matrix is close to I)
+            Z1 = (warm_Z - chol_solve(self.L0, AEF @ warm_Z.T).T @ AEF) * self.Fm
+            G1 = np.tril(Z1 @ Z1.T)
+            L1 = _chol_guard_loop(G1 + np.tril(G1, -1).T, np.ones(k), NS_ZWARM_THR)
+            self.nfact += 1
+            if not (np.diag(L1) >= 0.5 * PIV_BIG).any():
+                Zt = solve_triangular(L1, Z1, lower=True)
+                self.how = 'basis'
+        if Zt is None and J is not None and len(J) == k and np.all(self.Fm[J] > 0):
             Zt = basis_from(J)
+            if Zt is not None:
+                self.how = 'columns'
         if Zt is None:
             self.cold = True
             Y = solve_triangular(self.L0, AEF, lower=True)           # L0^-1 A_EF  (nE x n)
@@ -266,7 +291,7 @@ class IPM:
     lengths, Schur (row) form.
     Resumable: `run(tol, max_more)` continues from the current iterate."""
 
-    def __init__(self, lp, ns_J=None):
+    def __init__(self, lp, ns_J=None, nsp=None):
         self.lp = lp
         M, n, ns = lp.M, lp.n, lp.ns
         self.ineq = lp.rtype != 0
@@ -308,8 +333,11 @@ class IPM:
         self.ns_ok = bool(ns == 0 and nE >= NS_MIN_E and nF - nE <= NS_MAX_RATIO * M and n <= M and np.count_nonzero(lp.A) * 16 <= M * n)
         self.ns_off = False
         self.ns_iters = 0
-        self.ns = None
+        self.ns = nsp                 # prebuilt by the caller (solve_scaled: the active-set solves use it as well) or made at the first iteration
         self.ns_J = ns_J              # basis columns retained from the previous LP of the phase (in), of this LP (out)
+        if nsp is not None:
+            self.ns_J = nsp.J
+            self.ns_ok = self.ns_ok and nsp.valid
 
     def measures(self):
         lp, ineq, sg, free = self.lp, self.ineq, self.sg, self.free
@@ -615,6 +643,58 @@ def identify(lp, o):
     return rowst, bst, sst
 
 
+def ns_applicable(lp):
+    """The LP qualifies for the null-space form: normal phase, many hard equality rows, small null space, sparse matrix."""
+    M, n = lp.M, lp.n
+    nE = int((lp.rtype == 0).sum())
+    nF = int((lp.ub > lp.lb).sum())
+    return bool(lp.ns == 0 and nE >= NS_MIN_E and nF - nE <= NS_MAX_RATIO * M and n <= M and np.count_nonzero(lp.A) * 16 <= M * n)
+
+
+def eqp_ns(lp, nsp, sets, sweeps=3):
+    """`eqp` with p_ref = 0 clipped into the box and y_ref = 0 for a normal-phase LP, through the null-space basis of the equality
+    rows (class NullSpace): the equality rows are in every working set, so a working set is the bound-active variables B (not
+    fixed ones) and the active inequality rows Ia, i.e. nact <= ~k constraints  C u = d  on the reduced coordinates u
+    ( p = pbar + Z u ):   rows of C = rows B of Z, then rows Ia of A_I Z,   d = (bound - pbar_B, r_Ia - A_Ia pbar).
+       primal:  u = u0 + C'(CC')^-1 (d - C u0),  u0 = Z'(p_ref - pbar)        (the point of aff(W) closest to p_ref)
+       dual:    (z_B, y_Ia) = (CC')^-1 C Z'q,   y_E = S0^-1 A_EF (q - A_Ia'y_Ia - z)   (least-squares multipliers)
+    with `sweeps` refinement sweeps on the guarded factor of the nact x nact Gram matrix CC' (a constraint that depends on
+    earlier ones - bounds first, by index, then rows - is dropped: multiplier 0).  Two solves with the factor of S0."""
+    rowst, bst, _ = sets
+    A, n, M = lp.A, lp.n, lp.M
+    Fm = nsp.Fm
+    B = np.nonzero((bst != 0) & (Fm > 0))[0]
+    ia_mask = (rowst[nsp.I] == 1)
+    Ia = nsp.I[ia_mask]
+    beta = np.where(bst < 0, lp.lb, lp.ub)
+    pfix = np.where(Fm > 0, 0.0, lp.lb)
+    pbar = pfix + nsp.AEF.T @ chol_solve(nsp.L0, lp.r[nsp.E] - A[nsp.E] @ pfix)
+    zero_p = np.clip(np.zeros(n), lp.lb, lp.ub) * Fm
+    u = nsp.Zt @ (zero_p - pbar * Fm)
+    C = np.vstack([nsp.Zt[:, B].T, nsp.GI[ia_mask]])
+    nact = C.shape[0]
+    nfact = 0
+    lam = np.zeros(nact)
+    if nact:
+        d = np.concatenate([beta[B] - pbar[B], lp.r[Ia] - A[Ia] @ pbar])
+        G = C @ C.T
+        idx = np.arange(nact)
+        Lc = chol_guard(G, G[idx, idx].copy(), 1e-10)
+        nfact = 1
+        qh = nsp.Zt @ lp.q
+        for _ in range(sweeps):
+            u = u + C.T @ chol_solve(Lc, d - C @ u)
+            lam = lam + chol_solve(Lc, C @ (qh - C.T @ lam))
+    p = pbar + (nsp.Zt.T @ u) * Fm
+    p[B] = beta[B]
+    y = np.zeros(M)
+    y[Ia] = lam[len(B):]
+    w = (lp.q - A[Ia].T @ lam[len(B):]) * Fm
+    w[B] -= lam[:len(B)]
+    y[nsp.E] = chol_solve(nsp.L0, nsp.AEF @ w)
+    return p, lp.slo.copy(), y, nfact
+
+
 def eqp(lp, sets, p_ref, y_ref, refine=4):
     """Equality-constrained solve on the active set (rowst, bst, sst):
        rows H (active, no basic slack) hold with equality, bound-active variables sit on their bound,
@@ -724,11 +804,12 @@ def _same(a, b):
     return all(np.array_equal(x, y) for x, y in zip(a, b))
 
 
-def eqp_loop(lp, sets, p_ref, y_ref, rounds, stats):
+def eqp_loop(lp, sets, p_ref, y_ref, rounds, stats, nsp=None):
+    """`nsp`: the LP's NullSpace - the solves then go through it (eqp_ns; only with the reference point of the unique-optimum polish)."""
     prev = None
     p = s = y = None
     for k in range(rounds + 1):
-        p, s, y, nf = eqp(lp, sets, p_ref, y_ref)
+        p, s, y, nf = eqp_ns(lp, nsp, sets) if nsp is not None else eqp(lp, sets, p_ref, y_ref)
         stats['nfact'] += nf
         stats['eqp'] += 1
         pr, du = kkt_measures(lp, p, s, y, sets)
@@ -1125,6 +1206,19 @@ def solve_scaled(lp, warm=None, stats=None, hint=None):
     stats.update(nfact=0, eqp=0, ipm_iters=0, path='', polished=1)
     zero_p = np.clip(np.zeros(lp.n), lp.lb, lp.ub)
     zero_y = np.zeros(lp.M)
+    # null-space basis of the equality rows (normal-phase LPs that qualify): made first, because the active-set solves of the warm
+    # attempt and of the polish go through it as well as the interior-point iterations
+    nsp = None
+    stats['ns_fact'] = 0
+    if ns_applicable(lp):
+        nsp = NullSpace(lp, hint.get('ns_J'), hint.get('ns_Z'))
+        stats['nfact'] += nsp.nfact
+        stats['ns_fact'] = nsp.nfact
+        stats['ns_cold'] = int(nsp.cold)
+        hint['ns_J'] = nsp.J
+        hint['ns_Z'] = nsp.Zt if nsp.valid else None
+        if not nsp.valid:
+            nsp = None
     if warm is not None and len(warm[0]) == lp.M and len(warm[1]) == lp.n and len(warm[2]) == lp.ns:
         # attempt when the last two LPs of this phase ended on the same sets ('stable', set by the caller) or when the
         # back-off has run out; the first re-solve of a phase is not attempted (warm_skip starts at 1): early in an SLP
@@ -1132,7 +1226,7 @@ def solve_scaled(lp, warm=None, stats=None, hint=None):
         if not hint.get('stable', False) and hint.get('warm_skip', 1) > 0:
             hint['warm_skip'] = hint.get('warm_skip', 1) - 1
         else:
-            ok, p, s, y, sets = eqp_loop(lp, warm, zero_p, zero_y, 1, stats)
+            ok, p, s, y, sets = eqp_loop(lp, warm, zero_p, zero_y, 1, stats, nsp)
             if ok:
                 hint['warm_fail'] = 0
                 hint['warm_skip'] = 0
@@ -1142,7 +1236,9 @@ def solve_scaled(lp, warm=None, stats=None, hint=None):
             hint['warm_skip'] = 2 ** hint['warm_fail'] - 1          # 1, 3, 7 solves
             hint['stable'] = False
     prefer_ref = bool(hint.get('prefer_ref', False))
-    ip = IPM(lp, hint.get('ns_J'))
+    ip = IPM(lp, hint.get('ns_J'), nsp)
+    if nsp is None:
+        ip.ns_ok = False
     sets0 = None
     for stage, (tol, more) in enumerate(IPM_STAGES):
         st = ip.run(tol, more)
@@ -1151,7 +1247,6 @@ def solve_scaled(lp, warm=None, stats=None, hint=None):
         stats['col_iters'] = ip.col_iters
         stats['red_iters'] = ip.red_iters
         stats['ns_iters'] = ip.ns_iters
-        hint['ns_J'] = ip.ns_J
         if st == INFEASIBLE:
             stats['path'] = 'ipm-infeasible'
             return INFEASIBLE, None, None, None, None
@@ -1161,7 +1256,7 @@ def solve_scaled(lp, warm=None, stats=None, hint=None):
             pinf, dinf, gap = ip.log[-1][1:]
             if pinf <= 1e-3 and dinf <= 1e-3 and gap <= 1e-4:
                 sets0 = identify(lp, ip)
-                ok, p, s, y, sets = eqp_loop(lp, sets0, zero_p, zero_y, 3, stats)
+                ok, p, s, y, sets = eqp_loop(lp, sets0, zero_p, zero_y, 3, stats, nsp)
                 if ok:
                     stats['path'] = 'ipm~+ln'
                     return OPTIMAL, p, s, y, sets
@@ -1179,7 +1274,7 @@ def solve_scaled(lp, warm=None, stats=None, hint=None):
                 stats['path'] = 'ipm+' + how
                 return OPTIMAL, p, s, y, sets
             continue
-        ok, p, s, y, sets = eqp_loop(lp, sets0, zero_p, zero_y, 2, stats)
+        ok, p, s, y, sets = eqp_loop(lp, sets0, zero_p, zero_y, 2, stats, nsp)
         if ok:
             stats['path'] = 'ipm%d+ln' % stage
             return OPTIMAL, p, s, y, sets
@@ -1204,7 +1299,7 @@ def solve_scaled(lp, warm=None, stats=None, hint=None):
             return OPTIMAL, p, s, y, sets
         hint['prefer_ref'] = False
         if prefer_ref:                              # the least-norm polish has not been tried on this LP yet
-            ok, p, s, y, sets = eqp_loop(lp, sets0, zero_p, zero_y, 2, stats)
+            ok, p, s, y, sets = eqp_loop(lp, sets0, zero_p, zero_y, 2, stats, nsp)
             if ok:
                 stats['path'] = 'ipm%d+ln' % (len(IPM_STAGES) - 1)
                 return OPTIMAL, p, s, y, sets
