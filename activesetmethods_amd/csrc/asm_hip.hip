@@ -48,7 +48,7 @@ const int RED_MIN_M = 4096, RED_MAX_CG = 10;
 const double RED_TAU = 100.0, RED_MIN_FRAC = 0.1;
 // null-space form of the normal-phase Newton system (oracle/lp_solver.py: NS_*)
 const int NS_MIN_E = 64;
-const double NS_MAX_RATIO = 0.3, NS_WARM_THR = 1e-6, NS_ZWARM_THR = 0.25, NS_BIG = 0.5e128, NS_DERR = 0.1;
+const double NS_MAX_RATIO = 0.3, NS_WARM_THR = 1e-6, NS_ZWARM_THR = 0.25, NS_BIG = 0.5e128, NS_RERR = 1e-6;
 const double NS_SEL_THR[4] = {1e-2, 1e-4, 1e-7, 1e-10};
 const int PCG_MAXIT = 20;       // conjugate-gradient steps per Newton solve (preconditioner = the Cholesky factor)
 const double PCG_KAPPA = 1e-3;  // Newton-system residual tolerance relative to the current primal residual
@@ -824,6 +824,7 @@ struct Solver {
         int red_iters = 0;
         bool ns_ok = false, ns_off = false, ns_ready = false;   // null-space form (normal phase, many hard equality rows)
         int ns_iters = 0, ns_k = 0;
+        bool ns_e_ready = false;  // the component e of the iterate outside pbar + null(A_EF) has been split off
         int iters = 0;
         int status = ASM_OTHER;
         double mu = 0, pinf = 0, dinf = 0, gap = 0, ymax = 0, rpmax = 0;
@@ -928,7 +929,14 @@ struct Solver {
         dev.gemv_n_dev(h->d_Ah, P.p, P.act);
         dev.gemv_t_dev(h->d_Ah, P.y, P.aty);
         const unsigned pub = pub_next();
-        hipLaunchKernelGGL(k_ipm_measures, dim3(1), dim3(1024), 0, h->stream, P, pub);
+        if (ns_live()) {
+            // null-space form: the equality rows' multipliers are carried as 0, the dual residual that counts is Z'rdp (oracle: IPM.measures)
+            hipLaunchKernelGGL(k_ipm_measures, dim3(1), dim3(1024), 0, h->stream, P, 0u);
+            hipLaunchKernelGGL(k_gemv_n, dim3((unsigned)((ip.ns_k + 3) / 4)), dim3(256), 0, h->stream, (const double*)h->d_nsG, h->ns_ldg, (const double*)P.rdp, nsv(12), (int64_t)ip.ns_k, h->ldn);
+            hipLaunchKernelGGL(k_ns_dinf, dim3(1), dim3(1024), 0, h->stream, P, (const double*)nsv(12), ip.ns_k, pub);
+        } else {
+            hipLaunchKernelGGL(k_ipm_measures, dim3(1), dim3(1024), 0, h->stream, P, pub);
+        }
         read_scal(pub);
         ip.pinf = h->h_scal[SC_PINF];
         ip.dinf = h->h_scal[SC_DINF];
@@ -1149,7 +1157,7 @@ struct Solver {
         if (which < 5) return h->d_nsv + (int64_t)which * h->ldn;
         if (which < 8) return h->d_nsv + 5 * h->ldn + (int64_t)(which - 5) * h->Mp;
         if (which < 10) return h->d_nsv + 5 * h->ldn + 3 * h->Mp + (int64_t)(which - 8) * h->ns_nEp;
-        return h->d_nsv + 5 * h->ldn + 3 * h->Mp + 2 * h->ns_nEp + (int64_t)(which - 10) * h->ldn;
+        return h->d_nsv + 5 * h->ldn + 3 * h->Mp + 2 * h->ns_nEp + (int64_t)(which - 10) * h->ldn;      // 10..13 k-sized, 14..15 n-sized (14 = e)
     }
     // oracle: ns_applicable
     bool ns_applicable() const {
@@ -1258,6 +1266,22 @@ struct Solver {
         h->stats.eqp += 1;
         return true;
     }
+    bool ns_live() const { return ip.ns_ok && !ip.ns_off; }
+    // least-squares multipliers of the equality rows for the current iterate (oracle: IPM.ns_finish_y); P.rdp is the dual residual of the last
+    // measures (with the equality multipliers as they stand: 0, or the values recovered at the end of the previous stage)
+    void ns_finish_y() {
+        const int nE = h->ns_nE;
+        const NsIdx X = nsX();
+        const unsigned gE = (unsigned)((nE + 255) / 256);
+        double *aM = nsv(6), *rE = nsv(8), *tE = nsv(9);
+        dev.gemv_n_dev(h->d_Ah, P.rdp, aM);
+        hipLaunchKernelGGL(k_ns_gather_e, dim3(gE), dim3(256), 0, h->stream, X, (const double*)aM, 1.0, rE);
+        dev.use_factor(h->ns_f0);
+        dev.chol_solve_dev(rE, tE, nE);
+        dev.use_main();
+        // P.rdp already contains -A_E'y_E of the multipliers recovered at the end of an earlier stage: the solve gives the correction
+        hipLaunchKernelGGL(k_ns_scatter_e, dim3(gE), dim3(256), 0, h->stream, X, (const double*)tE, P.y, 1);
+    }
     // Per iteration (oracle: IPM.run, use_ns branch): reduced matrix N = Zt Th Zt' + GI' D_I^-1 GI (an unregularised copy is kept for the
     // refinement sweep), its factor, dpbar = A_EF' S0^-1 (-rp_E) and K dpbar (shared by predictor and corrector)
     void ns_iter_setup() {
@@ -1276,21 +1300,26 @@ struct Solver {
         hipLaunchKernelGGL(k_ns_copy_lower, dim3((unsigned)((k + 255) / 256), (unsigned)k), dim3(256), 0, h->stream, (const double*)h->ns_fN.S, h->ns_fN.ld, h->d_nsN0, h->ns_fN.ld, k);
         dev.diag_prepare(k, 0, 1e-13, 1e-30);
         dev.chol(k);
-        hipLaunchKernelGGL(k_ns_gather_e, dim3(gE), dim3(256), 0, h->stream, X, (const double*)P.rp, -1.0, rE);
-        dev.use_factor(h->ns_f0);
-        dev.chol_solve_dev(rE, tE, nE);
-        dev.use_main();
-        hipLaunchKernelGGL(k_ns_rowvec_e, dim3(gM), dim3(256), 0, h->stream, X, (const double*)tE, yM, M);
-        dev.gemv_t_dev(h->d_Ah, yM, dpb);
-        hipLaunchKernelGGL(k_ns_mask, dim3(gN), dim3(256), 0, h->stream, dpb, th, ldn);
+        // dpbar = -e: the component of the iterate outside pbar + null(A_EF), split off once per LP and shrunk by (1 - a) with every step
+        double* e = nsv(14);
+        if (!ip.ns_e_ready) {
+            ip.ns_e_ready = true;
+            double *d0 = nsv(2), *zz = nsv(3), *tk = nsv(12);
+            hipLaunchKernelGGL(k_ns_e0, dim3(gN), dim3(256), 0, h->stream, P, (const double*)nsq().pbar, d0, ldn);
+            hipLaunchKernelGGL(k_gemv_n, dim3((unsigned)((k + 3) / 4)), dim3(256), 0, h->stream, (const double*)h->d_nsG, h->ns_ldg, (const double*)d0, tk, (int64_t)k, ldn);
+            ns_gemv_t_dense(tk, k, zz);
+            hipLaunchKernelGGL(k_ns_e1, dim3(gN), dim3(256), 0, h->stream, P, (const double*)d0, (const double*)zz, e, ldn);
+        }
+        hipLaunchKernelGGL(k_ns_neg, dim3(gN), dim3(256), 0, h->stream, (const double*)e, dpb, ldn);
+        HIPCHK(hipMemsetAsync(P.scal + SC_NSERR, 0, sizeof(double), h->stream));
         dev.gemv_n_dev(h->d_Ah, dpb, aM);
         hipLaunchKernelGGL(k_ns_wm, dim3(gM), dim3(256), 0, h->stream, X, thI, (const double*)aM, yM, M);
         dev.gemv_t_dev(h->d_Ah, yM, atw);
         hipLaunchKernelGGL(k_ns_kx, dim3(gN), dim3(256), 0, h->stream, th, (const double*)dpb, (const double*)atw, (const double*)nullptr, kdpb, ldn);
     }
-    // One Newton solve in null-space form (oracle: IPM.run, solve_ns): mode 0 affine, 1 Mehrotra corrector on `base`.  want_dy: recover the
-    // multipliers of the equality rows (one solve with the factor of S0) and record the dual-equation error of the step in SC_NSERR.
-    void ns_newton(int mode, const IpmDir& base, IpmDir& D, bool want_dy) {
+    // One Newton solve in null-space form (oracle: IPM.run, solve_ns): mode 0 affine, 1 Mehrotra corrector on `base`.  The relative residual of
+    // the reduced solve (after its refinement sweep) is accumulated in SC_NSERR.
+    void ns_newton(int mode, const IpmDir& base, IpmDir& D) {
         const int k = ip.ns_k, nE = h->ns_nE;
         const int64_t M = lp.M, n = lp.n, ldn = h->ldn;
         const NsIdx X = nsX();
@@ -1311,21 +1340,12 @@ struct Solver {
         dev.chol_solve_dev(rr, dd, k);
         dev.use_main();
         hipLaunchKernelGGL(k_ns_add, dim3(gK), dim3(256), 0, h->stream, (const double*)du, (const double*)dd, du, (int64_t)k);
+        hipLaunchKernelGGL(k_ns_symv_res, dim3((unsigned)((k + 3) / 4)), dim3(256), 0, h->stream, (const double*)h->d_nsN0, h->ns_fN.ld, k, (const double*)du, (const double*)ru, rr);
+        hipLaunchKernelGGL(k_ns_relres, dim3(1), dim3(1024), 0, h->stream, (const double*)rr, (const double*)ru, k, P.scal + SC_NSERR);
         ns_gemv_t_dense(du, k, v);
         hipLaunchKernelGGL(k_ns_dp, dim3(gN), dim3(256), 0, h->stream, P, D, th, (const double*)dpb, res, (const double*)v, ldn);
         dev.gemv_n_dev(h->d_Ah, D.dp, aM);
         hipLaunchKernelGGL(k_ns_rows, dim3(gM), dim3(256), 0, h->stream, P, D, X, thI, (const double*)bI, (const double*)aM, yM);
-        if (!want_dy) return;
-        dev.gemv_t_dev(h->d_Ah, yM, atw);
-        hipLaunchKernelGGL(k_ns_kx, dim3(gN), dim3(256), 0, h->stream, th, (const double*)D.dp, (const double*)atw, (const double*)ht, v, ldn);
-        dev.gemv_n_dev(h->d_Ah, v, aM);
-        hipLaunchKernelGGL(k_ns_gather_e, dim3(gE), dim3(256), 0, h->stream, X, (const double*)aM, 1.0, rE);
-        dev.use_factor(h->ns_f0);
-        dev.chol_solve_dev(rE, tE, nE);
-        dev.use_main();
-        hipLaunchKernelGGL(k_ns_scatter_e, dim3(gE), dim3(256), 0, h->stream, X, (const double*)tE, D.dy);
-        dev.gemv_t_dev(h->d_Ah, D.dy, atw);
-        hipLaunchKernelGGL(k_ns_err, dim3(1), dim3(1024), 0, h->stream, th, (const double*)D.dp, (const double*)atw, (const double*)P.hp, n, P.scal + SC_NSERR);
     }
     // out[n] = Zt' u   (Zt dense, k rows of pitch ldg)
     void ns_gemv_t_dense(const double* u, int k, double* out) {
@@ -1413,17 +1433,19 @@ struct Solver {
         while (true) {
             ipm_measures();
             if (h->verbose) std::fprintf(stderr, "[asm] ipm %3d pinf %.3e dinf %.3e gap %.3e\n", ip.iters, ip.pinf, ip.dinf, ip.gap);
-            if (ip.pinf <= tol && ip.dinf <= tol && ip.gap <= tol) return ip.status = ASM_OPTIMAL;
+            if (ip.pinf <= tol && ip.dinf <= tol && ip.gap <= tol) { if (ns_live()) ns_finish_y(); return ip.status = ASM_OPTIMAL; }
             if (ip.iters >= 3 && ip.ymax > 1e3 * lp.scale_q) {
+                if (ns_live()) ns_finish_y();
                 down(ip.y, P.y, lp.M);
                 HIPCHK(hipStreamSynchronize(h->stream));
                 if (farkas_margin(ip.y) > 1e-9) return ip.status = ASM_INFEASIBLE;
             }
-            if (done >= max_more) return ip.status = ASM_OTHER;
+            if (done >= max_more) { if (ns_live()) ns_finish_y(); return ip.status = ASM_OTHER; }
             // jammed: complementarity collapsed but the primal residual no longer decreases (oracle: IPM.run)
             ip.pinf_hist.push_back(ip.pinf);
             if (ip.iters >= 10 && ip.pinf > JAM_PINF && ip.gap <= 1e-2 * ip.pinf && ip.pinf > 0.5 * ip.pinf_hist[ip.pinf_hist.size() - 4]) {
                 ip.stalled = true;
+                if (ns_live()) ns_finish_y();
                 return ip.status = ASM_OTHER;
             }
             hipLaunchKernelGGL(k_ipm_theta, dim3(grid_all()), dim3(256), 0, h->stream, P, IPM_RHO_P);
@@ -1484,10 +1506,10 @@ struct Solver {
             done += 1;
             cg_max = 0;
             cg_fail = false;
-            if (use_ns) ns_newton(0, dirA, dirA, false); else ipm_solve(0, dirA, dirA);
+            if (use_ns) ns_newton(0, dirA, dirA); else ipm_solve(0, dirA, dirA);
             hipLaunchKernelGGL(k_ipm_steps, dim3(1), dim3(1024), 0, h->stream, P, dirA, 0u);
             hipLaunchKernelGGL(k_ipm_muaff, dim3(1), dim3(1024), 0, h->stream, P, dirA);
-            if (use_ns) ns_newton(1, dirA, dirC, true); else ipm_solve(1, dirA, dirC);
+            if (use_ns) ns_newton(1, dirA, dirC); else ipm_solve(1, dirA, dirC);
             unsigned pub = pub_next();
             hipLaunchKernelGGL(k_ipm_steps, dim3(1), dim3(1024), 0, h->stream, P, dirC, pub);
             read_scal(pub);
@@ -1507,7 +1529,8 @@ struct Solver {
                 ap = ap2; ad = ad2;
             }
             if (h->verbose) std::fprintf(stderr, "[asm]     ap %.3e ad %.3e  cg steps so far %lld\n", ap, ad, (long long)h->stats_pcg);
-            if (use_ns && h->h_scal[SC_NSERR] / lp.scale_q > NS_DERR * std::max(tol, ip.dinf)) {
+            if (use_ns && h->h_scal[SC_NSERR] > NS_RERR) {
+                ns_finish_y();
                 ip.ns_off = true;          // the reduced system lost its accuracy: redo the iteration in row form (oracle: IPM.run)
                 continue;
             }
@@ -1521,6 +1544,7 @@ struct Solver {
             }
             const double eta = ip.mu >= 1.0 ? 0.995 : std::min(std::max(0.995, 1.0 - ip.mu / lp.scale_q), 0.999999);
             hipLaunchKernelGGL(k_ipm_update, dim3(grid_all()), dim3(256), 0, h->stream, P, dirC, std::min(1.0, eta * ap), std::min(1.0, eta * ad));
+            if (use_ns) hipLaunchKernelGGL(k_ns_scale, dim3((unsigned)((h->ldn + 255) / 256)), dim3(256), 0, h->stream, nsv(14), 1.0 - std::min(1.0, eta * ap), h->ldn);
             if (use_col && cg_max > COL_MAX_CG) ip.col_off = true;
             if (use_red && cg_max > RED_MAX_CG) ip.red_off = true;
         }
@@ -1684,6 +1708,7 @@ struct Solver {
             h->stats.kkt_pr = pr;
             h->stats.kkt_du = du;
             final_sets = cur;
+            if (h->verbose) std::fprintf(stderr, "[asm] eqp round %d: pr %.3e du %.3e changes %d\n", k, pr, du, h->h_ascnt[AC_NCHG]);
             if (pr <= TOL_P && du <= TOL_D) return true;
             if (k == rounds) break;
             if (h->h_ascnt[AC_NCHG] == 0 || (have_prev && h->h_ascnt[AC_NDIFF] == 0)) break;
@@ -1990,6 +2015,15 @@ struct Solver {
             double t1 = now_ms();
             identify_dev(3);
             have_sets = true;
+            bool tried_ln = false;
+            if (ns_lp) {
+                // the least-norm polish in reduced coordinates costs two solves with the factor of S0: tried first whatever the last LP
+                // needed (oracle: solve_scaled)
+                as_copy_sets(0, 3);
+                const bool okn = eqp_loop(d_zero, nullptr, 2);
+                if (okn) { t_polish += now_ms() - t1; h->stats.path = 1 + stage; return ASM_OPTIMAL; }
+                tried_ln = true;
+            }
             if (prefer_ref) {
                 // non-unique optimum expected: the canonical pair as soon as the partition passes the LP optimality test
                 // (oracle: solve_scaled)
@@ -1999,6 +2033,7 @@ struct Solver {
                 if (how == 1) { h->stats.path = 9; return ASM_OPTIMAL; }
                 continue;
             }
+            if (tried_ln) { t_polish += now_ms() - t1; continue; }
             as_copy_sets(0, 3);
             bool okp = eqp_loop(d_zero, nullptr, 2);
             t_polish += now_ms() - t1;
@@ -2027,7 +2062,7 @@ struct Solver {
                 return ASM_OPTIMAL;
             }
             hint.prefer_ref = false;
-            if (prefer_ref) {                               // the least-norm polish has not been tried on this LP yet
+            if (prefer_ref && !ns_lp) {                     // the least-norm polish has not been tried on this LP yet
                 as_copy_sets(0, 3);
                 if (eqp_loop(d_zero, nullptr, 2)) { h->stats.path = 3; return ASM_OPTIMAL; }
             }
@@ -2321,7 +2356,7 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
             h->d_nsLt = ns_dalloc(h, (int64_t)h->ns_nEp * h->ns_nEp);
             h->d_nsth = ns_dalloc(h, h->ns_ldg);
             h->d_nsFm = ns_dalloc(h, h->ldn);
-            h->d_nsv = ns_dalloc(h, 9 * h->ldn + 3 * h->Mp + 2 * h->ns_nEp);
+            h->d_nsv = ns_dalloc(h, 11 * h->ldn + 3 * h->Mp + 2 * h->ns_nEp);
         }
     }
     h->pin_len = std::max(std::max(h->ldn, h->Mp), h->nsp);

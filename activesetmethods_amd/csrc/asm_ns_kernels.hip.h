@@ -369,10 +369,10 @@ __global__ __launch_bounds__(256) void k_ns_rows(IpmPtrs P, IpmDir D, NsIdx X, c
     D.dg[i] = dg;
     wM[i] = w;
 }
-// out[Eidx[e]] = tE[e]
-__global__ __launch_bounds__(256) void k_ns_scatter_e(NsIdx X, const double* __restrict__ tE, double* __restrict__ out) {
+// out[Eidx[e]] = tE[e]   (add != 0: += )
+__global__ __launch_bounds__(256) void k_ns_scatter_e(NsIdx X, const double* __restrict__ tE, double* __restrict__ out, int add) {
     int t = blockIdx.x * 256 + threadIdx.x;
-    if (t < X.nE) out[X.Eidx[t]] = tE[t];
+    if (t < X.nE) out[X.Eidx[t]] = (add ? out[X.Eidx[t]] : 0.0) + tE[t];
 }
 // slot[0] = max_j |th_j dp_j - aty_j - hp_j| over the free columns: the dual-equation error of the step (one workgroup)
 __global__ __launch_bounds__(1024) void k_ns_err(const double* __restrict__ th, const double* __restrict__ dp, const double* __restrict__ aty,
@@ -490,4 +490,45 @@ __global__ __launch_bounds__(256) void k_nseq_y(AsPtrs A, NsIdx X, const double*
     if (i >= A.M) return;
     const int ep = X.Epos[i];
     A.y[i] = ep >= 0 ? tE[ep] : yM[i];
+}
+
+// ---- null-space iteration without solves against S0 (oracle: IPM.run use_ns / IPM.measures / IPM.ns_finish_y)
+// d0 = Fm (p - pbar)
+__global__ __launch_bounds__(256) void k_ns_e0(IpmPtrs P, const double* __restrict__ pbar, double* __restrict__ d0, int64_t ldn) {
+    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= ldn) return;
+    d0[j] = (j < P.n && P.ub[j] > P.lb[j]) ? P.p[j] - pbar[j] : 0.0;
+}
+// e = d0 - zz on the free columns ; dpb = -e
+__global__ __launch_bounds__(256) void k_ns_e1(IpmPtrs P, const double* __restrict__ d0, const double* __restrict__ zz, double* __restrict__ e, int64_t ldn) {
+    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= ldn) return;
+    e[j] = (j < P.n && P.ub[j] > P.lb[j]) ? d0[j] - zz[j] : 0.0;
+}
+// x *= a
+__global__ __launch_bounds__(256) void k_ns_scale(double* __restrict__ x, double a, int64_t len) {
+    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < len) x[j] *= a;
+}
+__global__ __launch_bounds__(256) void k_ns_neg(const double* __restrict__ x, double* __restrict__ out, int64_t len) {
+    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < len) out[j] = -x[j];
+}
+// scal[SC_DINF] = max_c |zr_c| / scale_q  (the dual residual inside the null space of the equality rows), then the scalar block goes to the host
+__global__ __launch_bounds__(1024) void k_ns_dinf(IpmPtrs P, const double* __restrict__ zr, int k, unsigned pub) {
+    __shared__ double sh[16];
+    double m = 0.0;
+    for (int c = threadIdx.x; c < k; c += 1024) m = fmax(m, fabs(zr[c]));
+    m = blk_reduce_max(m, sh);
+    if (threadIdx.x == 0) P.scal[SC_DINF] = m / P.scale_q;
+    scal_publish(P, pub);
+}
+// slot[0] = max(slot[0], max|r| / max(1, max|rhs|))   (relative residual of a reduced solve; one workgroup)
+__global__ __launch_bounds__(1024) void k_ns_relres(const double* __restrict__ r, const double* __restrict__ rhs, int k, double* __restrict__ slot) {
+    __shared__ double sh[16];
+    double a = 0.0, b = 1.0;
+    for (int c = threadIdx.x; c < k; c += 1024) { a = fmax(a, fabs(r[c])); b = fmax(b, fabs(rhs[c])); }
+    a = blk_reduce_max(a, sh);
+    b = blk_reduce_max(b, sh);
+    if (threadIdx.x == 0) slot[0] = fmax(slot[0], a / b);
 }

@@ -56,9 +56,9 @@ IPM_RHO_P = 1e-8     # primal proximal regularisation of the Newton system (boun
 NS_MIN_E = 64         # null-space form (normal phase): fewest hard equality rows, largest null-space dimension relative to M,
 NS_MAX_RATIO = 0.3    # pivot thresholds of the basis-column selection (first one that yields a full basis), pivot threshold
 NS_SEL_THR = (1e-2, 1e-4, 1e-7, 1e-10)    # for re-using the previous LP's basis columns,
-NS_WARM_THR = 1e-6    # share of the stage tolerance / of the current dual infeasibility the dual-equation error of a step may
-NS_DERR = 0.1         # reach before the LP returns to the row form; smallest Gram pivot for re-using the previous LP's basis
-NS_ZWARM_THR = 0.25
+NS_WARM_THR = 1e-6
+NS_RERR = 1e-6        # relative residual of a reduced solve beyond which the LP returns to the row form; smallest Gram pivot for
+NS_ZWARM_THR = 0.25   # re-using the previous LP's basis
 CHOL_NB = 64
 PIV_BIG = 1e128
 
@@ -281,6 +281,9 @@ class NullSpace:
                 return
         self.J = J
         self.Zt = Zt                                                # k x n
+        # particular solution of the equality rows (fixed columns at their value): the least-norm one, orthogonal to the null space
+        self.pfix = np.where(self.Fm > 0, 0.0, lp.lb)
+        self.pbar = self.pfix + AEF.T @ chol_solve(self.L0, lp.r[self.E] - A[self.E] @ self.pfix)
         self.AI = A[self.I] * self.Fm
         self.GI = self.AI @ Zt.T                                    # |I| x k
         self.valid = True
@@ -335,6 +338,7 @@ class IPM:
         self.ns_iters = 0
         self.ns = nsp                 # prebuilt by the caller (solve_scaled: the active-set solves use it as well) or made at the first iteration
         self.ns_J = ns_J              # basis columns retained from the previous LP of the phase (in), of this LP (out)
+        self.ns_e = None              # part of the iterate outside  pbar + null(A_EF): the infeasibility of the equality rows, shrinks by (1 - a)
         if nsp is not None:
             self.ns_J = nsp.J
             self.ns_ok = self.ns_ok and nsp.valid
@@ -349,7 +353,20 @@ class IPM:
                    + self.g[ineq] @ self.pi[ineq]) / self.ncomp
         pinf = float((np.abs(self.rp) / (1.0 + np.abs(lp.r))).max(initial=0.0))
         dinf = max(np.abs(self.rdp).max(initial=0.0), np.abs(self.rds).max(initial=0.0)) / self.scale_q
+        if self.ns_live():
+            # null-space form: the multipliers of the equality rows are free in sign and carried as 0 (recovered once, at the end): the
+            # dual residual that counts is its part in the null space of the equality rows, Z'rdp
+            dinf = float(np.abs(self.ns.Zt @ self.rdp).max(initial=0.0)) / self.scale_q
         return pinf, dinf, self.mu / self.scale_q
+
+    def ns_live(self):
+        return bool(self.ns_ok and not self.ns_off and self.ns is not None and self.ns.valid)
+
+    def ns_finish_y(self):
+        """Least-squares multipliers of the equality rows for the current iterate (null-space form carries them as 0)."""
+        nsp = self.ns
+        w = np.where(self.free, self.lp.q - nsp.AI.T @ self.y[nsp.I] - self.muL + self.muU, 0.0)
+        self.y[nsp.E] = chol_solve(nsp.L0, nsp.AEF @ w)
 
     def run(self, tol, max_more):
         lp = self.lp
@@ -362,19 +379,27 @@ class IPM:
             pinf, dinf, gap = self.measures()
             self.log.append((self.iters, pinf, dinf, gap))
             if pinf <= tol and dinf <= tol and gap <= tol:
+                if self.ns_live():
+                    self.ns_finish_y()
                 self.status = OPTIMAL
                 return self.status
             if self.iters >= 3 and np.abs(self.y).max(initial=0.0) > 1e3 * self.scale_q:
+                if self.ns_live():
+                    self.ns_finish_y()
                 if farkas_margin(lp, self.y) > 1e-9:
                     self.status = INFEASIBLE
                     return self.status
             if done >= max_more:
+                if self.ns_live():
+                    self.ns_finish_y()
                 self.status = OTHER
                 return self.status
             # jammed: complementarity has collapsed but the primal residual no longer decreases (the
             # signature of a slightly infeasible LP) -> give up, the caller runs the elastic phase-1 LP
             self.pinf_hist.append(pinf)
             if self.iters >= 10 and pinf > JAM_PINF and gap <= 1e-2 * pinf and pinf > 0.5 * self.pinf_hist[-4]:
+                if self.ns_live():
+                    self.ns_finish_y()
                 self.status = OTHER
                 self.stalled = True
                 return self.status
@@ -407,10 +432,11 @@ class IPM:
                 #   N du = Z'(h~ - K dpbar),   N = Z'K Z (k x k),  K = Th + A_I' D_I^-1 A_I,  h~ = hp + A_I' D_I^-1 b_I,
                 #   dy_E = S0^-1 A_EF (K dp - h~)      (least-squares multipliers of the equality rows).
                 # The primal equations hold to rounding by construction; all inexactness sits in the dual equation, where the
-                # next iteration's right-hand side picks it up (its size is monitored: `ns_err`).  Per iteration: one factorisation
-                # of N, two solves with the factor of S0 = A_EF A_EF' (dpbar for the residual of the equality rows, shared by
-                # predictor and corrector; dy_E of the final direction) - no Gondzio correctors in this form (a Newton solve
-                # costs more than the factorisation here).
+                # next iteration's right-hand side picks it up.  The multipliers of the equality rows are free in sign and enter the
+                # reduced system through Z'A_EF' = 0 only: they are carried as 0 and recovered once per stage (ns_finish_y), and
+                # dpbar is the tracked component e of the iterate outside pbar + null(A_EF) - so an iteration needs NO solve with
+                # the factor of S0, only the k x k factorisation.  `ns_err` = residual of the reduced solve after its refinement
+                # sweep.  No Gondzio correctors in this form (a Newton solve costs as much as the factorisation here).
                 self.ns_iters += 1
                 nsp = self.ns
                 thF = (muL / tL + muU / tU + IPM_RHO_P) * nsp.Fm
@@ -422,7 +448,10 @@ class IPM:
                 Nm[kdx, kdx] += 1e-13 * nd0 + 1e-30
                 LN = chol_guard(Nm, nd0)
                 AIF = nsp.AI
-                dpb1 = nsp.AEF.T @ chol_solve(nsp.L0, -rp[nsp.E])
+                if self.ns_e is None:
+                    d0 = (self.p - nsp.pbar) * nsp.Fm
+                    self.ns_e = d0 - nsp.Zt.T @ (nsp.Zt @ d0)
+                dpb1 = -self.ns_e                   # A_EF dpb1 = -rp_E: the least-norm particular solution, without a solve
                 sgI, piI = sg[nsp.I], pi[nsp.I]
                 ns_err = [0.0]
             use_col = (not use_ns) and self.col_ok and not self.col_off
@@ -532,7 +561,7 @@ class IPM:
                 dg = np.where(ineq, (rcg - g * dpi) / np.where(ineq, pi, 1.0), 0.0)
                 return dp, ds, dg, dy, dmuL, dmuU, dmus, dpi
 
-            def solve_ns(rcL, rcU, rcs, rcg, res=1.0, want_dy=True):
+            def solve_ns(rcL, rcU, rcs, rcg, res=1.0):
                 hp = np.where(free, -res * rdp + rcL / tL - rcU / tU, 0.0)
                 bI = -res * rp[nsp.I] + sgI * rcg[nsp.I] / piI
                 dpb = res * dpb1
@@ -540,13 +569,10 @@ class IPM:
                 rhs_u = nsp.Zt @ (ht - (thF * dpb + AIF.T @ (dinvI * (AIF @ dpb))))
                 du = chol_solve(LN, rhs_u)
                 du = du + chol_solve(LN, rhs_u - Nm0 @ du)      # one refinement sweep on the unregularised reduced matrix
+                ns_err[0] = max(ns_err[0], float(np.abs(rhs_u - Nm0 @ du).max(initial=0.0)) / max(1.0, float(np.abs(rhs_u).max(initial=0.0))))
                 dp = dpb + nsp.Zt.T @ du
                 dy = np.zeros(M)
                 dy[nsp.I] = dinvI * (bI - AIF @ dp)
-                if want_dy:
-                    gE = thF * dp + AIF.T @ (dinvI * (AIF @ dp)) - ht
-                    dy[nsp.E] = chol_solve(nsp.L0, nsp.AEF @ gE)
-                    ns_err[0] = float(np.abs(nsp.Fm * (thF * dp - A.T @ dy - hp)).max(initial=0.0))
                 dmuL = np.where(free, (rcL - muL * dp) / tL, 0.0)
                 dmuU = np.where(free, (rcU + muU * dp) / tU, 0.0)
                 dpi = np.where(ineq, sg * dy, 0.0)
@@ -560,7 +586,7 @@ class IPM:
 
             # predictor (affine scaling)
             if use_ns:
-                dp, ds, dg, dy, dmuL, dmuU, dmus, dpi = solve_ns(-tL * muL, -tU * muU, -ts * mus, -g * pi, 1.0, False)
+                dp, ds, dg, dy, dmuL, dmuU, dmus, dpi = solve_ns(-tL * muL, -tU * muU, -ts * mus, -g * pi)
             else:
                 dp, ds, dg, dy, dmuL, dmuU, dmus, dpi = solve(-tL * muL, -tU * muU, -ts * mus, -g * pi)
             ap, ad = steps(dp, ds, dg, dmuL, dmuU, dmus, dpi)
@@ -594,7 +620,8 @@ class IPM:
                 dp, ds, dg, dy, dmuL, dmuU, dmus, dpi = cand
                 ap, ad = ap2, ad2
             self.last_cg = (cg_max[0], cg_fail[0])
-            if use_ns and ns_err[0] / self.scale_q > NS_DERR * max(tol, dinf):
+            if use_ns and ns_err[0] > NS_RERR:
+                self.ns_finish_y()
                 self.ns_off = True                  # the reduced system lost its accuracy: redo the iteration in row form
                 continue
             if use_col and cg_fail[0]:
@@ -617,6 +644,8 @@ class IPM:
             self.mus = mus + b * dmus
             self.pi = pi + b * dpi
             self.y = np.where(ineq, sg * self.pi, self.y + b * dy)
+            if use_ns:
+                self.ns_e = (1.0 - a) * self.ns_e
             if use_col and cg_max[0] > COL_MAX_CG:
                 self.col_off = True
             if use_red and cg_max[0] > RED_MAX_CG:
@@ -667,8 +696,7 @@ def eqp_ns(lp, nsp, sets, sweeps=3):
     ia_mask = (rowst[nsp.I] == 1)
     Ia = nsp.I[ia_mask]
     beta = np.where(bst < 0, lp.lb, lp.ub)
-    pfix = np.where(Fm > 0, 0.0, lp.lb)
-    pbar = pfix + nsp.AEF.T @ chol_solve(nsp.L0, lp.r[nsp.E] - A[nsp.E] @ pfix)
+    pbar = nsp.pbar
     zero_p = np.clip(np.zeros(n), lp.lb, lp.ub) * Fm
     u = nsp.Zt @ (zero_p - pbar * Fm)
     C = np.vstack([nsp.Zt[:, B].T, nsp.GI[ia_mask]])
@@ -1265,6 +1293,14 @@ def solve_scaled(lp, warm=None, stats=None, hint=None):
                 return INFEASIBLE, None, None, None, None
             break                                   # never reached 1e-8: no identification attempt
         sets0 = identify(lp, ip)
+        tried_ln = False
+        if nsp is not None:
+            # the least-norm polish in reduced coordinates costs two solves with the factor of S0: tried first whatever the last LP needed
+            ok, p, s, y, sets = eqp_loop(lp, sets0, zero_p, zero_y, 2, stats, nsp)
+            if ok:
+                stats['path'] = 'ipm%d+ln' % stage
+                return OPTIMAL, p, s, y, sets
+            tried_ln = True
         if prefer_ref:
             # non-unique optimum expected: the canonical pair as soon as the partition passes the LP optimality test (its
             # first step is that test - one solve when it fails); pushing the iterate further than needed only costs
@@ -1273,6 +1309,8 @@ def solve_scaled(lp, warm=None, stats=None, hint=None):
             if how is not None:
                 stats['path'] = 'ipm+' + how
                 return OPTIMAL, p, s, y, sets
+            continue
+        if tried_ln:
             continue
         ok, p, s, y, sets = eqp_loop(lp, sets0, zero_p, zero_y, 2, stats, nsp)
         if ok:
@@ -1298,7 +1336,7 @@ def solve_scaled(lp, warm=None, stats=None, hint=None):
             stats['path'] = 'ipm+ref'
             return OPTIMAL, p, s, y, sets
         hint['prefer_ref'] = False
-        if prefer_ref:                              # the least-norm polish has not been tried on this LP yet
+        if prefer_ref and nsp is None:              # the least-norm polish has not been tried on this LP yet
             ok, p, s, y, sets = eqp_loop(lp, sets0, zero_p, zero_y, 2, stats, nsp)
             if ok:
                 stats['path'] = 'ipm%d+ln' % (len(IPM_STAGES) - 1)
