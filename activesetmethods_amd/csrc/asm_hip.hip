@@ -13,6 +13,8 @@
 #include "asm_eval_kernels.hip.h"
 #include "../../include/asm_hip.h"
 
+#include <sched.h>
+#include <time.h>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -893,11 +895,16 @@ struct Solver {
             HIPCHK(hipStreamSynchronize(h->stream));
             return;
         }
+        // hot spin for the common case (the kernel is next on an otherwise idle stream: 6.7 us), then yield, then sleep: with several
+        // solver threads per process (scenario batches) the kernel may be queued behind other streams' work for milliseconds, and a
+        // spinning thread would burn the CPU share the launching threads need
         const double t0 = now_ms();
         for (unsigned long spins = 1;; ++spins) {
             if (__atomic_load_n(h->h_seq, __ATOMIC_ACQUIRE) == pub) return;
-            __builtin_ia32_pause();
-            if ((spins & 0xfffff) == 0 && now_ms() - t0 > 30000.0) {
+            if (spins < 20000) __builtin_ia32_pause();
+            else if (spins < 20200) sched_yield();
+            else { struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
+            if (((spins < 20200 && (spins & 0xfffff) == 0) || (spins >= 20200 && (spins & 0x3ff) == 0)) && now_ms() - t0 > 30000.0) {
                 HIPCHK(hipStreamSynchronize(h->stream));            // a device fault surfaces here
                 if (__atomic_load_n(h->h_seq, __ATOMIC_ACQUIRE) == pub) return;
                 throw HipError("read_scal: the publishing kernel finished without setting its sequence word");
@@ -2140,7 +2147,10 @@ void check_panel_timeout(asm_handle* h) {
     if (!h->fused_panel || !h->d_ptmo) return;
     unsigned tmo = 0;
     HIPCHK(hipMemcpy(&tmo, h->d_ptmo, sizeof(unsigned), hipMemcpyDeviceToHost));
-    if (tmo != 0) throw HipError("k_chol_panel: a workgroup timed out waiting for a producer (grid not resident?)");
+    if (tmo != 0) {
+        HIPCHK(hipMemset(h->d_ptmo, 0, sizeof(unsigned)));      // reported once: the handle stays usable
+        throw HipError("k_chol_panel: a workgroup timed out waiting for a producer (grid not resident?)");
+    }
 }
 
 void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j_row, const int64_t* j_col, const double* c_lb,
@@ -3061,6 +3071,20 @@ int asm_test_cholesky(asm_handle* h, const double* S, int64_t N, double* L_out) 
     });
 }
 
+// The bounded wait of the panel kernel with a producer that never publishes: the probe's workgroups must give up (the first after the
+// full bound, the others at their next look at the timeout word), the host must report ASM_ERR_HIP once, and the handle must stay usable.
+int asm_test_panel_timeout(asm_handle* h, int workgroups) {
+    return guarded(h, [&] {
+        if (workgroups < 1 || workgroups > 64) throw std::invalid_argument("asm_test_panel_timeout: 1..64 workgroups");
+        test_alloc(h, 64, 16);
+        h->panel_epoch += 1;
+        if (h->panel_epoch == 0) h->panel_epoch = 1;
+        hipLaunchKernelGGL(k_pnl_wait_probe, dim3((unsigned)workgroups), dim3(256), 0, h->stream, h->d_pflags, h->panel_epoch, h->d_ptmo);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        check_panel_timeout(h);
+    });
+}
+
 int asm_test_chol_solve(asm_handle* h, const double* S, int64_t N, const double* b, double* x) {
     return guarded(h, [&] {
         test_load_S(h, S, N);
@@ -3068,6 +3092,47 @@ int asm_test_chol_solve(asm_handle* h, const double* S, int64_t N, const double*
         d.diag_prepare((int)N, 0, 0.0, 0.0);
         d.chol((int)N);
         d.chol_solve(b, x, (int)N);
+        d.resolve_timing();
+    });
+}
+
+int asm_test_gemm_nt(asm_handle* h, const double* A, const double* B, const double* C0, int64_t Ma, int64_t Mb, int64_t K, int mode, double* C_out) {
+    return guarded(h, [&] {
+        if (Ma <= 0 || Mb <= 0 || K <= 0 || K % 32 != 0 || !A || !B || !C_out || (mode != 0 && !C0)) throw std::invalid_argument("asm_test_gemm_nt: bad argument");
+        HIPCHK(hipSetDevice(h->device));
+        double *dA = nullptr, *dB = nullptr, *dC = nullptr;
+        dmalloc(&dA, Ma * K); dmalloc(&dB, Mb * K); dmalloc(&dC, Ma * Mb);
+        HIPCHK(hipMemcpy(dA, A, Ma * K * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dB, B, Mb * K * sizeof(double), hipMemcpyHostToDevice));
+        if (mode != 0) HIPCHK(hipMemcpy(dC, C0, Ma * Mb * sizeof(double), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_gemm_nt, dim3((unsigned)((Mb + 63) / 64), (unsigned)((Ma + 63) / 64)), dim3(256), 0, h->stream, (const double*)dA, K, (const double*)dB, K,
+                           (const double*)(mode != 0 ? dC : nullptr), Mb, dC, Mb, (int)Ma, (int)Mb, (int)K, mode);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(C_out, dC, Ma * Mb * sizeof(double), hipMemcpyDeviceToHost));
+        (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC);
+    });
+}
+
+int asm_test_trsm_rows(asm_handle* h, const double* S, int64_t N, const double* R, int64_t nrhs, int backward, double* X_out) {
+    return guarded(h, [&] {
+        if (N <= 0 || nrhs <= 0 || !S || !R || !X_out) throw std::invalid_argument("asm_test_trsm_rows: bad argument");
+        test_load_S(h, S, N);
+        Dev d(h);
+        d.diag_prepare((int)N, 0, 0.0, 0.0);
+        d.chol((int)N);
+        const int64_t ldr = round_up(N, 32);
+        double *dR = nullptr, *dX = nullptr, *dLt = nullptr;
+        dmalloc(&dR, nrhs * ldr); dmalloc(&dX, nrhs * ldr); dmalloc(&dLt, h->Mp * h->Mp);
+        HIPCHK(hipMemset(dR, 0, nrhs * ldr * sizeof(double)));
+        HIPCHK(hipMemset(dX, 0, nrhs * ldr * sizeof(double)));
+        HIPCHK(hipMemset(dLt, 0, h->Mp * h->Mp * sizeof(double)));
+        for (int64_t r = 0; r < nrhs; ++r) HIPCHK(hipMemcpy(dR + r * ldr, R + r * N, N * sizeof(double), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_transpose_dense, dim3((unsigned)((N + 63) / 64), (unsigned)((N + 63) / 64)), dim3(256), 0, h->stream, (const double*)h->d_S, h->Mp, N, N, dLt, h->Mp);
+        d.trsm_rows(dR, dX, ldr, (int)nrhs, (int)N, backward ? dLt : nullptr);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        const double* out = backward ? dR : dX;
+        for (int64_t r = 0; r < nrhs; ++r) HIPCHK(hipMemcpy(X_out + r * N, out + r * ldr, N * sizeof(double), hipMemcpyDeviceToHost));
+        (void)hipFree(dR); (void)hipFree(dX); (void)hipFree(dLt);
         d.resolve_timing();
     });
 }

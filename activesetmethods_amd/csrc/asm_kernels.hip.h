@@ -839,7 +839,10 @@ __device__ __forceinline__ void pnl_wait(unsigned* flag, unsigned epoch, unsigne
         unsigned spins = 0;
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
             __builtin_amdgcn_s_sleep(4);
-            if (++spins > (1u << 22)) {                       // bounded: a lost producer must not hang the GPU
+            ++spins;
+            // bounded: a lost producer must not hang the GPU.  Once one workgroup has given up the launch is void (the host reports
+            // it): every other wait ends at its next look at the timeout word instead of spinning to its own bound
+            if (spins > (1u << 22) || ((spins & 255u) == 0 && __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                 __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
@@ -848,6 +851,10 @@ __device__ __forceinline__ void pnl_wait(unsigned* flag, unsigned epoch, unsigne
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+}
+// test hook: workgroups waiting for a flag that no producer of the launch sets (the bounded spin must end and report)
+__global__ __launch_bounds__(256) void k_pnl_wait_probe(unsigned* flag, unsigned epoch, unsigned* tmo) {
+    pnl_wait(flag, epoch, tmo);
 }
 #define ASM_PNL_LDS (2 * ASM_NB * ASM_XP + 4 * 16 * 17 + 2 * ASM_NB)
 #define ASM_PNL_NS 8        // most 64-wide steps of one panel launch (flag words: NS for the diagonal blocks + NS * NS for the panel tiles)

@@ -183,6 +183,15 @@ int asm_test_syrk_update(asm_handle* h, const double* P /* Ms*K */, int64_t Ms, 
                          double* S_inout /* Ms*Ms */, int tile);
 int asm_test_cholesky(asm_handle* h, const double* S /* N*N sym */, int64_t N, double* L_out /* N*N lower */);
 int asm_test_chol_solve(asm_handle* h, const double* S, int64_t N, const double* b, double* x);
+/* the bounded wait of the dataflow panel kernel with a producer that never publishes: returns ASM_ERR_HIP (reported once), the
+ * handle stays usable */
+int asm_test_panel_timeout(asm_handle* h, int workgroups);
+/* C = (mode 1: C0) -/+ A B'  (A: Ma x K, B: Mb x K, row-major, K a multiple of 32) - the product kernel of the multi-right-hand-side
+ * triangular solves of the null-space form */
+int asm_test_gemm_nt(asm_handle* h, const double* A, const double* B, const double* C0, int64_t Ma, int64_t Mb, int64_t K, int mode,
+                     double* C_out);
+/* rows of R (nrhs x N) solved against the Cholesky factor of S: forward only (L x = r) or forward + backward (S x = r) */
+int asm_test_trsm_rows(asm_handle* h, const double* S, int64_t N, const double* R, int64_t nrhs, int backward, double* X_out);
 int asm_test_gemv(asm_handle* h, const double* A, int64_t M, int64_t K, const double* x, const double* y,
                   double* Ax, double* ATy);
 int asm_test_assemble(asm_handle* h, const double* dE, double* J_out /* (m+nadj)*n */);

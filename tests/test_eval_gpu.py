@@ -61,12 +61,14 @@ def test_affine_quadratic_evaluator_is_bit_identical(seed, sense):
     opt.close()
 
 
-def test_acopf_device_evaluator():
+@pytest.mark.parametrize("case,seed", [("case118", 2), ("case1354pegase", 1)])
+def test_acopf_device_evaluator(case, seed):
     """Polar ACOPF through the wrapper's lists + the Ohm's-law NLP-block kernel: the affine / quadratic rows bit-identical,
-    the trigonometric rows and their Jacobian values within 1e-13 relative (device sin / cos vs NumPy's)."""
+    the trigonometric rows and their Jacobian values within 1e-13 relative (device sin / cos vs NumPy's).  case118 size and the
+    size of BASELINE.json configs[3] (n = 11192, m = 18637, 64233 Jacobian entries)."""
     from activesetmethods_amd import acopf
-    fm = acopf.function_model(acopf.synthetic_case("case118", 2))
-    pr = fm.to_problem("case118")
+    fm = acopf.function_model(acopf.synthetic_case(case, seed))
+    pr = fm.to_problem(case)
     opt = _optimizer_for(pr)
     opt.eval_setup(fm)
     rng = np.random.default_rng(7)
@@ -133,6 +135,20 @@ def test_slp_reductions_on_device():
         want = host.compute_derivative()
         got = opt.slp_merit(1, 0.0, host.p, host.nu, host.p_slack, fr, host.prim_infeas)
         assert abs(got - want) <= 1e-11 * max(1.0, abs(want)), (fr, got, want)
+    # ... and directly against the oracle's restatement of slp.jl:79-147 (oracle/slp.py: compute_phi, compute_derivative)
+    om = O.Model(pr.n, pr.m, pr.x_L, pr.x_U, pr.g_L, pr.g_U, pr.j_str, pr.eval_f, pr.eval_g, pr.eval_grad_f, pr.eval_jac_g, O.Parameters())
+    osl = O.SlpLS(om)
+    osl.x = x.copy(); osl.f = f; osl.df = df.copy(); osl.E = E.copy(); osl.nu = host.nu.copy(); osl.p = host.p.copy()
+    osl.prim_infeas = ref[0]; osl.p_slack = {i: list(v) for i, v in host.p_slack.items()}
+    for fr in (False, True):
+        osl.feasibility_restoration = fr
+        for alpha in (0.0, 1.0, 0.37):
+            want = osl.compute_phi(osl.x, alpha, osl.p)
+            got = opt.slp_merit(0, alpha, host.p, host.nu, host.p_slack, fr, host.prim_infeas)
+            assert abs(got - want) <= 1e-11 * max(1.0, abs(want)), ("oracle", fr, alpha, got, want)
+        want = osl.compute_derivative()
+        got = opt.slp_merit(1, 0.0, host.p, host.nu, host.p_slack, fr, host.prim_infeas)
+        assert abs(got - want) <= 1e-11 * max(1.0, abs(want)), ("oracle", fr, got, want)
     opt.close()
 
 

@@ -136,3 +136,83 @@ def test_mfma_f64_probe_runs(hip_lib, handle):
     t = C.c_double(0.0)
     assert hip_lib.asm_test_mfma_peak(handle, 20000, 2, C.byref(t)) == 0
     assert 5.0 < t.value < 200.0
+
+
+# ----------------------------------------------------------------------------- round 3: kernels of the null-space form
+@pytest.mark.parametrize("Ma,Mb,K,mode", [(64, 64, 32, 0), (130, 200, 96, 0), (130, 200, 96, 1), (519, 1024, 1024, 1), (37, 469, 480, 0)])
+def test_gemm_nt_matches_numpy(hip_lib, handle, Ma, Mb, K, mode):
+    """C = (C0) -/+ A B' on the matrix cores (k_gemm_nt): ragged tile edges, both modes, in-place accumulation."""
+    rng = np.random.default_rng(Ma + Mb + K)
+    A = rng.standard_normal((Ma, K)); B = rng.standard_normal((Mb, K)); C0 = rng.standard_normal((Ma, Mb))
+    Cout = np.zeros((Ma, Mb))
+    rc = hip_lib.asm_test_gemm_nt(handle, _d(A), _d(B), _d(C0), Ma, Mb, K, mode, _d(Cout))
+    assert rc == 0, hip_lib.asm_last_error(handle)
+    ref = A @ B.T if mode == 0 else C0 - A @ B.T
+    assert np.abs(Cout - ref).max() / np.abs(ref).max() < 1e-13
+
+
+@pytest.mark.parametrize("N,nrhs,backward", [(100, 5, 1), (700, 37, 0), (700, 37, 1), (1500, 64, 1), (2600, 130, 1), (981, 107, 1)])
+def test_multi_rhs_triangular_solves(hip_lib, handle, N, nrhs, backward):
+    """Rows of R solved against the Cholesky factor by right-looking block substitution (products with the explicit inverses of
+    the wide diagonal blocks + one update of all remaining columns per block): forward only and forward + backward."""
+    from scipy.linalg import solve_triangular
+    rng = np.random.default_rng(N + nrhs)
+    Bm = rng.standard_normal((N, N + 5))
+    S = Bm @ Bm.T + 0.1 * np.eye(N)
+    R = rng.standard_normal((nrhs, N))
+    X = np.zeros((nrhs, N))
+    rc = hip_lib.asm_test_trsm_rows(handle, _d(S), N, _d(R), nrhs, backward, _d(X))
+    assert rc == 0, hip_lib.asm_last_error(handle)
+    L = np.linalg.cholesky(S)
+    ref = solve_triangular(L, R.T, lower=True).T
+    if backward:
+        ref = solve_triangular(L.T, ref.T, lower=False).T
+    assert np.abs(X - ref).max() / np.abs(ref).max() < 1e-9
+    if backward:
+        assert np.abs(X @ S - R).max() < 1e-9 * max(1.0, np.abs(S).max() * np.abs(X).max())
+
+
+@pytest.mark.parametrize("N", [11192, 18637])
+def test_cholesky_and_solve_at_case1354_sizes(hip_lib, handle, N):
+    """The three-level blocked factorisation with look-ahead at the sizes the case1354pegase-sized LPs factor (n = 11192, M = 18637):
+    ||L (L'v) - S v|| / (||S|| ||v||) <= 1e-12 for several v, the solve's residual, and at N = 11192 the factor against LAPACK."""
+    rng = np.random.default_rng(N)
+    Bm = rng.standard_normal((N, 96))
+    S = Bm @ Bm.T
+    S[np.arange(N), np.arange(N)] += rng.uniform(1.0, 3.0, N) * 96.0
+    L = np.zeros((N, N))
+    assert hip_lib.asm_test_cholesky(handle, _d(S), N, _d(L)) == 0, hip_lib.asm_last_error(handle)
+    assert np.isfinite(L).all() and (np.diag(L) > 0).all() and (np.diag(L) < 1e100).all()
+    nS = np.abs(S).sum(axis=1).max()
+    for t in range(4):
+        v = rng.standard_normal(N) if t else np.ones(N)
+        r = L @ (L.T @ v) - S @ v
+        assert np.abs(r).max() <= 1e-12 * nS * np.abs(v).max(), (t, np.abs(r).max() / (nS * np.abs(v).max()))
+    if N <= 12000:
+        Lref = np.linalg.cholesky(S)
+        assert np.abs(L - Lref).max() / np.abs(Lref).max() < 1e-11
+    del L
+    b = rng.standard_normal(N)
+    x = np.zeros(N)
+    assert hip_lib.asm_test_chol_solve(handle, _d(S), N, _d(b), _d(x)) == 0, hip_lib.asm_last_error(handle)
+    assert np.abs(S @ x - b).max() <= 1e-11 * max(1.0, nS * np.abs(x).max())
+
+
+def test_panel_wait_timeout_is_reported_once_and_the_handle_survives(hip_lib, handle):
+    """The dataflow panel kernel's bounded wait with a producer that never publishes: every waiting workgroup gives up (the first after
+    the full bound, the others at their next look at the timeout word), the host reports ASM_ERR_HIP with the kernel's message once,
+    and the same handle factors correctly afterwards."""
+    import time
+    t0 = time.time()
+    rc = hip_lib.asm_test_panel_timeout(handle, 8)
+    dt = time.time() - t0
+    assert rc == -2, rc                                         # ASM_ERR_HIP
+    assert b"timed out" in hip_lib.asm_last_error(handle)
+    assert dt < 60.0
+    N = 300
+    rng = np.random.default_rng(5)
+    Bm = rng.standard_normal((N, N + 5))
+    S = Bm @ Bm.T + 0.1 * np.eye(N)
+    L = np.zeros((N, N))
+    assert hip_lib.asm_test_cholesky(handle, _d(S), N, _d(L)) == 0, hip_lib.asm_last_error(handle)      # no stale timeout
+    assert np.abs(L - np.linalg.cholesky(S)).max() < 1e-10

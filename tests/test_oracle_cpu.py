@@ -230,3 +230,71 @@ def test_sparse_lp_statement_agrees_with_oracle_and_highs(seed, infeasible):
         st, obj, p, _, _ = sparse_lp.solve_highs(lp)
         assert st == out[5] == 1
         assert abs(obj - sum(sum(v) for v in out[4].values())) <= 1e-8 * max(1.0, abs(obj))
+
+
+# ----------------------------------------------------------------------------- round 3: null-space form (oracle/lp_solver.py: NullSpace)
+def _eq_rich_lp(seed, n=300, neq=260, nineq=160):
+    from tests.util import equality_rich_subproblem
+    from oracle.subproblem import QpData, QpModel, compute_jacobian_matrix
+    sp = equality_rich_subproblem(seed, n, neq, nineq)
+    A, stored = compute_jacobian_matrix(sp['m'], sp['n'], sp['j_row'] - 1, sp['j_col'] - 1, sp['dE'])
+    qp = QpModel(QpData(sp['df'], sp['f'], A, sp['E'], sp['c_lb'], sp['c_ub'], sp['v_lb'], sp['v_ub'], stored), sp['j_row'], sp['j_col'])
+    return sp, qp.build_lp(sp['x_k'], sp['delta'], False)
+
+
+@pytest.mark.parametrize("seed", [81, 84])
+def test_null_space_form_agrees_with_row_form_and_highs(seed, monkeypatch):
+    """The same LP solved with the equality rows eliminated (k x k Newton systems, active-set solves in reduced coordinates) and with
+    the M x M row form: same status and working sets, step and multipliers to 1e-8; optimal value against HiGHS."""
+    from oracle import lp_solver as L
+    from scipy.optimize import linprog
+    sp, lp = _eq_rich_lp(seed)
+    assert L.ns_applicable(lp)
+    a = L.solve_lp(lp)
+    assert a['status'] == L.OPTIMAL and a['stats']['ns_iters'] > 0 and a['stats']['ns_cold'] == 1
+    monkeypatch.setattr(L, "ns_applicable", lambda lp_: False)
+    b = L.solve_lp(lp)
+    assert b['status'] == L.OPTIMAL and b['stats']['ns_iters'] == 0
+    assert all(np.array_equal(u, v) for u, v in zip(a['sets'], b['sets']))
+    assert np.abs(a['p'] - b['p']).max() <= 1e-8 * max(1.0, np.abs(b['p']).max())
+    assert np.abs(a['y'] - b['y']).max() <= 1e-8 * max(1.0, np.abs(b['y']).max())
+    e, g, l = lp.rtype == 0, lp.rtype == 1, lp.rtype == -1
+    res = linprog(lp.q, A_ub=np.vstack([-lp.A[g], lp.A[l]]), b_ub=np.concatenate([-lp.r[g], lp.r[l]]), A_eq=lp.A[e], b_eq=lp.r[e],
+                  bounds=np.c_[lp.lb, lp.ub], method="highs")
+    assert res.status == 0 and abs(lp.q @ a['p'] - res.fun) <= 1e-8 * max(1.0, abs(res.fun))
+
+
+def test_null_space_basis_is_carried_between_lps():
+    """The orthonormal basis of one LP, projected onto the next LP's null space, is accepted when the equality rows move a little and
+    rejected (fresh selection) when they are replaced; the basis is orthonormal and annihilates the equality rows to 1e-12."""
+    from oracle import lp_solver as L
+    sp, lp = _eq_rich_lp(85)
+    s1, c, rho, kap = L.scale_lp(lp)
+    n1 = L.NullSpace(s1)
+    assert n1.valid and n1.cold and n1.k == 300 - 260
+    assert np.abs(n1.Zt @ n1.Zt.T - np.eye(n1.k)).max() < 1e-12 and np.abs(n1.AEF @ n1.Zt.T).max() < 1e-12
+    lp2 = L.LP(lp.q, lp.A * (1.0 + 1e-2 * np.random.default_rng(1).standard_normal(lp.A.shape)), lp.rtype, lp.r, lp.lb, lp.ub)
+    s2, _, _, _ = L.scale_lp(lp2)
+    n2 = L.NullSpace(s2, n1.J, n1.Zt)
+    assert n2.valid and not n2.cold and n2.how == 'basis'
+    assert np.abs(n2.Zt @ n2.Zt.T - np.eye(n2.k)).max() < 1e-12 and np.abs(n2.AEF @ n2.Zt.T).max() < 1e-12
+    sp3, lp3 = _eq_rich_lp(86)
+    s3, _, _, _ = L.scale_lp(lp3)
+    n3 = L.NullSpace(s3, n1.J, n1.Zt)                      # unrelated rows: neither the old basis nor the old columns survive
+    assert n3.valid and n3.how in ('cold', 'columns')
+
+
+def test_reduced_active_set_solve_agrees_with_the_full_one():
+    """eqp_ns (constraints of the working set on the reduced coordinates) against eqp (Gram matrix of all active rows) on the optimal
+    working set: the same point and multipliers."""
+    from oracle import lp_solver as L
+    sp, lp = _eq_rich_lp(87)
+    out = L.solve_lp(lp)
+    assert out['status'] == L.OPTIMAL
+    s, c, rho, kap = L.scale_lp(lp)
+    nsp = L.NullSpace(s)
+    zero_p = np.clip(np.zeros(s.n), s.lb, s.ub)
+    p1, _, y1, _ = L.eqp(s, out['sets'], zero_p, np.zeros(s.M))
+    p2, _, y2, _ = L.eqp_ns(s, nsp, out['sets'])
+    assert np.abs(p1 - p2).max() <= 1e-10 * max(1.0, np.abs(p1).max())
+    assert np.abs(y1 - y2).max() <= 1e-9 * max(1.0, np.abs(y1).max())

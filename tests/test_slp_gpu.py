@@ -228,6 +228,7 @@ def test_scenario_batch_on_one_gpu():
     ("case118", 1.0, "Trust Region", (0, 6, -1)),
     ("case300", 0.5, "Line Search", (0,)),
     ("case300", 1.0, "Line Search", (0, 6, -1, 2)),
+    ("case1354pegase", 0.5, "Line Search", (0,)),      # BASELINE.json configs[3] size, the bench's C4 instance: terminates LOCALLY_SOLVED
 ])
 def test_slp_run_to_termination_every_lp_polished(case, load, alg, expect):
     from activesetmethods_amd import acopf

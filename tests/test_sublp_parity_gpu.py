@@ -4,20 +4,21 @@ slack values within 1e-10 relative (BASELINE.json north_star)."""
 import numpy as np
 import pytest
 
-from tests.util import random_subproblem, oracle_solve, hip_solve, rel_err
+from tests.util import random_subproblem, equality_rich_subproblem, oracle_solve, hip_solve, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
 
 
-def _compare(o_out, h_out, opt, qp_info):
+def _compare(o_out, h_out, opt, qp_info, sets=None):
+    """`sets`: the handle's active_set() taken right after the call (the handle only keeps the last call's)."""
     Xo, lo, uo, Lo, pso, sto, info = o_out
     Xh, lh, uh, Lh, psh, sth = h_out
     assert sth == sto
     if sto != 1:
         assert not Xh.any() and not lh.any()
         return
-    rows, bnd, sl = opt.active_set()
+    rows, bnd, sl = sets if sets is not None else opt.active_set()
     orow, obst, osst = info['sets']
     assert np.array_equal(rows, orow) and np.array_equal(bnd, obst) and np.array_equal(sl, osst)
     assert rel_err(Xh, Xo) < TOL
@@ -131,24 +132,27 @@ def test_random_campaign():
         dens = float(rng.choice([1.0, 0.5, 0.1, 0.03])); dup = float(rng.choice([0.0, 0.2])); nr = int(rng.integers(0, min(m, 6)))
         infeas = bool(rng.random() < 0.3); delta = float(rng.choice([0.4, 0.05, 1000.0]))
         sp = random_subproblem(seed, n, m, dens, dup, nr, infeasible=infeas, delta=delta)
+        def snap():                          # the handle only keeps the last call's sets and statistics
+            return (opt.active_set() if h_out[5] == 1 else None), opt.last_stats()
         qp, o_out = oracle_solve(sp)
         opt, h_out = hip_solve(sp)
-        calls = [(o_out, h_out)]
+        calls = [(o_out, h_out) + snap()]
         if o_out[5] == 2:
             qp, o_out = oracle_solve(sp, True, qp)
             opt, h_out = hip_solve(sp, True, opt)
-            calls.append((o_out, h_out))
+            calls.append((o_out, h_out) + snap())
         sp2 = dict(sp); sp2['dE'] = sp['dE'] * (1.0 + 1e-3 * rng.standard_normal(len(sp['dE'])))
-        qp, o2 = oracle_solve(sp2, False, qp)
-        opt, h2 = hip_solve(sp2, False, opt)
-        for (oo, hh), last in ((calls[0], False), (calls[-1], False), ((o2, h2), True)):
+        qp, o_out = oracle_solve(sp2, False, qp)
+        opt, h_out = hip_solve(sp2, False, opt)
+        calls.append((o_out, h_out) + snap())
+        # EVERY call of the seed: status, path, working sets, values (round 2 compared the last call only)
+        for oo, hh, sets, st in calls:
+            so = oo[6]['stats']
             assert oo[5] == hh[5], seed
-        # the handle holds the state of the last call: full comparison there, status-level comparison for the earlier ones
-        st, so = opt.last_stats(), o2[6]['stats']
-        assert PATH_NAMES[st['path']] == so['path'], (seed, st, so)
-        if o2[5] == 1:                       # every OPTIMAL answer is an active-set solve on discrete sets ('ipm+ref', the
-            _compare(o2, h2, opt, None)      # projection of the interior iterate, does not occur in this campaign: asserted below)
-            assert so['path'] != 'ipm+ref' and so['polished'] == 1, (seed, so)
+            assert PATH_NAMES[st['path']] == so['path'], (seed, st, so)
+            if oo[5] == 1:                   # every OPTIMAL answer is an active-set solve on discrete sets ('ipm+ref', the projection
+                _compare(oo, hh, opt, None, sets)      # of the interior iterate, does not occur in this campaign: asserted here)
+                assert so['path'] != 'ipm+ref' and so['polished'] == 1, (seed, so)
         checked += 1
         opt.close()
     assert checked >= 40
@@ -364,3 +368,82 @@ def test_scalar_readback_paths_agree(seed, infeasible, monkeypatch):
     assert a[5] == b[5] == 1
     for u, v in zip(a[:4], b[:4]):
         assert np.array_equal(u, v)
+
+
+# ----------------------------------------------------------------------------- round 3
+@pytest.mark.parametrize("seed,n,neq,nineq", [(81, 300, 260, 160), (82, 500, 470, 200), (83, 200, 150, 260)])
+def test_null_space_form_parity(seed, n, neq, nineq):
+    """Equality-rich sparse sub-problems (the ACOPF row structure): the interior-point iterations factor the k x k null-space form, the
+    active-set solves run in reduced coordinates, the basis is carried from LP to LP - three LPs on one handle, each compared with
+    the oracle: status, path, working sets, iteration counts, 1e-10 on step and multipliers."""
+    sp = equality_rich_subproblem(seed, n, neq, nineq)
+    rng = np.random.default_rng(seed)
+    qp = opt = None
+    cold = []
+    for call in range(3):
+        sp2 = dict(sp)
+        if call:
+            sp2['dE'] = sp['dE'] * (1.0 + 2e-2 * rng.standard_normal(len(sp['dE'])))
+            sp2['df'] = sp['df'] + 0.1 * rng.standard_normal(n)
+        qp, o_out = oracle_solve(sp2, False, qp)
+        opt, h_out = hip_solve(sp2, False, opt)
+        st, so = opt.last_stats(), o_out[6]['stats']
+        assert o_out[5] == h_out[5] == 1, (call, o_out[5], h_out[5])
+        assert st['ns_dim'] == n - neq and st['ns_iters'] > 0, st                       # the form was used (k = n - #equality rows)
+        assert st['ns_iters'] == so['ns_iters'] and st['ipm_iters'] == so['ipm_iters'], (call, st, so)
+        assert PATH_NAMES[st['path']] == so['path'], (call, st, so)
+        _compare(o_out, h_out, opt, None)
+        cold.append(st['ns_cold'])
+    assert cold == [1, 0, 0], cold                                                      # basis selected once, then carried
+    opt.close()
+
+
+def _acopf_subproblem(pr, x, delta):
+    return dict(n=pr.n, m=pr.m, j_row=pr.j_row, j_col=pr.j_col, dE=pr.eval_jac_g(x, np.zeros(pr.nnz)), df=pr.eval_grad_f(x, np.zeros(pr.n)),
+                f=pr.eval_f(x), E=pr.eval_g(x, np.zeros(pr.m)), x_k=x.copy(), c_lb=pr.g_L, c_ub=pr.g_U, v_lb=pr.x_L, v_ub=pr.x_U, delta=delta)
+
+
+def _highs_value(pr, sp, fr):
+    """Optimal value of the sub-LP from an independent code (SciPy's HiGHS on the sparse statement, oracle/sparse_lp.py)."""
+    from oracle import sparse_lp
+    lp = sparse_lp.build(pr.n, pr.m, pr.j_row, pr.j_col, sp['dE'], sp['df'], sp['E'], pr.g_L, pr.g_U, pr.x_L, pr.x_U, sp['x_k'], sp['delta'], fr)
+    st, obj, p, dt, nit = sparse_lp.solve_highs(lp)
+    return st, obj
+
+
+def test_c4_size_three_consecutive_normal_phase_lps():
+    """case1354pegase-sized grid at load scale 0.5 (the bench workload): three consecutive normal-phase LPs on ONE handle along the
+    SLP's own steps (the second and third re-use the null-space basis), each checked through the LP's optimality certificates
+    recomputed in NumPy and its optimal value against HiGHS."""
+    from activesetmethods_amd import acopf
+    pr = acopf.acopf_problem(acopf.synthetic_case("case1354pegase", 1, 0.5), "c4")
+    x = pr.x0.copy()
+    opt = None
+    for k in range(3):
+        sp = _acopf_subproblem(pr, x, 1000.0)
+        opt, out = hip_solve(sp, False, opt)
+        assert out[5] == 1
+        st = opt.last_stats()
+        assert st['polished'] == 1 and st['ns_iters'] > 0 and st['ns_cold'] == (1 if k == 0 else 0), st
+        _lp_properties(sp, out, opt)
+        hs, hobj = _highs_value(pr, sp, False)
+        assert hs == 1
+        assert abs(sp['df'] @ out[0] - hobj) <= 1e-7 * max(1.0, abs(hobj)), (k, sp['df'] @ out[0], hobj)
+        x = np.clip(x + 0.1 * out[0], pr.x_L, pr.x_U)
+    opt.close()
+
+
+def test_c4_size_three_consecutive_restoration_lps():
+    """The nominal-load case1354pegase-sized grid (never leaves feasibility restoration): three consecutive restoration LPs on ONE
+    handle along damped steps, each with the NumPy certificates and the HiGHS optimal value of _restoration_lp_properties."""
+    from activesetmethods_amd import acopf
+    pr = acopf.acopf_problem(acopf.synthetic_case("case1354pegase", 1), "c4fr")
+    x = pr.x0.copy()
+    opt = None
+    for k in range(3):
+        sp = _acopf_subproblem(pr, x, 1000.0)
+        opt, out = hip_solve(sp, True, opt)
+        assert opt.last_stats()['polished'] == 1
+        _restoration_lp_properties(sp, out)
+        x = np.clip(x + 0.05 * out[0], pr.x_L, pr.x_U)
+    opt.close()

@@ -42,6 +42,36 @@ def random_subproblem(seed, n, m, density=1.0, dup_frac=0.0, n_range=0, infeasib
                 c_lb=c_lb, c_ub=c_ub, v_lb=v_lb, v_ub=v_ub, delta=delta, J=J)
 
 
+def equality_rich_subproblem(seed, n=300, neq=260, nineq=160, per_row=4, delta=0.6):
+    """A sparse sub-problem with the row structure of the ACOPF configurations: many equality rows (their null space is small),
+    fewer inequality rows, a few non-zeros per row - the shape on which the solver eliminates the equality rows
+    (null-space form of the interior-point Newton system, active-set solves in reduced coordinates)."""
+    rng = np.random.default_rng(seed)
+    m = neq + nineq
+    rows = np.repeat(np.arange(m), per_row)
+    cols = np.concatenate([rng.choice(n, per_row, replace=False) for _ in range(m)])
+    # every equality row owns one column (a permuted identity keeps the equality block of full row rank)
+    own = np.arange(neq) * per_row
+    cols[own] = rng.permutation(n)[:neq]
+    vals = rng.standard_normal(len(rows)) * 0.5
+    vals[own] = 1.0 + rng.random(neq)
+    J = np.zeros((m, n))
+    np.add.at(J, (rows, cols), vals)
+    x_k = rng.uniform(-0.3, 0.3, n)
+    v_lb = -np.ones(n); v_ub = np.ones(n)
+    p_star = rng.uniform(-0.2, 0.2, n)
+    E = rng.standard_normal(m) * 0.05
+    act = E + J @ p_star
+    c_lb = np.full(m, -INF); c_ub = np.full(m, INF)
+    c_lb[:neq] = act[:neq]; c_ub[:neq] = act[:neq]
+    k = nineq // 2
+    c_ub[neq:neq + k] = act[neq:neq + k] + rng.uniform(0, 0.05, k)
+    c_lb[neq + k:] = act[neq + k:] - rng.uniform(0, 0.05, nineq - k)
+    df = rng.standard_normal(n)
+    return dict(n=n, m=m, j_row=rows + 1, j_col=cols + 1, dE=vals, df=df, f=0.1, E=E, x_k=x_k,
+                c_lb=c_lb, c_ub=c_ub, v_lb=v_lb, v_ub=v_ub, delta=delta, J=J)
+
+
 def oracle_solve(sp, feasibility=False, qp=None):
     from oracle.subproblem import QpData, QpModel, compute_jacobian_matrix
     A, stored = compute_jacobian_matrix(sp['m'], sp['n'], sp['j_row'] - 1, sp['j_col'] - 1, sp['dE'])
