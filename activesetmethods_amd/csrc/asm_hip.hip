@@ -2780,6 +2780,14 @@ int asm_sublp_reset_warm(asm_handle* h) {
     return ASM_OK;
 }
 
+int asm_sublp_ns_basis(const asm_handle* h, int32_t* J, int64_t* k) {
+    if (!h || !k) return ASM_ERR_ARG;
+    const std::vector<int>& v = h->hint[0].ns_J;
+    *k = (int64_t)v.size();
+    if (J) for (size_t a = 0; a < v.size(); ++a) J[a] = v[a];
+    return ASM_OK;
+}
+
 int asm_sublp_last_stats(const asm_handle* h, asm_solve_stats* out) {
     if (!h || !out) return ASM_ERR_ARG;
     *out = h->stats;

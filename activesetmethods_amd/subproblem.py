@@ -136,6 +136,14 @@ class HipSubOptimizer:
     def reset_warm(self):
         self._check(self._lib.asm_sublp_reset_warm(self._h))
 
+    def ns_basis(self):
+        """Columns (0-based) retained by the null-space form of the normal phase (asm_sublp_ns_basis); empty when the form is not in use."""
+        k = C.c_int64(0)
+        self._check(self._lib.asm_sublp_ns_basis(self._h, None, C.byref(k)))
+        J = np.zeros(max(int(k.value), 1), np.int32)
+        self._check(self._lib.asm_sublp_ns_basis(self._h, J.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(k)))
+        return J[:int(k.value)].astype(np.int64)
+
     def last_stats(self):
         s = _lib.SolveStats()
         self._check(self._lib.asm_sublp_last_stats(self._h, C.byref(s)))

@@ -231,7 +231,7 @@ def highs_sequence(pr, timed, budget_s):
         return dict(error=repr(e))
 
 
-def cpu_baseline(pr, algorithm, budget_s, mix, timed):
+def cpu_baseline(pr, algorithm, budget_s, mix, timed, ns_J=None):
     """Oracle (NumPy restatement of the same path) on a bounded sample of the same workload.
     Small NLPs: whole SLP iterations from x0.  Large NLPs (one LP would take minutes on the host): single
     interior-point iterations of the oracle are timed in both forms of the Newton system and priced with the mix of
@@ -262,9 +262,31 @@ def cpu_baseline(pr, algorithm, budget_s, mix, timed):
                     sample="oracle (NumPy restatement of the same dense algorithm) SLP (%s) from x0, first %d SLP iterations of the same NLP, %.1f s"
                            % (algorithm, steps, t_total),
                     highs_sequence=highs_sequence(pr, timed, budget_s))
-    # large NLPs: one oracle LP takes many minutes.  Time single interior-point iterations of the oracle in the two forms the
-    # solver uses - the M x M row form on the first (normal-phase) sub-LP, the n x n column form on the restoration LP at
-    # the same point - and price the GPU run's own mix of iterations with them (active-set solves by their cubic size ratio).
+    # large NLPs: ONE sub-LP of the timed sequence (the last timed step: its iterate, radius and phase) solved by the oracle end to
+    # end - assembly, formulation, scaling, the LP solve with the same algorithm the GPU runs.  Normal-phase LPs: the columns of
+    # the null-space basis are the ones the GPU run retained (asm_sublp_ns_basis), so the oracle skips its own from-scratch
+    # selection exactly as every LP after the first does; restoration LPs (dense row / column forms, minutes per LP on the host): the
+    # round-2 pricing - single interior-point iterations in both forms, priced with the GPU run's own mix.
+    rec = timed[-1] if timed else None
+    if rec is not None and not rec["fr"]:
+        x = np.asarray(rec["x"], float)
+        t0 = time.perf_counter()
+        dE = pr.eval_jac_g(x, np.zeros(pr.nnz))
+        A, st = compute_jacobian_matrix(pr.m, pr.n, pr.j_row - 1, pr.j_col - 1, dE)
+        qp = QpModel(QpData(pr.eval_grad_f(x, np.zeros(pr.n)), pr.eval_f(x), A, pr.eval_g(x, np.zeros(pr.m)), pr.g_L, pr.g_U, pr.x_L, pr.x_U, st),
+                     pr.j_row, pr.j_col)
+        if ns_J is not None and len(ns_J):
+            qp.hint[False]['ns_J'] = np.asarray(ns_J, np.int64)
+        out = qp.sub_optimize(x, rec["delta"], False)
+        dt = time.perf_counter() - t0
+        stt = out[6]['stats']
+        return dict(value=1.0 / dt, unit="iter/s", cores=cores, kind="port",
+                    sample="oracle (NumPy restatement of the same algorithm incl. the null-space form; scipy.sparse products, LAPACK Cholesky) on ONE sub-LP of the timed "
+                           "sequence, end to end (assembly + formulation + scaling + LP solve): %.1f s, status %d, path %s, %d interior-point "
+                           "iterations (%d in null-space form, dimension %d), basis columns %s"
+                           % (dt, out[5], stt.get('path'), stt.get('ipm_iters', 0), stt.get('ns_iters', 0), len(ns_J) if ns_J is not None else 0,
+                              "taken from the GPU run" if ns_J is not None and len(ns_J) and not stt.get('ns_cold', 1) else "selected from scratch"),
+                    highs_sequence=highs_sequence(pr, timed, budget_s))
     x = pr.x0.copy()
     t0 = time.perf_counter()
     dE = pr.eval_jac_g(x, np.zeros(pr.nnz))
@@ -272,12 +294,14 @@ def cpu_baseline(pr, algorithm, budget_s, mix, timed):
     qp = QpModel(QpData(pr.eval_grad_f(x, np.zeros(pr.n)), pr.eval_f(x), A, pr.eval_g(x, np.zeros(pr.m)), pr.g_L, pr.g_U, pr.x_L, pr.x_U, st),
                  pr.j_row, pr.j_col)
     delta = 1000.0 if algorithm == "Line Search" else 0.4
-    lp = qp.build_lp(x, delta, False)
-    slp, _, _, _ = L.scale_lp(lp)
+    slp_fr, _, _, _ = L.scale_lp(qp.build_lp(x, delta, True))
     t_setup = time.perf_counter() - t0
 
-    def time_iterations(scaled_lp, budget, cap):
+    def time_iterations(scaled_lp, budget, cap, col):
         ip = L.IPM(scaled_lp)
+        ip.ns_ok = False
+        if not col:
+            ip.col_ok = False
         its, t_ipm = 0, 0.0
         while t_ipm < budget and its < cap:
             t1 = time.perf_counter()
@@ -286,19 +310,18 @@ def cpu_baseline(pr, algorithm, budget_s, mix, timed):
             its += 1
         return t_ipm / its, its, ip
 
-    t_row, n_row, _ = time_iterations(slp, 0.6 * budget_s, 4)
+    t_row, n_row, _ = time_iterations(slp_fr, 0.6 * budget_s, 3, False)
     t_col, n_col = t_row, 0
     if mix["col_iters"] > 0:
-        slp_fr, _, _, _ = L.scale_lp(qp.build_lp(x, delta, True))
-        t_col, n_col, ipc = time_iterations(slp_fr, 0.4 * budget_s, 3)
+        t_col, n_col, ipc = time_iterations(slp_fr, 0.4 * budget_s, 3, True)
         if not ipc.col_ok:
             t_col = t_row
     eqp_cost = t_row * 0.2                      # an active-set factorisation has ~0.58 M rows: 0.58^3
     step_s = t_setup + (mix["row_iters"] * t_row + mix["col_iters"] * t_col + mix["eqp"] * eqp_cost) / max(mix["steps"], 1)
     return dict(value=1.0 / step_s, unit="iter/s", cores=cores, kind="port",
-                sample="oracle (NumPy restatement of the same dense algorithm): assembly+formulation+scaling of the first sub-LP (%.1f s), %d row-form interior-point iterations of it (%.1f s each) and "
-                       "%d column-form iterations of the restoration LP at the same point (%.1f s each), priced with the GPU run's own mix per SLP "
-                       "step: %.1f row-form + %.1f column-form iterations + %.1f active-set solves (0.2 row-form iterations each)"
+                sample="oracle (NumPy restatement of the same dense algorithm) on the restoration LP at x0: assembly+formulation+scaling (%.1f s), %d row-form "
+                       "interior-point iterations (%.1f s each) and %d column-form iterations (%.1f s each), priced with the GPU run's own mix per SLP "
+                       "step: %.1f row-form + %.1f column-form iterations + %.1f active-set factorisations (0.2 row-form iterations each)"
                        % (t_setup, n_row, t_row, n_col, t_col, mix["row_iters"] / max(mix["steps"], 1), mix["col_iters"] / max(mix["steps"], 1),
                           mix["eqp"] / max(mix["steps"], 1)),
                 highs_sequence=highs_sequence(pr, timed, budget_s))
@@ -470,6 +493,7 @@ def main():
             "null_space_dimension": max([r["stats"].get("ns_dim", 0) for r in timed], default=0),
             "factorisations_per_lp_all_sizes": _mean([r["stats"]["nfact"] for r in timed])}
         out["lp_outcomes"] = {"paths": hist, "unpolished": sum(1 for r in timed if r["stats"]["polished"] != 1),
+                              "non_canonical_answers": sum(1 for r in timed if r["stats"]["path"] == 9),     # 'ipm+ref': projection of the iterate
                               "status_other": sum(1 for r in timed if r["status"] not in (1, 2)),
                               "restoration_lps": sum(1 for r in timed if r["fr"]),
                               "slp_status_last": int(state["slp"].ret) if state.get("slp") is not None else None,
@@ -480,7 +504,7 @@ def main():
                        eqp=sum(max(r["stats"]["nfact"] - r["stats"]["ipm_iters"], 0) for r in timed))   # active-set FACTORISATIONS
             if not timed:
                 mix = dict(steps=args.steps, col_iters=0, row_iters=nfact, eqp=0)
-            out["cpu_baseline"] = cpu_baseline(pr_host, args.algorithm, args.cpu_seconds, mix, timed)
+            out["cpu_baseline"] = cpu_baseline(pr_host, args.algorithm, args.cpu_seconds, mix, timed, opt.ns_basis())
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

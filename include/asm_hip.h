@@ -98,6 +98,11 @@ int asm_sublp_active_set(const asm_handle* h, int32_t* row_state, int32_t* bound
 /* Drop the retained active sets (the analogue of GLPK's retained basis, slp.jl:38-40). */
 int asm_sublp_reset_warm(asm_handle* h);
 
+/* The other retained state of the normal phase: the columns J (0-based) whose projections span null(A_EF) - the null-space form's
+ * counterpart of a simplex basis (its complement holds a basis of the equality rows).  k = 0 when the form is not in use.
+ * J may be NULL to query k. */
+int asm_sublp_ns_basis(const asm_handle* h, int32_t* J, int64_t* k);
+
 /* Statistics of the last solve / accumulated device-kernel timing. */
 typedef struct {
     int32_t path;          /* 0 warm, 1 ipm stage0+polish, 2 stage1, 3 stage2, 4 ipm+face (non-unique optimum: least-norm point of the optimal

@@ -28,6 +28,7 @@ Dual sign convention = MOI (subproblem.jl:510-529; KKT of common.jl:38):  q - A'
 y_i >= 0 on GE rows, <= 0 on LE rows; z_j >= 0 at lower bound, <= 0 at upper bound.
 """
 import numpy as np
+import scipy.sparse as sps
 from scipy.linalg import solve_triangular
 from scipy.linalg.blas import dsyrk
 
@@ -214,7 +215,11 @@ class NullSpace:
         self.cold = False
         AEF = A[self.E] * self.Fm
         self.AEF = AEF
-        S0 = AEF @ AEF.T
+        # the form is only used on sparse matrices (ns_applicable): the products with the equality / inequality rows go through
+        # scipy.sparse copies (same arithmetic, entries in another order of summation)
+        AEs = sps.csr_matrix(AEF)
+        self.AEs = AEs
+        S0 = (AEs @ AEs.T).toarray()
         idx = np.arange(nE)
         d0 = S0[idx, idx].copy()
         self.L0 = chol_guard(S0, d0, 1e-10)
@@ -228,7 +233,7 @@ class NullSpace:
         def basis_from(J):
             """Orthonormal basis from the columns J of P, or None when P[J, J] has a pivot below NS_WARM_THR."""
             W = chol_solve(self.L0, AEF[:, J])                       # S0^-1 a_j   (nE x k)
-            PJ = -(W.T @ AEF)                                       # P[J, :] = E_J' - W' A_EF
+            PJ = -(AEs.T @ W).T                                     # P[J, :] = E_J' - W' A_EF
             PJ[np.arange(len(J)), J] += 1.0
             PJ *= self.Fm
             T = np.tril(PJ[:, J])
@@ -240,7 +245,7 @@ class NullSpace:
             # second pass ("twice is enough"): the columns J picked in index order can be badly conditioned (cond(L_J) ~ 1e4), which
             # leaves A_EF Z ~ 1e-10 and Z'Z - I ~ 1e-6 - fine for the interior-point steps, not for the active-set solves that must
             # hold the equality rows to 1e-13.  Project the rows once more and orthonormalise with their own Gram matrix (~ I).
-            Z1 = (Z0 - chol_solve(self.L0, AEF @ Z0.T).T @ AEF) * self.Fm
+            Z1 = (Z0 - (AEs.T @ chol_solve(self.L0, AEs @ Z0.T)).T) * self.Fm
             G1 = np.tril(Z1 @ Z1.T)
             L1 = _chol_guard_loop(G1 + np.tril(G1, -1).T, np.ones(len(J)), NS_WARM_THR)
             self.nfact += 1
@@ -253,7 +258,7 @@ class NullSpace:
         J = None if warm_J is None else np.asarray(warm_J, np.int64)
         if warm_Z is not None and warm_Z.shape == (k, n):
             # the previous LP's orthonormal basis, projected onto this LP's null space (one pass: its Gram matrix is close to I)
-            Z1 = (warm_Z - chol_solve(self.L0, AEF @ warm_Z.T).T @ AEF) * self.Fm
+            Z1 = (warm_Z - (AEs.T @ chol_solve(self.L0, AEs @ warm_Z.T)).T) * self.Fm
             G1 = np.tril(Z1 @ Z1.T)
             L1 = _chol_guard_loop(G1 + np.tril(G1, -1).T, np.ones(k), NS_ZWARM_THR)
             self.nfact += 1
@@ -283,9 +288,9 @@ class NullSpace:
         self.Zt = Zt                                                # k x n
         # particular solution of the equality rows (fixed columns at their value): the least-norm one, orthogonal to the null space
         self.pfix = np.where(self.Fm > 0, 0.0, lp.lb)
-        self.pbar = self.pfix + AEF.T @ chol_solve(self.L0, lp.r[self.E] - A[self.E] @ self.pfix)
-        self.AI = A[self.I] * self.Fm
-        self.GI = self.AI @ Zt.T                                    # |I| x k
+        self.pbar = self.pfix + AEs.T @ chol_solve(self.L0, lp.r[self.E] - A[self.E] @ self.pfix)
+        self.AI = sps.csr_matrix(A[self.I] * self.Fm)
+        self.GI = np.asarray(self.AI @ Zt.T)                        # |I| x k
         self.valid = True
 
 
@@ -366,7 +371,7 @@ class IPM:
         """Least-squares multipliers of the equality rows for the current iterate (null-space form carries them as 0)."""
         nsp = self.ns
         w = np.where(self.free, self.lp.q - nsp.AI.T @ self.y[nsp.I] - self.muL + self.muU, 0.0)
-        self.y[nsp.E] = chol_solve(nsp.L0, nsp.AEF @ w)
+        self.y[nsp.E] = chol_solve(nsp.L0, nsp.AEs @ w)
 
     def run(self, tol, max_more):
         lp = self.lp
@@ -719,7 +724,7 @@ def eqp_ns(lp, nsp, sets, sweeps=3):
     y[Ia] = lam[len(B):]
     w = (lp.q - A[Ia].T @ lam[len(B):]) * Fm
     w[B] -= lam[:len(B)]
-    y[nsp.E] = chol_solve(nsp.L0, nsp.AEF @ w)
+    y[nsp.E] = chol_solve(nsp.L0, nsp.AEs @ w)
     return p, lp.slo.copy(), y, nfact
 
 

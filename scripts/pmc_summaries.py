@@ -1,21 +1,21 @@
 #!/usr/bin/env python3
-"""profiles/r02_<wl>_pmc_mfma.txt, profiles/r02_<wl>_pmc_traffic.{txt,json} from the per-kernel sums scripts/probe/pmc_collect.sh
-leaves under gpurun_out/pmc_r02_{mfma,fetch,write}/ (three separate rocprofv3 --pmc passes of the same command).
+"""<tag>_<wl>_pmc_mfma.txt, <tag>_<wl>_pmc_traffic.{txt,json} from the per-kernel sums scripts/probe/pmc_collect.sh
+leaves under gpurun_out/pmc_<tag>_<wl>/{mfma,clock,fetch,write}/ (three separate rocprofv3 --pmc passes of the same command).
 FETCH_SIZE is doubled for gfx950 as /opt/skills/guides/MI355X_MICROARCH.md prescribes (wide coalesced reads are tallied at 1/2).
-usage: pmc_summaries.py <workload>"""
+usage: pmc_summaries.py <round tag> <workload> "<profiled command>"   (writes gpurun_out/<tag>_<wl>_pmc_*.{txt,json}; copy to profiles/)"""
 import json, sys
-wl = sys.argv[1]
-M = json.load(open("gpurun_out/pmc_r02_mfma/m_summary.json"))["sums"]
-F = json.load(open("gpurun_out/pmc_r02_fetch/f_summary.json"))["sums"]
-W = json.load(open("gpurun_out/pmc_r02_write/w_summary.json"))["sums"]
+tag, wl, CMD = sys.argv[1], sys.argv[2], sys.argv[3]
+base = "gpurun_out/pmc_%s_%s" % (tag, wl)
+M = json.load(open(base + "/mfma/m_summary.json"))["sums"]
+F = json.load(open(base + "/fetch/f_summary.json"))["sums"]
+W = json.load(open(base + "/write/w_summary.json"))["sums"]
 try:
-    CK = json.load(open("gpurun_out/pmc_r02_clock/c_summary.json"))["sums"]
+    CK = json.load(open(base + "/clock/c_summary.json"))["sums"]
 except Exception:
     CK = {}
-CMD = "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
-with open("profiles/r02_%s_pmc_mfma.txt" % wl, "w") as f:
+with open("gpurun_out/%s_%s_pmc_mfma.txt" % (tag, wl), "w") as f:
     f.write("# rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS --kernel-trace -- %s\n" % CMD)
-    f.write("# (workload %s, MI355X, round 2; counters collected in their own pass: kernels run serialised under --pmc, so these are the kernels ALONE on the chip)\n" % wl)
+    f.write("# (workload %s, MI355X, round %s; counters collected in their own pass: kernels run serialised under --pmc, so these are the kernels ALONE on the chip)\n" % (wl, tag[1:]))
     f.write("# mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (kernel time x 2.4 GHz x 1024 SIMDs); tflops = SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 / kernel time;\n")
     f.write("# wait_any / wait_inst / active / wait_lds = share of SQ_WAVE_CYCLES\n")
     f.write("# clock_GHz = GRBM_GUI_ACTIVE / 8 / kernel time (own pass; MI355X_MICROARCH.md, DVFS give-back); busy@clk = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs):\n")
@@ -43,14 +43,14 @@ doc = {"_comment": "HBM traffic per launch of the dominant kernel family (k_syrk
        "workload": wl, "kernel": "k_syrk_upd + k_syrk<T,NW,KC,WPE> (all rank-K launches)", "launches": L,
        "fetch_bytes_per_launch": sum(v["fetch_bytes"] for v in per.values()) / L, "write_bytes_per_launch": sum(v["write_bytes"] for v in per.values()) / L,
        "traffic_bytes_per_launch": sum(v["fetch_bytes"] + v["write_bytes"] for v in per.values()) / L, "per_instantiation": per}
-json.dump(doc, open("profiles/r02_%s_pmc_traffic.json" % wl, "w"), indent=1)
-with open("profiles/r02_%s_pmc_traffic.txt" % wl, "w") as f:
-    f.write("# HBM traffic of the k_syrk kernels (PMC, separate passes, one counter per pass), MI355X, round 2\n")
+json.dump(doc, open("gpurun_out/%s_%s_pmc_traffic.json" % (tag, wl), "w"), indent=1)
+with open("gpurun_out/%s_%s_pmc_traffic.txt" % (tag, wl), "w") as f:
+    f.write("# HBM traffic of the k_syrk kernels (PMC, separate passes, one counter per pass), MI355X, round %s\n" % tag[1:])
     f.write("#   rocprofv3 --pmc FETCH_SIZE --kernel-trace -- %s\n#   rocprofv3 --pmc WRITE_SIZE --kernel-trace -- %s\n" % (CMD, CMD))
     f.write("# FETCH_SIZE / WRITE_SIZE are reported in KB; FETCH_SIZE x2 (gfx950: wide coalesced reads are tallied at 1/2, MI355X_MICROARCH.md, HBM section).\n")
     f.write("%-24s %8s %16s %16s %12s\n" % ("kernel", "launches", "fetch MB/launch", "write MB/launch", "ms/launch"))
     for k, v in per.items():
         f.write("%-24s %8d %16.1f %16.1f %12.3f\n" % (k, v["launches"], v["fetch_bytes"] / v["launches"] / 1e6, v["write_bytes"] / v["launches"] / 1e6, v["time_ms"] / v["launches"]))
     g = F.get("k_gemv_n", None)
-print(open("profiles/r02_%s_pmc_mfma.txt" % wl).read())
-print(open("profiles/r02_%s_pmc_traffic.txt" % wl).read())
+print(open("gpurun_out/%s_%s_pmc_mfma.txt" % (tag, wl)).read())
+print(open("gpurun_out/%s_%s_pmc_traffic.txt" % (tag, wl)).read())
