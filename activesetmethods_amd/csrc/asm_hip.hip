@@ -161,6 +161,7 @@ struct asm_handle {
     bool nz_valid = false;
     int nz_T = 0, nz_pitch = 0;
     double nz_fraction = 1.0;       // executed share of the (tile pair, k-chunk) products of the Schur build
+    double nz_frac_cache[2] = {-1.0, -1.0};   // ... cached per handle: all rows / the equality rows (the pattern is fixed)
     // ---- null-space form of the interior-point Newton system (asm_ns_kernels.hip.h; oracle: class NullSpace)
     bool ns_cap = false;            // the LP skeleton qualifies (sparse pattern, enough hard equality rows, small null space)
     int ns_nE = 0, ns_nI = 0, ns_nEp = 0, ns_nIp = 0, ns_kcap = 0;
@@ -423,7 +424,7 @@ struct Dev {
         if (skip) {
             hipLaunchKernelGGL(k_tile_nzflags, dim3((unsigned)nt, (unsigned)((nch + 7) / 8)), dim3(256), 0, h->stream, h->d_Ah, h->ldn, (int64_t)Ms, TS, nch,
                                nz2, nch, idx_dev);
-            frac = executed_fraction(nz2, nt, nch);
+            frac = executed_fraction(nz2, nt, nch, idx_dev == h->d_nsEidx ? 1 : -1);
         }
         int id = begin(ASM_K_SYRK, frac * (double)Ms * (Ms + 1) * h->ldn, 8.0 * (Ms * (double)h->ldn + 0.5 * Ms * (double)Ms));
         launch_syrk(T, h->d_Ah, h->ldn, idx_dev, 0, Ms, (int)h->ldn, theta_dev, nullptr, S, ldS, 0, 0, -1, skip ? nz2 : nullptr, nch, frac);
@@ -502,11 +503,19 @@ struct Dev {
         hipLaunchKernelGGL(k_tile_nzflags, dim3((unsigned)nt, (unsigned)((nch + 7) / 8)), dim3(256), 0, h->stream, h->d_Ah, h->ldn, h->M, TS,
                            nch, h->d_nz, h->nz_pitch, (const int*)nullptr);
         h->nz_valid = true;
-        h->nz_fraction = executed_fraction(h->d_nz, nt, nch);
+        h->nz_fraction = executed_fraction(h->d_nz, nt, nch, 0);
     }
     // fraction of (tile pair, chunk) products actually executed: keeps the flop accounting of the roofline honest
-    double executed_fraction(const unsigned char* d_flags, int nt, int nch) {
+    double executed_fraction(const unsigned char* d_flags, int nt, int nch, int cache_slot = -1) {
         if (h->timing == 0) return h->nz_valid ? h->nz_fraction : 1.0;      // only the flop accounting needs it: no read-back when timing is off
+        // the flags follow the fixed pattern of the Jacobian: for the row sets that recur every LP (all rows; the equality rows of the
+        // null-space form) the share is computed once per handle - the read-back and the O(nt^2 nch) host loop cost milliseconds per LP
+        if (cache_slot >= 0 && h->nz_frac_cache[cache_slot] >= 0.0) return h->nz_frac_cache[cache_slot];
+        const double fr_ = executed_fraction_now(d_flags, nt, nch);
+        if (cache_slot >= 0) h->nz_frac_cache[cache_slot] = fr_;
+        return fr_;
+    }
+    double executed_fraction_now(const unsigned char* d_flags, int nt, int nch) {
         std::vector<unsigned char> fl((size_t)nt * nch);
         HIPCHK(hipMemcpyAsync(fl.data(), d_flags, fl.size(), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -2100,7 +2109,7 @@ void free_device(asm_handle* h) {
     F(h->d_dE); F(h->d_J); F(h->d_Ah); F(h->d_S); F(h->d_c); F(h->d_rho); F(h->d_theta); F(h->d_diag); F(h->d_diag0);
     F(h->d_vecN); F(h->d_vecM); F(h->d_vecM2); F(h->d_partial); F(h->d_idx); F(h->d_Linv); F(h->d_Binv); F(h->d_wpart); F(h->d_BinvT); F(h->d_wt);
     h->d_Binv = h->d_wpart = h->d_BinvT = h->d_wt = nullptr; F(h->d_ipm); F(h->d_ipm_i); F(h->d_nz);
-    h->d_nz = nullptr; h->nz_valid = false;
+    h->d_nz = nullptr; h->nz_valid = false; h->nz_frac_cache[0] = h->nz_frac_cache[1] = -1.0;
     F(h->d_idxI); F(h->d_rdI); F(h->d_rce); F(h->d_rze); F(h->d_sdiag);
     h->d_idxI = nullptr; h->d_rdI = h->d_rce = h->d_rze = h->d_sdiag = nullptr;
     F(h->d_AhT); F(h->d_cdinv); F(h->d_cth); F(h->d_cu); F(h->d_ct); F(h->d_cv); F(h->d_cw); F(h->d_nzT);

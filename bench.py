@@ -370,7 +370,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--scenarios-per-gpu", type=int, default=None, help="workload c5: scenarios per GPU (alias of --steps)")
     ap.add_argument("--max-iter", type=int, default=100, help="workload c5: SLP iteration cap per scenario")
-    ap.add_argument("--concurrency", type=int, default=4, help="workload c5: scenarios in flight per GPU (one handle / HIP stream each)")
+    ap.add_argument("--concurrency", type=int, default=2, help="workload c5: scenarios in flight per GPU (one handle / HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-eval", action="store_true", help="evaluate f, grad f, g, Jacobian values with the NumPy callbacks instead of the device kernels")
     ap.add_argument("--kernel-breakdown", action="store_true",
