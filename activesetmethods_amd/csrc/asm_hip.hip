@@ -2434,15 +2434,28 @@ void solve_raw(asm_handle* h, const LpRaw& L, int slot, LpSol& out) {
     h->stats.M = (int)M; h->stats.n = (int)n; h->stats.ns = (int)lp.ns;
     // Jacobian -> dense rows incl. range rows; scaled copy (column scale = min(box, matrix cap), oracle: scale_lp)
     vec c(n), rel(n);
+    const double tr0 = Solver::now_ms();
+    auto lap = [&](const char* what) {
+        if (!h->verbose) return;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        static thread_local double last = 0.0;
+        const double t = Solver::now_ms();
+        std::fprintf(stderr, "[asm] solve_raw %-10s +%.2f ms\n", what, t - (last > tr0 ? last : tr0));
+        last = t;
+    };
     sv.dev.assemble();
+    lap("assemble");
     sv.dev.col_relmax(rel.data());
+    lap("relmax");
     for (int64_t j = 0; j < n; ++j) {
         double c_mat = rel[j] > 0.0 ? 1.0 / rel[j] : 1.0;
         c[j] = pow2_round(std::min(std::max(L.ub[j], -L.lb[j]), c_mat));
     }
     vec rho(M);
     sv.dev.scale(c.data(), rho.data());
+    lap("scale");
     sv.dev.tile_flags();
+    lap("flags");
     lp.q.resize(n); lp.lb.resize(n); lp.ub.resize(n); lp.r.resize(M); lp.w.resize(lp.ns); lp.slo.resize(lp.ns);
     double qmax = 0.0;
     for (int64_t j = 0; j < n; ++j) { lp.q[j] = L.q[j] * c[j]; qmax = std::max(qmax, std::fabs(lp.q[j])); }
@@ -2456,7 +2469,9 @@ void solve_raw(asm_handle* h, const LpRaw& L, int slot, LpSol& out) {
     for (double v : lp.w) lp.scale_q = std::max(lp.scale_q, std::fabs(v));
 
     Solver::EqpOut o;
+    lap("host-lp");
     out.status = sv.solve_scaled(&h->warm[slot], h->hint[slot]);
+    lap("solve");
     if (out.status == ASM_OPTIMAL) {
         sv.as_download(o, out.as);
         const ActiveSet& prev = h->warm[slot];
@@ -2484,8 +2499,11 @@ void solve_raw(asm_handle* h, const LpRaw& L, int slot, LpSol& out) {
     } else {
         h->last = ActiveSet();
     }
+    lap("extract");
     sv.dev.resolve_timing();
+    lap("timing");
     check_panel_timeout(h);
+    lap("ptmo");
 }
 
 void do_solve(asm_handle* h, double delta, int feasibility, double* p_out, double* lambda, double* mult_x_U, double* mult_x_L,
