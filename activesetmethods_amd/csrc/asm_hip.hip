@@ -107,6 +107,7 @@ struct FacBuf {
     double *S = nullptr, *Linv = nullptr, *Binv = nullptr, *BinvT = nullptr;
     int64_t ld = 0;
     int wb = 512;                   // wide-block width of its substitution kernels
+    bool small = false;             // k x k systems of the null-space form: solved in one workgroup when the order is <= ASM_SMALL_MAX
 };
 
 }  // namespace
@@ -263,9 +264,10 @@ struct Dev {
     double *fS, *fLinv, *fBinv, *fBinvT;
     int64_t fld;
     int fwb;
+    bool fsmall = false;
     explicit Dev(asm_handle* hh) : h(hh), cur(hh->stream) { use_main(); }
-    void use_main() { fS = h->d_S; fld = h->Mp; fLinv = h->d_Linv; fBinv = h->d_Binv; fBinvT = h->d_BinvT; fwb = h->wb; }
-    void use_factor(const FacBuf& f) { fS = f.S; fld = f.ld; fLinv = f.Linv; fBinv = f.Binv; fBinvT = f.BinvT; fwb = f.wb; }
+    void use_main() { fS = h->d_S; fld = h->Mp; fLinv = h->d_Linv; fBinv = h->d_Binv; fBinvT = h->d_BinvT; fwb = h->wb; fsmall = false; }
+    void use_factor(const FacBuf& f) { fS = f.S; fld = f.ld; fLinv = f.Linv; fBinv = f.Binv; fBinvT = f.BinvT; fwb = f.wb; fsmall = f.small; }
 
     hipEvent_t get_event() {
         if (!h->event_pool.empty()) {
@@ -532,6 +534,10 @@ struct Dev {
     }
     void chol_solve_dev(const double* rhs_dev, double* out_dev, int Ms) {
         // the substitution runs in place in the caller's output buffer (w), z in d_vecM
+        if (fsmall && Ms <= ASM_SMALL_USE) {       // small systems: one workgroup, factor + inverses of its 64-wide diagonal blocks
+            hipLaunchKernelGGL(k_small_solve, dim3(1), dim3(1024), 0, h->stream, (const double*)fS, fld, (const double*)fLinv, Ms, rhs_dev, out_dev);
+            return;
+        }
         if (out_dev != rhs_dev) HIPCHK(hipMemcpyAsync(out_dev, rhs_dev, Ms * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         int id = begin(ASM_K_TRSV, 2.0 * Ms * (double)Ms, 8.0 * Ms * (double)Ms);
         solve_w = out_dev;
@@ -618,10 +624,17 @@ struct Dev {
                                    fS, fld, Ms, fBinv, fBinvT, hh, stage);
         hipLaunchKernelGGL((k_transpose_wb<WB>), dim3(nW, WSUB * WSUB), dim3(256), 0, h->stream, fBinv, fBinvT);
     }
-    void chol(int Ms, double thr = 1e-14) {
+    // want_inverse = false: the caller only solves against the factor and the factor is a "small" one (one-workgroup solves): the
+    // explicit inverses of the wide blocks are not built
+    void chol(int Ms, double thr = 1e-14, bool want_inverse = true) {
         if (Ms <= 0) return;
         int id = begin(ASM_K_CHOL, (double)Ms * Ms * Ms / 3.0, 8.0 * 1.5 * Ms * (double)Ms);
         chol_launches(Ms, thr);
+        if (!want_inverse && fsmall && Ms <= ASM_SMALL_USE) {
+            end(id);
+            h->stats.nfact += 1;
+            return;
+        }
         // explicit inverses of the wide diagonal blocks by divide and conquer over the 64-wide sub-blocks: diagonal
         // blocks from k_potrf_diag, then log2 levels of two launches each (the scratch T uses the buffer of the
         // transposed copy, which is written afterwards)
@@ -1014,6 +1027,7 @@ struct Solver {
         h->d_nsX = ns_dalloc(h, (int64_t)cap * h->ns_nEp);
         h->d_nsG = ns_dalloc(h, (int64_t)cap * h->ns_ldg);
         ns_alloc_factor(h, h->ns_fN, cap);
+        h->ns_fN.small = true;
         h->d_nsN0 = ns_dalloc(h, h->ns_fN.ld * h->ns_fN.ld);
         h->d_nsZT = ns_dalloc(h, h->ldn * h->ns_fN.ld);        // transposed copy of the basis rows (right operand of the orthonormalisation product)
         int* dj = nullptr;
@@ -1024,6 +1038,7 @@ struct Solver {
         // active-set solves in reduced coordinates: up to 2 cap constraints (an over-determined working set has more than k)
         h->ns_ccap = (int)std::min<int64_t>(2 * cap, h->Mp);
         ns_alloc_factor(h, h->ns_fC, h->ns_ccap);
+        h->ns_fC.small = true;
         int* qi = nullptr;
         dmalloc(&qi, (int64_t)h->ns_ccap + h->ldn + h->ns_nIp + 16);
         h->ns_bufs.push_back((void*)qi);
@@ -1250,7 +1265,7 @@ struct Solver {
             dev.use_factor(h->ns_fC);
             dev.launch_syrk(Dev::pick_tile(nact), Q.Csel, Q.ldc, nullptr, 0, nact, (int)Q.ldc, nullptr, nullptr, h->ns_fC.S, h->ns_fC.ld, 0, 0);
             dev.diag_prepare(nact, 1, 0.0, 0.0);
-            dev.chol(nact, 1e-10);
+            dev.chol(nact, 1e-10, false);
             for (int sw = 0; sw < 3; ++sw) {
                 nsq_gemv_n(Q, nact, Q.u, Q.v);                                                                           // C u
                 hipLaunchKernelGGL(k_nseq_sub, dim3(gA), dim3(256), 0, h->stream, (const double*)Q.d, (const double*)Q.v, Q.v, (int64_t)nact);
@@ -1301,11 +1316,11 @@ struct Solver {
     // Per iteration (oracle: IPM.run, use_ns branch): reduced matrix N = Zt Th Zt' + GI' D_I^-1 GI (an unregularised copy is kept for the
     // refinement sweep), its factor, dpbar = A_EF' S0^-1 (-rp_E) and K dpbar (shared by predictor and corrector)
     void ns_iter_setup() {
-        const int k = ip.ns_k, nE = h->ns_nE;
+        const int k = ip.ns_k;
         const int64_t M = lp.M, ldn = h->ldn;
         const NsIdx X = nsX();
-        const unsigned gM = (unsigned)((M + 255) / 256), gN = (unsigned)((ldn + 255) / 256), gE = (unsigned)((nE + 255) / 256);
-        double *dpb = nsv(0), *kdpb = nsv(1), *atw = nsv(4), *yM = nsv(5), *aM = nsv(6), *rE = nsv(8), *tE = nsv(9);
+        const unsigned gM = (unsigned)((M + 255) / 256), gN = (unsigned)((ldn + 255) / 256);
+        double *dpb = nsv(0), *kdpb = nsv(1), *atw = nsv(4), *yM = nsv(5), *aM = nsv(6);
         const double* th = h->d_nsth;
         const double* thI = h->d_nsth + ldn;
         hipLaunchKernelGGL(k_ns_theta, dim3((unsigned)((std::max<int64_t>(ldn, h->ns_nIp) + 255) / 256)), dim3(256), 0, h->stream, P, X, IPM_RHO_P, h->d_nsth, ldn, h->ns_nIp);
@@ -1315,7 +1330,7 @@ struct Solver {
         dev.end(id);
         hipLaunchKernelGGL(k_ns_copy_lower, dim3((unsigned)((k + 255) / 256), (unsigned)k), dim3(256), 0, h->stream, (const double*)h->ns_fN.S, h->ns_fN.ld, h->d_nsN0, h->ns_fN.ld, k);
         dev.diag_prepare(k, 0, 1e-13, 1e-30);
-        dev.chol(k);
+        dev.chol(k, 1e-14, false);
         // dpbar = -e: the component of the iterate outside pbar + null(A_EF), split off once per LP and shrunk by (1 - a) with every step
         double* e = nsv(14);
         if (!ip.ns_e_ready) {
@@ -1336,11 +1351,11 @@ struct Solver {
     // One Newton solve in null-space form (oracle: IPM.run, solve_ns): mode 0 affine, 1 Mehrotra corrector on `base`.  The relative residual of
     // the reduced solve (after its refinement sweep) is accumulated in SC_NSERR.
     void ns_newton(int mode, const IpmDir& base, IpmDir& D) {
-        const int k = ip.ns_k, nE = h->ns_nE;
+        const int k = ip.ns_k;
         const int64_t M = lp.M, n = lp.n, ldn = h->ldn;
         const NsIdx X = nsX();
-        const unsigned g = grid_all(), gM = (unsigned)((M + 255) / 256), gN = (unsigned)((ldn + 255) / 256), gE = (unsigned)((nE + 255) / 256), gK = (unsigned)((k + 255) / 256);
-        double *dpb = nsv(0), *kdpb = nsv(1), *ht = nsv(2), *v = nsv(3), *atw = nsv(4), *yM = nsv(5), *aM = nsv(6), *bI = nsv(7), *rE = nsv(8), *tE = nsv(9);
+        const unsigned g = grid_all(), gM = (unsigned)((M + 255) / 256), gN = (unsigned)((ldn + 255) / 256), gK = (unsigned)((k + 255) / 256);
+        double *dpb = nsv(0), *kdpb = nsv(1), *ht = nsv(2), *v = nsv(3), *atw = nsv(4), *yM = nsv(5), *aM = nsv(6), *bI = nsv(7);
         double *ru = nsv(10), *du = nsv(11), *rr = nsv(12), *dd = nsv(13);
         const double* th = h->d_nsth;
         const double* thI = h->d_nsth + ldn;
@@ -1350,14 +1365,20 @@ struct Solver {
         dev.gemv_t_dev(h->d_Ah, yM, atw);
         hipLaunchKernelGGL(k_ns_ht, dim3(gN), dim3(256), 0, h->stream, th, (const double*)P.hp, (const double*)atw, (const double*)kdpb, res, ht, v, n, ldn);
         hipLaunchKernelGGL(k_gemv_n, dim3((unsigned)((k + 3) / 4)), dim3(256), 0, h->stream, (const double*)h->d_nsG, h->ns_ldg, (const double*)v, ru, (int64_t)k, ldn);
-        dev.use_factor(h->ns_fN);
-        dev.chol_solve_dev(ru, du, k);
-        hipLaunchKernelGGL(k_ns_symv_res, dim3((unsigned)((k + 3) / 4)), dim3(256), 0, h->stream, (const double*)h->d_nsN0, h->ns_fN.ld, k, (const double*)du, (const double*)ru, rr);
-        dev.chol_solve_dev(rr, dd, k);
-        dev.use_main();
-        hipLaunchKernelGGL(k_ns_add, dim3(gK), dim3(256), 0, h->stream, (const double*)du, (const double*)dd, du, (int64_t)k);
-        hipLaunchKernelGGL(k_ns_symv_res, dim3((unsigned)((k + 3) / 4)), dim3(256), 0, h->stream, (const double*)h->d_nsN0, h->ns_fN.ld, k, (const double*)du, (const double*)ru, rr);
-        hipLaunchKernelGGL(k_ns_relres, dim3(1), dim3(1024), 0, h->stream, (const double*)rr, (const double*)ru, k, P.scal + SC_NSERR);
+        if (k <= ASM_SMALL_USE) {
+            // solve, refinement sweep on the unregularised matrix and the residual check in ONE one-workgroup launch
+            hipLaunchKernelGGL(k_ns_reduced_solve, dim3(1), dim3(1024), 0, h->stream, (const double*)h->ns_fN.S, h->ns_fN.ld, (const double*)h->ns_fN.Linv,
+                               (const double*)h->d_nsN0, k, (const double*)ru, du, P.scal + SC_NSERR);
+        } else {
+            dev.use_factor(h->ns_fN);
+            dev.chol_solve_dev(ru, du, k);
+            hipLaunchKernelGGL(k_ns_symv_res, dim3((unsigned)((k + 3) / 4)), dim3(256), 0, h->stream, (const double*)h->d_nsN0, h->ns_fN.ld, k, (const double*)du, (const double*)ru, rr);
+            dev.chol_solve_dev(rr, dd, k);
+            dev.use_main();
+            hipLaunchKernelGGL(k_ns_add, dim3(gK), dim3(256), 0, h->stream, (const double*)du, (const double*)dd, du, (int64_t)k);
+            hipLaunchKernelGGL(k_ns_symv_res, dim3((unsigned)((k + 3) / 4)), dim3(256), 0, h->stream, (const double*)h->d_nsN0, h->ns_fN.ld, k, (const double*)du, (const double*)ru, rr);
+            hipLaunchKernelGGL(k_ns_relres, dim3(1), dim3(1024), 0, h->stream, (const double*)rr, (const double*)ru, k, P.scal + SC_NSERR);
+        }
         ns_gemv_t_dense(du, k, v);
         hipLaunchKernelGGL(k_ns_dp, dim3(gN), dim3(256), 0, h->stream, P, D, th, (const double*)dpb, res, (const double*)v, ldn);
         dev.gemv_n_dev(h->d_Ah, D.dp, aM);
@@ -1365,6 +1386,10 @@ struct Solver {
     }
     // out[n] = Zt' u   (Zt dense, k rows of pitch ldg)
     void ns_gemv_t_dense(const double* u, int k, double* out) {
+        if (k <= ASM_SMALL_USE) {
+            hipLaunchKernelGGL(k_gemv_t_small, dim3((unsigned)((h->ldn + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->d_nsG, h->ns_ldg, k, u, out, h->ldn);
+            return;
+        }
         int64_t R = std::min<int64_t>((k + 31) / 32, ASM_TMAXCHUNKS);
         int64_t chunk = (k + R - 1) / R;
         R = (k + chunk - 1) / chunk;

@@ -532,3 +532,131 @@ __global__ __launch_bounds__(1024) void k_ns_relres(const double* __restrict__ r
     b = blk_reduce_max(b, sh);
     if (threadIdx.x == 0) slot[0] = fmax(slot[0], a / b);
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Small systems (order k <= 1024) in ONE workgroup: the k x k matrices of the null-space form are factored in every interior-point
+// iteration and solved against a handful of times; with the explicit block inverses + wide-block substitution of the large
+// factorisations that is ~10 launches per factorisation and 4 per solve - more launch overhead than arithmetic.  Here the solve uses
+// the factor L (lower, pitch ld) and the inverses of its 64 x 64 diagonal blocks (Linv, written by the factorisation), vectors in LDS.
+#define ASM_SMALL_MAX 1024      // LDS capacity of the one-workgroup kernels
+#define ASM_SMALL_USE 256       // ... used up to this order: beyond it one workgroup is slower than the launches it saves (k = 519: 86 vs 66 ms per C4 LP)
+// x (LDS, length k) <- (L L')^-1 x.   t: LDS scratch (k), part: LDS scratch (16 * 64).  Called by all 1024 threads.
+__device__ __forceinline__ void small_chol_solve(const double* __restrict__ L, int64_t ld, const double* __restrict__ Linv, int k, double* x, double* t, double* part) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nb = (k + 63) >> 6;
+    // forward: L z = x   (z overwrites x block by block)
+    for (int b = 0; b < nb; ++b) {
+        const int b0 = b << 6;
+        for (int rr = wv; rr < 64; rr += 16) {                     // t_b = x_b - L[b, 0:b0] z[0:b0]: one wavefront per row, lanes along the row
+            const int row = b0 + rr;
+            double acc = 0.0;
+            if (row < k)
+                for (int j = lane; j < b0; j += 64) acc = fma(L[(int64_t)row * ld + j], x[j], acc);
+            acc = wave_sum(acc);
+            if (lane == 0) t[rr] = row < k ? x[row] - acc : 0.0;
+        }
+        __syncthreads();
+        {                                                          // z_b = Linv_b t_b  (64 x 64, lower triangular)
+            const double* Lb = Linv + (int64_t)b * 64 * 64;
+            const int row = lane, c0 = wv * 4;
+            double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc = fma(Lb[row * 64 + c0 + c], t[c0 + c], acc);
+            part[wv * 64 + row] = acc;
+        }
+        __syncthreads();
+        if (tid < 64 && b0 + tid < k) {
+            double acc = 0.0;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) acc += part[p * 64 + tid];
+            x[b0 + tid] = acc;
+        }
+        __syncthreads();
+    }
+    // backward: L' y = z
+    for (int b = nb - 1; b >= 0; --b) {
+        const int b0 = b << 6, b1 = min(b0 + 64, k);
+        {                                                          // t_b = z_b - L[b1:, b]' y[b1:]: thread = (column of the block, row residue mod 16)
+            const int c = lane;
+            double acc = 0.0;
+            if (b0 + c < k)
+                for (int r = b1 + wv; r < k; r += 16) acc = fma(L[(int64_t)r * ld + b0 + c], x[r], acc);
+            part[wv * 64 + c] = acc;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            double acc = 0.0;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) acc += part[p * 64 + tid];
+            t[tid] = b0 + tid < k ? x[b0 + tid] - acc : 0.0;
+        }
+        __syncthreads();
+        {                                                          // y_b = Linv_b' t_b
+            const double* Lb = Linv + (int64_t)b * 64 * 64;
+            const int col = lane, r0 = wv * 4;
+            double acc = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = fma(Lb[(r0 + r) * 64 + col], t[r0 + r], acc);
+            part[wv * 64 + col] = acc;
+        }
+        __syncthreads();
+        if (tid < 64 && b0 + tid < k) {
+            double acc = 0.0;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) acc += part[p * 64 + tid];
+            x[b0 + tid] = acc;
+        }
+        __syncthreads();
+    }
+}
+// out = (L L')^-1 rhs
+__global__ __launch_bounds__(1024) void k_small_solve(const double* __restrict__ L, int64_t ld, const double* __restrict__ Linv, int k,
+                                                      const double* __restrict__ rhs, double* __restrict__ out) {
+    __shared__ double x[ASM_SMALL_MAX], t[64], part[16 * 64];
+    for (int i = threadIdx.x; i < k; i += 1024) x[i] = rhs[i];
+    __syncthreads();
+    small_chol_solve(L, ld, Linv, k, x, t, part);
+    for (int i = threadIdx.x; i < k; i += 1024) out[i] = x[i];
+}
+// r (LDS) = rhs - N0 x  with N0 symmetric, lower triangle stored: one wavefront per row
+__device__ __forceinline__ void small_symv_res(const double* __restrict__ N0, int64_t ld, int k, const double* x, const double* rhs, double* r) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i = wv; i < k; i += 16) {
+        double acc = 0.0;
+        for (int j = lane; j <= i; j += 64) acc = fma(N0[(int64_t)i * ld + j], x[j], acc);
+        for (int j = i + 1 + lane; j < k; j += 64) acc = fma(N0[(int64_t)j * ld + i], x[j], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) r[i] = rhs[i] - acc;
+    }
+    __syncthreads();
+}
+// The reduced solve of a null-space Newton step in one launch (oracle: solve_ns): du = N^-1 ru, one refinement sweep on the unregularised
+// N0, and slot[0] = max(slot[0], max|ru - N0 du| / max(1, max|ru|)).
+__global__ __launch_bounds__(1024) void k_ns_reduced_solve(const double* __restrict__ L, int64_t ld, const double* __restrict__ Linv, const double* __restrict__ N0,
+                                                           int k, const double* __restrict__ ru, double* __restrict__ du, double* __restrict__ slot) {
+    __shared__ double x[ASM_SMALL_MAX], y[ASM_SMALL_MAX], b[ASM_SMALL_MAX], t[64], part[16 * 64], sh[16];
+    for (int i = threadIdx.x; i < k; i += 1024) { b[i] = ru[i]; x[i] = ru[i]; }
+    __syncthreads();
+    small_chol_solve(L, ld, Linv, k, x, t, part);          // x = du0
+    small_symv_res(N0, ld, k, x, b, y);                    // y = ru - N0 du0
+    small_chol_solve(L, ld, Linv, k, y, t, part);          // y = correction
+    for (int i = threadIdx.x; i < k; i += 1024) x[i] += y[i];
+    __syncthreads();
+    small_symv_res(N0, ld, k, x, b, y);                    // y = ru - N0 du
+    double a = 0.0, m = 1.0;
+    for (int i = threadIdx.x; i < k; i += 1024) { a = fmax(a, fabs(y[i])); m = fmax(m, fabs(b[i])); du[i] = x[i]; }
+    a = blk_reduce_max(a, sh);
+    m = blk_reduce_max(m, sh);
+    if (threadIdx.x == 0) slot[0] = fmax(slot[0], a / m);
+}
+// out[j] = sum_c Zt[c, j] u[c]   (k rows of pitch ld, one thread per column; u staged in LDS) - the basis applied in one launch
+__global__ __launch_bounds__(256) void k_gemv_t_small(const double* __restrict__ Zt, int64_t ld, int k, const double* __restrict__ u, double* __restrict__ out, int64_t ncols) {
+    __shared__ double us[ASM_SMALL_MAX];
+    for (int i = threadIdx.x; i < k; i += 256) us[i] = u[i];
+    __syncthreads();
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= ncols) return;
+    double acc = 0.0;
+    for (int c = 0; c < k; ++c) acc = fma(Zt[(int64_t)c * ld + j], us[c], acc);
+    out[j] = acc;
+}

@@ -447,3 +447,98 @@ def test_c4_size_three_consecutive_restoration_lps():
         _restoration_lp_properties(sp, out)
         x = np.clip(x + 0.05 * out[0], pr.x_L, pr.x_U)
     opt.close()
+
+
+def test_null_space_form_edge_paths():
+    """Sequences on one handle that leave the common path of the null-space form: variables that become fixed between LPs (the
+    null-space dimension changes: the carried basis and the retained columns are dropped and selected afresh), a duplicated
+    equality row (S0 singular: the guarded factor drops it, k grows by one), a zero trust region (every variable fixed: the form is
+    not used), and back.  Every call against the oracle: status, path, sets, 1e-10."""
+    sp = equality_rich_subproblem(88, 300, 250, 170)
+    n, m = sp['n'], sp['m']
+    rng = np.random.default_rng(88)
+    variants = []
+    variants.append(dict(sp))                                                   # 0: plain
+    a = dict(sp); a['v_lb'] = sp['v_lb'].copy(); a['v_ub'] = sp['v_ub'].copy()
+    fix = rng.choice(n, 12, replace=False)
+    a['v_lb'][fix] = sp['x_k'][fix]; a['v_ub'][fix] = sp['x_k'][fix]            # 1: twelve variables fixed at the current point
+    variants.append(a)
+    variants.append(dict(sp))                                                   # 2: free again
+    b = dict(sp); b['delta'] = 0.0                                              # 3: zero radius (all fixed)
+    variants.append(b)
+    c = dict(sp); c['dE'] = sp['dE'] * (1.0 + 1e-2 * rng.standard_normal(len(sp['dE'])))   # 4: perturbed, basis carried again
+    variants.append(c)
+    qp = opt = None
+    dims = []
+    for k, v in enumerate(variants):
+        if k in (1, 2):                         # bounds are part of the skeleton state of the oracle's QpModel data only; the handle gets them via set_bounds
+            pass
+        qp, o_out = oracle_solve(v, False, qp)
+        if opt is not None and k in (1, 2, 3, 4):
+            from activesetmethods_amd.subproblem import QpData
+            opt.set_bounds(QpData(v['df'], v['f'], v['dE'], v['E'], v['c_lb'], v['c_ub'], v['v_lb'], v['v_ub']))
+            qp.warm = {False: None, True: None}; qp.hint = {False: {}, True: {'prefer_ref': True}}      # set_bounds drops the retained state
+        opt, h_out = hip_solve(v, False, opt)
+        st, so = opt.last_stats(), o_out[6]['stats']
+        assert o_out[5] == h_out[5], (k, o_out[5], h_out[5])
+        if o_out[5] == 1:
+            assert PATH_NAMES[st['path']] == so['path'], (k, st, so)
+            assert st['ns_iters'] == so.get('ns_iters', 0), (k, st, so)
+            _compare(o_out, h_out, opt, None)
+        dims.append(st['ns_dim'])
+    assert dims[0] == n - 250 and dims[1] == n - 12 - 250 and dims[2] == n - 250 and dims[3] == 0 and dims[4] == n - 250, dims
+    opt.close()
+    # a duplicated equality row: dependent rows of A_EF
+    sp2 = equality_rich_subproblem(89, 260, 200, 150)
+    J = sp2['J']
+    rows, cols = sp2['j_row'] - 1, sp2['j_col'] - 1
+    src = 5; dst = 6                                                            # row 6 := row 5 (same coefficients, same bounds and value)
+    keep = rows != dst
+    add = rows == src
+    j_row = np.concatenate([rows[keep], np.full(add.sum(), dst)]) + 1
+    j_col = np.concatenate([cols[keep], cols[add]]) + 1
+    dE = np.concatenate([sp2['dE'][keep], sp2['dE'][add]])
+    sp3 = dict(sp2); sp3['j_row'] = j_row; sp3['j_col'] = j_col; sp3['dE'] = dE
+    sp3['E'] = sp2['E'].copy(); sp3['E'][dst] = sp2['E'][src]
+    sp3['c_lb'] = sp2['c_lb'].copy(); sp3['c_ub'] = sp2['c_ub'].copy()
+    sp3['c_lb'][dst] = sp2['c_lb'][src]; sp3['c_ub'][dst] = sp2['c_ub'][src]
+    qp, o_out = oracle_solve(sp3)
+    opt, h_out = hip_solve(sp3)
+    st, so = opt.last_stats(), o_out[6]['stats']
+    assert o_out[5] == h_out[5] == 1
+    assert st['ns_dim'] == sp3['n'] - 200 + 1, st                               # one dependent equality row dropped: the null space has one more dimension
+    assert PATH_NAMES[st['path']] == so['path'], (st, so)
+    _compare(o_out, h_out, opt, None)
+    opt.close()
+
+
+def test_null_space_campaign():
+    """Seeded equality-rich sub-problems of varying shape, with a perturbed re-solve on the same handle: status, path, working
+    sets, interior-point and null-space iteration counts, 1e-10 - on every call."""
+    checked = 0
+    for k in range(12):
+        seed = 9100 + k
+        rng = np.random.default_rng(seed)
+        n = int(rng.integers(150, 500)); neq = int(rng.integers(max(64, n - 120), n - 10)); nineq = int(rng.integers(max(n - neq, 40), 300))
+        if n > neq + nineq or n - neq > 0.3 * (neq + nineq):
+            continue
+        sp = equality_rich_subproblem(seed, n, neq, nineq, per_row=int(rng.integers(3, 6)), delta=float(rng.choice([0.6, 0.2, 1000.0])))
+        qp, o1 = oracle_solve(sp)
+        opt, h1 = hip_solve(sp)
+        s1 = (opt.active_set() if h1[5] == 1 else None), opt.last_stats()
+        sp2 = dict(sp); sp2['dE'] = sp['dE'] * (1.0 + 1e-2 * rng.standard_normal(len(sp['dE']))); sp2['df'] = sp['df'] + 0.2 * rng.standard_normal(n)
+        qp, o2 = oracle_solve(sp2, False, qp)
+        opt, h2 = hip_solve(sp2, False, opt)
+        s2 = (opt.active_set() if h2[5] == 1 else None), opt.last_stats()
+        for oo, hh, (sets, st) in ((o1, h1, s1), (o2, h2, s2)):
+            so = oo[6]['stats']
+            assert oo[5] == hh[5], seed
+            if oo[5] != 1:
+                continue
+            assert PATH_NAMES[st['path']] == so['path'], (seed, st, so)
+            assert st['ns_iters'] == so['ns_iters'] and st['ipm_iters'] == so['ipm_iters'], (seed, st, so)
+            assert st['ns_dim'] > 0
+            _compare(oo, hh, opt, None, sets)
+        checked += 1
+        opt.close()
+    assert checked >= 6
