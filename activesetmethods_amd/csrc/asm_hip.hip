@@ -51,6 +51,7 @@ const double RED_TAU = 100.0, RED_MIN_FRAC = 0.1;
 // null-space form of the normal-phase Newton system (oracle/lp_solver.py: NS_*)
 const int NS_MIN_E = 64;
 const double NS_MAX_RATIO = 0.3, NS_WARM_THR = 1e-6, NS_ZWARM_THR = 0.25, NS_BIG = 0.5e128, NS_RERR = 1e-6;
+const int NS_CMAX = 2;
 const double NS_SEL_THR[4] = {1e-2, 1e-4, 1e-7, 1e-10};
 const int PCG_MAXIT = 20;       // conjugate-gradient steps per Newton solve (preconditioner = the Cholesky factor)
 const double PCG_KAPPA = 1e-3;  // Newton-system residual tolerance relative to the current primal residual
@@ -1255,7 +1256,7 @@ struct Solver {
         HIPCHK(hipMemcpyAsync(cnt, Q.cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         const int nact = cnt[1];
-        if (nact > h->ns_ccap) return false;
+        if (nact > NS_CMAX * k || nact > h->ns_ccap) return false;             // oracle: eqp_ns returns None - the polish attempt ends (eqp_loop)
         const unsigned gC = (unsigned)((Q.ldc + 255) / 256), gA = (unsigned)((nact + 255) / 256);
         double *t1 = nsv(12), *t2 = nsv(13);
         HIPCHK(hipMemcpyAsync(Q.u, Q.u0, Q.ldc * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -1741,15 +1742,24 @@ struct Solver {
     bool eqp_loop(const double* p_ref, const double* y_ref, int rounds) {
         int cur = 0, nx = 1, prev = 2;
         bool have_prev = false;
+        double t_round = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
         for (int k = 0; k <= rounds; ++k) {
-            if (!(ns_lp && p_ref == d_zero && y_ref == nullptr && as_solve_ns(S_[cur]))) as_solve(S_[cur], p_ref, y_ref, 0);
+            if (ns_lp && p_ref == d_zero && y_ref == nullptr) {
+                if (!as_solve_ns(S_[cur])) return false;
+            } else {
+                as_solve(S_[cur], p_ref, y_ref, 0);
+            }
             hipLaunchKernelGGL(k_as_finish, dim3(1), dim3(1024), 0, h->stream, A, S_[cur], S_[nx], S_[prev], have_prev ? 1 : 0, TOL_P, TOL_D);
             as_read();
             const double pr = h->h_asscal[AS_PR], du = h->h_asscal[AS_DU];
             h->stats.kkt_pr = pr;
             h->stats.kkt_du = du;
             final_sets = cur;
-            if (h->verbose) std::fprintf(stderr, "[asm] eqp round %d: pr %.3e du %.3e changes %d\n", k, pr, du, h->h_ascnt[AC_NCHG]);
+            if (h->verbose) {
+                const double t_now = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+                std::fprintf(stderr, "[asm] eqp round %d: pr %.3e du %.3e changes %d  (%.2f ms)\n", k, pr, du, h->h_ascnt[AC_NCHG], t_now - t_round);
+                t_round = t_now;
+            }
             if (pr <= TOL_P && du <= TOL_D) return true;
             if (k == rounds) break;
             if (h->h_ascnt[AC_NCHG] == 0 || (have_prev && h->h_ascnt[AC_NDIFF] == 0)) break;
@@ -2055,6 +2065,7 @@ struct Solver {
             }
             double t1 = now_ms();
             identify_dev(3);
+            if (h->verbose) { HIPCHK(hipStreamSynchronize(h->stream)); std::fprintf(stderr, "[asm] stage %d identify %.2f ms\n", stage, now_ms() - t1); }
             have_sets = true;
             bool tried_ln = false;
             if (ns_lp) {
@@ -2062,7 +2073,7 @@ struct Solver {
                 // needed (oracle: solve_scaled)
                 as_copy_sets(0, 3);
                 const bool okn = eqp_loop(d_zero, nullptr, 2);
-                if (okn) { t_polish += now_ms() - t1; h->stats.path = 1 + stage; return ASM_OPTIMAL; }
+                if (okn) { t_polish += now_ms() - t1; hint.prefer_ref = false; h->stats.path = 1 + stage; return ASM_OPTIMAL; }
                 tried_ln = true;
             }
             if (prefer_ref) {

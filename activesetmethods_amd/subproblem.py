@@ -10,6 +10,7 @@ The Jacobian travels as the COO value vector `dE` in `j_str` order (what `eval_j
 slp.jl:186-191); `compute_jacobian_matrix` (common.jl:12-20) runs on the GPU inside the call.
 """
 import ctypes as C
+from collections.abc import Mapping
 import numpy as np
 from . import _lib
 
@@ -18,10 +19,38 @@ class AsmHipError(RuntimeError):
     pass
 
 
-class PSlack(dict):
-    """`p_slack::Dict{Int,Vector{Float64}}` of subproblem.jl:495-505 that also keeps the flat array the C ABI returned (two entries
-    per row, NaN where a row has one slack), so that the device-side merit function gets it back without a Python loop."""
-    raw = None
+class PSlack(Mapping):
+    """`p_slack::Dict{Int,Vector{Float64}}` of subproblem.jl:495-505 over the flat array the C ABI returned (`raw`: two entries per
+    row, NaN where a row has one slack).  The per-row lists are made when a row is first asked for: the SLP drivers hand `raw`
+    straight back to the device-side merit function, and a Python loop over 18 637 rows per LP costs milliseconds."""
+
+    def __init__(self, raw, one_slack):
+        self.raw, self._one, self._rows = raw, one_slack, None
+
+    def _dict(self):
+        if self._rows is None:
+            pl, one = self.raw.tolist(), self._one.tolist()
+            self._rows = {i: ([pl[2 * i]] if one[i] else [pl[2 * i], pl[2 * i + 1]]) for i in range(len(one))}
+        return self._rows
+
+    def __getitem__(self, i):
+        if self._rows is None:
+            if not 0 <= i < len(self._one):
+                raise KeyError(i)
+            return [float(self.raw[2 * i])] if self._one[i] else [float(self.raw[2 * i]), float(self.raw[2 * i + 1])]
+        return self._rows[i]
+
+    def __iter__(self):
+        return iter(range(len(self._one)))
+
+    def __len__(self):
+        return len(self._one)
+
+    def __eq__(self, other):
+        return self._dict() == (other._dict() if isinstance(other, PSlack) else other)
+
+    def __repr__(self):
+        return "PSlack(%r)" % (self._dict(),)
 
 
 class QpData:
@@ -104,10 +133,7 @@ class HipSubOptimizer:
         self._check(self._lib.asm_sublp_solve_resident(self._h, float(Delta), int(bool(feasibility)), _lib.dptr(Xsol),
                                                        _lib.dptr(lam), _lib.dptr(mU), _lib.dptr(mL), _lib.dptr(ps),
                                                        C.byref(status)))
-        pl = ps.tolist()
-        one = (self.nslack == 1).tolist()
-        p_slack = PSlack((i, [pl[2 * i]] if one[i] else [pl[2 * i], pl[2 * i + 1]]) for i in range(m))   # subproblem.jl:495-505
-        p_slack.raw = ps
+        p_slack = PSlack(ps, self.nslack == 1)            # subproblem.jl:495-505
         return Xsol, lam, mU, mL, p_slack, int(status.value)
 
     def lp_solve(self, dE, q, r, lb, ub, w=None, slo=None):

@@ -60,6 +60,7 @@ NS_SEL_THR = (1e-2, 1e-4, 1e-7, 1e-10)    # for re-using the previous LP's basis
 NS_WARM_THR = 1e-6
 NS_RERR = 1e-6        # relative residual of a reduced solve beyond which the LP returns to the row form; smallest Gram pivot for
 NS_ZWARM_THR = 0.25   # re-using the previous LP's basis
+NS_CMAX = 2           # reduced active-set solve: at most NS_CMAX * k active bounds + inequality rows, else the attempt is abandoned
 CHOL_NB = 64
 PIV_BIG = 1e128
 
@@ -704,8 +705,10 @@ def eqp_ns(lp, nsp, sets, sweeps=3):
     pbar = nsp.pbar
     zero_p = np.clip(np.zeros(n), lp.lb, lp.ub) * Fm
     u = nsp.Zt @ (zero_p - pbar * Fm)
+    nact = len(B) + int(ia_mask.sum())
+    if nact > NS_CMAX * nsp.k:
+        return None                                   # not the working set of a vertex of this LP (see eqp_loop)
     C = np.vstack([nsp.Zt[:, B].T, nsp.GI[ia_mask]])
-    nact = C.shape[0]
     nfact = 0
     lam = np.zeros(nact)
     if nact:
@@ -842,7 +845,16 @@ def eqp_loop(lp, sets, p_ref, y_ref, rounds, stats, nsp=None):
     prev = None
     p = s = y = None
     for k in range(rounds + 1):
-        p, s, y, nf = eqp_ns(lp, nsp, sets) if nsp is not None else eqp(lp, sets, p_ref, y_ref)
+        if nsp is not None:
+            sol = eqp_ns(lp, nsp, sets)
+            if sol is None:
+                # more than NS_CMAX * k active bounds and inequality rows on a k-dimensional null space: a bulk correction has run
+                # away from the partition (the corrections of a wrong partition roughly double the set each round); a solve on it
+                # would need a factor of that order and cannot pass the test below - the attempt ends here
+                return False, p, s, y, sets
+            p, s, y, nf = sol
+        else:
+            p, s, y, nf = eqp(lp, sets, p_ref, y_ref)
         stats['nfact'] += nf
         stats['eqp'] += 1
         pr, du = kkt_measures(lp, p, s, y, sets)
@@ -1303,6 +1315,7 @@ def solve_scaled(lp, warm=None, stats=None, hint=None):
             # the least-norm polish in reduced coordinates costs two solves with the factor of S0: tried first whatever the last LP needed
             ok, p, s, y, sets = eqp_loop(lp, sets0, zero_p, zero_y, 2, stats, nsp)
             if ok:
+                hint['prefer_ref'] = False              # this LP's optimum was unique: the next one does not start with the face polish
                 stats['path'] = 'ipm%d+ln' % stage
                 return OPTIMAL, p, s, y, sets
             tried_ln = True

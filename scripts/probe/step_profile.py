@@ -2,6 +2,9 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
+if os.environ.get('WITH_TORCH'):
+    import torch
+    torch.cuda.synchronize()
 import activesetmethods_amd as A
 from activesetmethods_amd import acopf, slp as S
 name, ls, nlp = sys.argv[1], float(sys.argv[2]), int(sys.argv[3])
@@ -21,10 +24,10 @@ for m in ("eval_functions", "norm_violations", "KT_residuals", "norm_complementa
     wrap(S.SlpLS, m)
 mdl = A.Model.from_problem(pr, A.Parameters(algorithm="Line Search", max_iter=1000, device_eval=True))
 slp = A.SlpLS(mdl)
-slp.run(max_lp_solves=3)
+slp.run(max_lp_solves=int(sys.argv[4]) if len(sys.argv) > 4 else 3)
 T.clear()
 t0 = time.perf_counter()
-slp.run(max_lp_solves=3 + nlp, resume=True)
+slp.run(max_lp_solves=(int(sys.argv[4]) if len(sys.argv) > 4 else 3) + nlp, resume=True)
 tot = time.perf_counter() - t0
 print("total %.1f ms/step" % (1e3 * tot / nlp))
 for k, v in sorted(T.items(), key=lambda kv: -kv[1]):
