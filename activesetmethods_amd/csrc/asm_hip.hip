@@ -104,11 +104,70 @@ struct TimedRegion {
 };
 
 // one Cholesky factor with the explicit inverses the substitution kernels use (the null-space form keeps two besides the main one)
+// Reverse Cuthill-McKee order of the rows `rows` of the CSR pattern (sp_ptr, sp_col); two rows are adjacent when they share a column.
+// Deterministic (oracle: rcm_order): components are started from the unvisited row of least degree (ties: first in `rows`), the
+// breadth-first search appends the unvisited neighbours by (degree, position in `rows`), the whole order is reversed.  Returns positions
+// into `rows`; *bandwidth = the largest distance between two adjacent rows in the new order; *pairs = the (row, column) positions, in the
+// new order, of the structural non-zeros of the lower triangle of the rows' Gram matrix.
+static std::vector<int> rcm_order(const std::vector<int>& rows, const std::vector<int>& sp_ptr, const std::vector<int>& sp_col, int64_t ncols, int* bandwidth,
+                                  std::vector<int>* pairs = nullptr) {
+    const int nR = (int)rows.size();
+    std::vector<std::vector<int>> col_rows((size_t)ncols);
+    for (int i = 0; i < nR; ++i)
+        for (int k = sp_ptr[rows[i]]; k < sp_ptr[rows[i] + 1]; ++k) col_rows[sp_col[k]].push_back(i);
+    std::vector<std::vector<int>> nbr((size_t)nR);
+    for (int i = 0; i < nR; ++i) {
+        std::vector<int>& v = nbr[i];
+        for (int k = sp_ptr[rows[i]]; k < sp_ptr[rows[i] + 1]; ++k) v.insert(v.end(), col_rows[sp_col[k]].begin(), col_rows[sp_col[k]].end());
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+        v.erase(std::remove(v.begin(), v.end(), i), v.end());
+    }
+    std::vector<int> deg(nR);
+    for (int i = 0; i < nR; ++i) deg[i] = (int)nbr[i].size();
+    auto by_deg = [&](int a, int b) { return deg[a] != deg[b] ? deg[a] < deg[b] : a < b; };
+    for (int i = 0; i < nR; ++i) std::sort(nbr[i].begin(), nbr[i].end(), by_deg);
+    std::vector<int> starts(nR), order;
+    for (int i = 0; i < nR; ++i) starts[i] = i;
+    std::sort(starts.begin(), starts.end(), by_deg);
+    std::vector<char> seen(nR, 0);
+    order.reserve(nR);
+    for (int s0 : starts) {
+        if (seen[s0]) continue;
+        seen[s0] = 1;
+        size_t head = order.size();
+        order.push_back(s0);
+        while (head < order.size()) {
+            const int v = order[head++];
+            for (int u : nbr[v])
+                if (!seen[u]) { seen[u] = 1; order.push_back(u); }
+        }
+    }
+    std::reverse(order.begin(), order.end());
+    std::vector<int> pos(nR);
+    for (int q = 0; q < nR; ++q) pos[order[q]] = q;
+    int bw = 0;
+    for (int i = 0; i < nR; ++i)
+        for (int u : nbr[i]) bw = std::max(bw, std::abs(pos[i] - pos[u]));
+    if (bandwidth) *bandwidth = bw;
+    if (pairs) {                    // structural non-zeros (new row, new column <= row) of the rows' Gram matrix, diagonal included
+        pairs->clear();
+        for (int i = 0; i < nR; ++i) {
+            pairs->push_back(pos[i]); pairs->push_back(pos[i]);
+            for (int u : nbr[i])
+                if (pos[u] < pos[i]) { pairs->push_back(pos[i]); pairs->push_back(pos[u]); }
+        }
+    }
+    return order;
+}
+
 struct FacBuf {
     double *S = nullptr, *Linv = nullptr, *Binv = nullptr, *BinvT = nullptr;
     int64_t ld = 0;
     int wb = 512;                   // wide-block width of its substitution kernels
     bool small = false;             // k x k systems of the null-space form: solved in one workgroup when the order is <= ASM_SMALL_MAX
+    int band = 0;                   // > 0: the matrix is banded (entry (i, j) is zero when |i - j| > band) and so is its factor: every panel
+                                    // operation stops `band` rows below the panel's last column
 };
 
 }  // namespace
@@ -173,6 +232,9 @@ struct asm_handle {
     double *d_nsLt = nullptr, *d_nsR = nullptr, *d_nsX = nullptr, *d_nsG = nullptr, *d_nsth = nullptr, *d_nsFm = nullptr, *d_nsv = nullptr, *d_nsYt = nullptr, *d_nsN0 = nullptr, *d_nsZT = nullptr;
     FacBuf ns_fC;                   // factor of the Gram matrix of the active constraints in reduced coordinates (active-set solves)
     int ns_ccap = 0;                // most constraints it is sized for
+    int64_t ns_npairs = 0;          // structural non-zeros of the lower triangle of S0 (banded S0 only)
+    int* d_nsS0pairs = nullptr;
+    int main_band = 0;              // band of the matrix in the main factor buffers (test hook asm_test_set_band; 0 = dense)
     int ns_Zk = 0;                  // rows of the orthonormal basis of the previous LP still resident in d_nsG (0: none)
     int *d_nsqi = nullptr;          // sel | bpos | rpos | cnt
     double *d_nsq = nullptr;        // Csel | d, u, lam, v, w | pbar, tbar, u0, qh
@@ -266,9 +328,12 @@ struct Dev {
     int64_t fld;
     int fwb;
     bool fsmall = false;
+    int fband = 0;
     explicit Dev(asm_handle* hh) : h(hh), cur(hh->stream) { use_main(); }
-    void use_main() { fS = h->d_S; fld = h->Mp; fLinv = h->d_Linv; fBinv = h->d_Binv; fBinvT = h->d_BinvT; fwb = h->wb; fsmall = false; }
-    void use_factor(const FacBuf& f) { fS = f.S; fld = f.ld; fLinv = f.Linv; fBinv = f.Binv; fBinvT = f.BinvT; fwb = f.wb; fsmall = f.small; }
+    void use_main() { fS = h->d_S; fld = h->Mp; fLinv = h->d_Linv; fBinv = h->d_Binv; fBinvT = h->d_BinvT; fwb = h->wb; fsmall = false; fband = h->main_band; }
+    void use_factor(const FacBuf& f) { fS = f.S; fld = f.ld; fLinv = f.Linv; fBinv = f.Binv; fBinvT = f.BinvT; fwb = f.wb; fsmall = f.small; fband = f.band; }
+    // first row that the columns [.., c1) of a banded matrix / factor cannot reach (the order Ms when the matrix is dense)
+    int rowlim(int Ms, int c1) const { return fband > 0 ? (int)std::min<int64_t>(Ms, round_up((int64_t)c1 + fband, 64)) : Ms; }
 
     hipEvent_t get_event() {
         if (!h->event_pool.empty()) {
@@ -451,13 +516,15 @@ struct Dev {
         for (int B = 0; B < nB; ++B) {
             const int b0 = B * WB, wv = std::min(WB, Ms - b0), b1 = b0 + wv, Kb = (int)round_up(wv, 32);
             gemm_nt(R + b0, ldr, fBinv + (int64_t)B * WB * WB, WB, nullptr, 0, X + b0, ldr, nrhs, wv, Kb, 0);
-            if (b1 < Ms) gemm_nt(X + b0, ldr, fS + (int64_t)b1 * fld + b0, fld, R + b1, ldr, R + b1, ldr, nrhs, Ms - b1, Kb, 1);
+            if (b1 < Ms) gemm_nt(X + b0, ldr, fS + (int64_t)b1 * fld + b0, fld, R + b1, ldr, R + b1, ldr, nrhs, rowlim(Ms, b1) - b1, Kb, 1);
         }
         if (!Lt) return;
         for (int B = nB - 1; B >= 0; --B) {
             const int b0 = B * WB, wv = std::min(WB, Ms - b0), Kb = (int)round_up(wv, 32);
             gemm_nt(X + b0, ldr, fBinvT + (int64_t)B * WB * WB, WB, nullptr, 0, R + b0, ldr, nrhs, wv, Kb, 0);
-            if (b0 > 0) gemm_nt(R + b0, ldr, Lt + b0, fld, X, ldr, X, ldr, nrhs, b0, Kb, 1);
+            // rows of L in this block reach back `band` columns at most
+            const int c0 = fband > 0 ? std::max(0, (b0 - fband) / 64 * 64) : 0;
+            if (b0 > 0) gemm_nt(R + b0, ldr, Lt + (int64_t)c0 * fld + b0, fld, X + c0, ldr, X + c0, ldr, nrhs, b0 - c0, Kb, 1);
         }
     }
     // out[i] = sum_j Ah_ij^2 thinv_j   (sparse patterns only)
@@ -648,10 +715,11 @@ struct Dev {
     void chol_chain(int Ms, double thr, int K0, int K1, bool beside_updates = false) {
         for (int I0 = K0; I0 < K1; I0 += CHOL_NBI) {
             const int I1 = std::min(I0 + CHOL_NBI, K1);
+            const int Mi = rowlim(Ms, I1);           // banded factor: the rows below are out of this inner panel's reach
             if (h->fused_panel) {
                 // the <= 8 steps of this inner panel in one dataflow launch (k_chol_panel): row tiles are owned by workgroups,
                 // diagonal-block factors and the panel tiles other workgroups need travel through release / acquire flags
-                const int nrt = (Ms - I0 + ASM_NB - 1) / ASM_NB;
+                const int nrt = (Mi - I0 + ASM_NB - 1) / ASM_NB;
                 // grid: one workgroup per row tile while they all fit (77 KB of LDS: two per CU); measured: fewer workgroups with several
                 // tiles each lengthen every step (M = 11192: 16.7 ms with one tile per workgroup, 21.1 ms with three)
                 const int G = std::max(1, std::min(nrt, h->panel_wgs));
@@ -659,27 +727,27 @@ struct Dev {
                 if (h->panel_epoch == 0) h->panel_epoch = 1;
                 // beside the trailing update the register-capped build must be used (its wavefronts have to fit into freed update slots)
                 if (beside_updates)
-                    hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)G), dim3(256), 0, cur, fS, fld, I0, std::min(I1, Ms), Ms, (const double*)h->d_diag0, thr,
+                    hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)G), dim3(256), 0, cur, fS, fld, I0, std::min(I1, Ms), Mi, (const double*)h->d_diag0, thr,
                                        fLinv, h->d_pflags, h->d_ptmo, h->panel_epoch);
                 else
-                    hipLaunchKernelGGL(k_chol_panel_solo, dim3((unsigned)G), dim3(256), 0, cur, fS, fld, I0, std::min(I1, Ms), Ms, (const double*)h->d_diag0, thr,
+                    hipLaunchKernelGGL(k_chol_panel_solo, dim3((unsigned)G), dim3(256), 0, cur, fS, fld, I0, std::min(I1, Ms), Mi, (const double*)h->d_diag0, thr,
                                        fLinv, h->d_pflags, h->d_ptmo, h->panel_epoch);
             } else
             for (int k0 = I0; k0 < I1; k0 += ASM_NB) {
-                int nb = std::min(ASM_NB, Ms - k0);
+                int nb = std::min(ASM_NB, Mi - k0);
                 hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, cur, fS, fld, k0, nb, h->d_diag0, thr, fLinv);
                 int k1 = k0 + nb;
-                if (k1 < Ms) {
-                    int rem = Ms - k1;
-                    hipLaunchKernelGGL(k_trsm_panel, dim3((unsigned)((rem + 63) / 64)), dim3(256), 0, cur, fS, fld, k0, nb, Ms, fLinv);
+                if (k1 < Mi) {
+                    int rem = Mi - k1;
+                    hipLaunchKernelGGL(k_trsm_panel, dim3((unsigned)((rem + 63) / 64)), dim3(256), 0, cur, fS, fld, k0, nb, Mi, fLinv);
                     if (k1 < I1)   // update the remaining columns of this inner panel only (rank 64: dedicated 64 x 64-tile kernel)
-                        hipLaunchKernelGGL(k_panel_update64, dim3((unsigned)((rem + 63) / 64), (unsigned)((std::min(I1, Ms) - k1 + 63) / 64)), dim3(256), 0,
-                                           cur, fS, fld, k0, k1, std::min(I1, Ms), Ms);
+                        hipLaunchKernelGGL(k_panel_update64, dim3((unsigned)((rem + 63) / 64), (unsigned)((std::min(I1, Mi) - k1 + 63) / 64)), dim3(256), 0,
+                                           cur, fS, fld, k0, k1, std::min(I1, Mi), Mi);
                 }
             }
-            if (I1 < K1 && I1 < Ms) {
-                int rem = Ms - I1;
-                launch_syrk(pick_tile(rem), fS + I0, fld, nullptr, I1, rem, I1 - I0, nullptr, nullptr, fS, fld, I1, 1, K1 - I1);
+            if (I1 < K1 && I1 < Mi) {
+                int rem = Mi - I1;
+                launch_syrk(pick_tile(rem), fS + I0, fld, nullptr, I1, rem, I1 - I0, nullptr, nullptr, fS, fld, I1, 1, std::min(K1 - I1, rem));
             }
         }
     }
@@ -701,7 +769,7 @@ struct Dev {
         for (int p = 0; p < nP; ++p) {
             const int K0 = p * NBO, K1 = std::min(K0 + NBO, Ms);
             if (K1 >= Ms) break;
-            const int rem = Ms - K1, wa = std::min(NBO, rem);            // next panel = first `wa` trailing columns
+            const int rem = rowlim(Ms, K1) - K1, wa = std::min(NBO, rem);   // next panel = first `wa` trailing columns (banded: `rem` stops where the panel's reach ends)
             hipEvent_t e_a = h->la_events[2 * p], e_c = h->la_events[2 * p + 1];
             cur = h->stream;
             // (a) rows >= K1, columns of the next outer panel
@@ -743,17 +811,19 @@ struct Dev {
         for (int B = 0; B < nB; ++B) {
             int b1 = std::min((B + 1) * WB, Ms);
             hipLaunchKernelGGL((k_wtrsv_fwd_diag<WB>), dim3(WB / 4), dim3(256), 0, h->stream, fBinv, B, Ms, w, z);
-            int rem = Ms - b1;
+            const int Me = rowlim(Ms, b1);
+            int rem = Me - b1;
             if (rem > 0)
-                hipLaunchKernelGGL((k_wtrsv_fwd_panel<WB>), dim3((unsigned)((rem + 31) / 32)), dim3(256), 0, h->stream, fS, fld, B, Ms, z, w);
+                hipLaunchKernelGGL((k_wtrsv_fwd_panel<WB>), dim3((unsigned)((rem + 31) / 32)), dim3(256), 0, h->stream, fS, fld, B, Me, z, w);
         }
         for (int B = nB - 1; B >= 0; --B) {
             int b1 = std::min((B + 1) * WB, Ms);
-            int rem = Ms - b1;
+            const int Me = rowlim(Ms, b1);
+            int rem = Me - b1;
             int np = 0;
             if (rem > 0) {
                 np = (rem + ASM_WBROWS - 1) / ASM_WBROWS;
-                hipLaunchKernelGGL((k_wtrsv_bwd_panel<WB>), dim3((unsigned)np), dim3(256), 0, h->stream, fS, fld, B, Ms, w, h->d_wpart);
+                hipLaunchKernelGGL((k_wtrsv_bwd_panel<WB>), dim3((unsigned)np), dim3(256), 0, h->stream, fS, fld, B, Me, w, h->d_wpart);
             }
             hipLaunchKernelGGL((k_wtrsv_bwd_reduce<WB>), dim3(WB / ASM_NB), dim3(256), 0, h->stream, B, Ms, z, h->d_wpart, np, h->d_wt);
             hipLaunchKernelGGL((k_wtrsv_bwd_diag<WB>), dim3(WB / 4), dim3(256), 0, h->stream, fBinvT, B, Ms, h->d_wt, w);
@@ -817,6 +887,7 @@ struct SLP {
 };
 
 struct Solver {
+    static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     asm_handle* h;
     Dev dev;
     SLP lp;
@@ -1128,10 +1199,29 @@ struct Solver {
             HIPCHK(hipMemcpyAsync(h->d_nsFm, fm.data(), h->ldn * sizeof(double), hipMemcpyHostToDevice, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
         }
+        double t_v = now_ms();
+        auto vlap = [&](const char* what) {
+            if (!h->verbose) return;
+            HIPCHK(hipStreamSynchronize(h->stream));
+            const double t = now_ms();
+            std::fprintf(stderr, "[asm] ns set-up %-10s +%.2f ms\n", what, t - t_v);
+            t_v = t;
+        };
         dev.use_factor(h->ns_f0);
-        dev.syrk_gathered_into(h->d_nsEidx, nE, h->d_nsFm, h->ns_f0.S, h->ns_f0.ld);
+        if (h->ns_f0.band > 0) {
+            // banded S0: the band is cleared (the last factor filled it) and the ~20 structural entries per row are written as merged
+            // sparse dot products of the two rows - the dense rank-K build spends 3 ms on the zeros at n = 11 192
+            const int64_t wz = std::min<int64_t>(round_up(h->ns_f0.band + 1, 64) + 64, h->ns_f0.ld);
+            hipLaunchKernelGGL(k_ns_zero_band, dim3((unsigned)((wz + 255) / 256), (unsigned)nE), dim3(256), 0, h->stream, h->ns_f0.S, h->ns_f0.ld, nE, (int)wz);
+            hipLaunchKernelGGL(k_ns_s0_sparse, dim3((unsigned)((h->ns_npairs + 255) / 256)), dim3(256), 0, h->stream, (const int*)h->d_nsS0pairs, h->ns_npairs, h->d_sp_ptr,
+                               h->d_sp_col, dev.sparse_vals(h->d_Ah), (const int*)h->d_nsEidx, (const double*)h->d_nsFm, h->ns_f0.S, h->ns_f0.ld);
+        } else {
+            dev.syrk_gathered_into(h->d_nsEidx, nE, h->d_nsFm, h->ns_f0.S, h->ns_f0.ld);
+        }
+        vlap("S0 build");
         dev.diag_prepare(nE, 1, 0.0, 0.0);
         dev.chol(nE, 1e-10);
+        vlap("S0 factor");
         hipLaunchKernelGGL(k_ns_count_big, dim3(1), dim3(1024), 0, h->stream, (const double*)h->ns_f0.S, h->ns_f0.ld, nE, NS_BIG, h->d_nscnt);
         const int dropped = ns_read_cnt();
         dev.use_main();
@@ -1144,7 +1234,9 @@ struct Solver {
         std::vector<int>& J = cur_hint->ns_J;
         bool have = false;
         ns_was_cold = false;
+        vlap("Lt");
         if (h->ns_Zk == (int)k) have = ns_reproject((int)k, NS_ZWARM_THR);      // the previous LP's basis, one projection pass
+        vlap("reproject");
         h->ns_Zk = 0;
         if (!have && (int64_t)J.size() == k) {
             bool free_all = true;
@@ -1992,7 +2084,6 @@ struct Solver {
 
     // oracle: solve_scaled
     double t_warm = 0, t_ipm = 0, t_polish = 0;
-    static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     int solve_scaled(const ActiveSet* warm, SolveHint& hint) {
         int st = solve_scaled_impl(warm, hint);
         if (h->verbose) std::fprintf(stderr, "[asm] phases: warm %.2f ms, ipm %.2f ms (%d its), polish %.2f ms, path %d\n", t_warm, t_ipm, ip.iters, t_polish, h->stats.path);
@@ -2164,6 +2255,7 @@ void free_device(asm_handle* h) {
     h->ns_bufs.clear();
     h->ns_cap = false; h->ns_kcap = 0; h->ns_ccap = 0; h->ns_Zk = 0; h->ns_fC = FacBuf(); h->d_nsqi = nullptr; h->d_nsq = nullptr;
     h->d_nsEidx = h->d_nsEpos = h->d_nsIidx = h->d_nsIpos = h->d_nsJ = h->d_nscnt = nullptr;
+    h->d_nsS0pairs = nullptr; h->ns_npairs = 0;
     h->ns_f0 = FacBuf(); h->ns_fN = FacBuf();
     h->d_nsLt = h->d_nsR = h->d_nsX = h->d_nsG = h->d_nsth = h->d_nsFm = h->d_nsv = h->d_nsYt = h->d_nsN0 = h->d_nsZT = nullptr;
     F(h->d_as); F(h->d_as_i);
@@ -2405,9 +2497,24 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
                 if (!v.empty()) HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
                 return d;
             };
+            // the equality rows in reverse Cuthill-McKee order of their coupling graph: S0 = A_EF A_EF' and its factor are banded in that order
+            int s0_band = 0;
+            std::vector<int> s0_pairs;
+            {
+                const std::vector<int> ord = rcm_order(eidx, sp_ptr, sp_col, h->ldn, &s0_band, &s0_pairs);
+                std::vector<int> e2(nE);
+                for (int q = 0; q < nE; ++q) e2[q] = eidx[ord[q]];
+                eidx.swap(e2);
+                for (int q = 0; q < nE; ++q) epos[eidx[q]] = q;
+            }
             h->d_nsEidx = ialloc(eidx, nE); h->d_nsEpos = ialloc(epos, h->M); h->d_nsIidx = ialloc(iidx, h->ns_nI); h->d_nsIpos = ialloc(ipos, h->M);
             h->d_nscnt = ialloc({}, 16);
             ns_alloc_factor(h, h->ns_f0, h->ns_nEp);
+            h->ns_f0.band = (std::getenv("ASM_HIP_NO_BAND") || 2 * (int64_t)s0_band >= nE) ? 0 : std::max(s0_band, 1);
+            if (h->ns_f0.band > 0) {            // S0 is then built entry by entry from its structural pattern (k_ns_s0_sparse)
+                h->ns_npairs = (int64_t)s0_pairs.size() / 2;
+                h->d_nsS0pairs = ialloc(s0_pairs, (int64_t)s0_pairs.size());
+            }
             h->d_nsLt = ns_dalloc(h, (int64_t)h->ns_nEp * h->ns_nEp);
             h->d_nsth = ns_dalloc(h, h->ns_ldg);
             h->d_nsFm = ns_dalloc(h, h->ldn);
@@ -3144,6 +3251,15 @@ int asm_test_cholesky(asm_handle* h, const double* S, int64_t N, double* L_out) 
 
 // The bounded wait of the panel kernel with a producer that never publishes: the probe's workgroups must give up (the first after the
 // full bound, the others at their next look at the timeout word), the host must report ASM_ERR_HIP once, and the handle must stay usable.
+// the matrices the following kernel hooks load are banded with this half-bandwidth (0 = dense again): their factorisation and
+// substitutions then stop at the band, as for the S0 of the null-space form
+int asm_test_set_band(asm_handle* h, int band) {
+    return guarded(h, [&] {
+        if (band < 0) throw std::invalid_argument("asm_test_set_band: bad argument");
+        h->main_band = band;
+    });
+}
+
 int asm_test_panel_timeout(asm_handle* h, int workgroups) {
     return guarded(h, [&] {
         if (workgroups < 1 || workgroups > 64) throw std::invalid_argument("asm_test_panel_timeout: 1..64 workgroups");

@@ -660,3 +660,31 @@ __global__ __launch_bounds__(256) void k_gemv_t_small(const double* __restrict__
     for (int c = 0; c < k; ++c) acc = fma(Zt[(int64_t)c * ld + j], us[c], acc);
     out[j] = acc;
 }
+
+// ---- banded S0 = A_EF A_EF' built from its structural pattern (equality rows in reverse Cuthill-McKee order)
+// clears row i, columns [i - w + 1, i] (w covers the band rounded up to the factorisation's tiles; the factor of the previous LP lives there)
+__global__ __launch_bounds__(256) void k_ns_zero_band(double* __restrict__ S, int64_t ld, int nE, int w) {
+    const int i = blockIdx.y;
+    const int c = i - (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i < nE && c >= 0 && (int)(blockIdx.x * 256 + threadIdx.x) < w) S[(int64_t)i * ld + c] = 0.0;
+}
+// one thread per structural entry (pi, pj), pj <= pi: the dot product of rows Eidx[pi] and Eidx[pj] over the free columns (both rows' column
+// lists are sorted: a merge)
+__global__ __launch_bounds__(256) void k_ns_s0_sparse(const int* __restrict__ pairs, int64_t npairs, const int* __restrict__ ptr, const int* __restrict__ col,
+                                                      const double* __restrict__ val, const int* __restrict__ Eidx, const double* __restrict__ Fm,
+                                                      double* __restrict__ S, int64_t ld) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= npairs) return;
+    const int pi = pairs[2 * t], pj = pairs[2 * t + 1];
+    const int ri = Eidx[pi], rj = Eidx[pj];
+    int a = ptr[ri], b = ptr[rj];
+    const int ae = ptr[ri + 1], be = ptr[rj + 1];
+    double acc = 0.0;
+    while (a < ae && b < be) {
+        const int ca = col[a], cb = col[b];
+        if (ca == cb) { acc += val[a] * val[b] * Fm[ca]; ++a; ++b; }
+        else if (ca < cb) ++a;
+        else ++b;
+    }
+    S[(int64_t)pi * ld + pj] = acc;
+}

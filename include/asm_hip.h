@@ -180,6 +180,11 @@ int asm_slp_norms(asm_handle* h, const double* lambda, const double* mult_x_U, c
 int asm_slp_merit(asm_handle* h, int mode, double alpha, const double* p, const double* nu, const double* p_slack,
                   int feasibility, double prim_infeas, double* out);
 
+/* Test hook: the matrices loaded by asm_test_cholesky / asm_test_chol_solve / asm_test_trsm_rows are banded with this half-bandwidth
+ * (0 = dense): factorisation and substitutions stop at the band, as they do for S0 = A_EF A_EF' of the null-space form (its equality
+ * rows are put in reverse Cuthill-McKee order at set-up). */
+int asm_test_set_band(asm_handle* h, int band);
+
 /* ---- kernel-level test hooks (used by tests/ to check each kernel against NumPy) ---------------- */
 int asm_test_syrk(asm_handle* h, const double* A, int64_t M, int64_t K, const int32_t* idx, int64_t Ms,
                   const double* theta, const double* diag, double* S_out /* Ms*Ms, lower valid */, int tile);

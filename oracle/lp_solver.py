@@ -83,6 +83,7 @@ class LP:
         self.w = np.asarray(w, float)
         self.slo = np.asarray(slo, float)
         self.ns = len(self.srow)
+        self.row_cols = None          # structural pattern of the first rows (list of column arrays) when the builder knows it; else A != 0
 
 
 # ----------------------------------------------------------------------------- scaling
@@ -113,6 +114,7 @@ def scale_lp(lp):
     kap = float(pow2_round(max(np.abs(qh).max(initial=0.0), np.abs(wh).max(initial=0.0)))[0])
     s = LP(qh / kap, Ah, lp.rtype, lp.r / rho, lp.lb / c, lp.ub / c,
            lp.srow, lp.scoef, wh / kap, lp.slo / rho[lp.srow])
+    s.row_cols = getattr(lp, 'row_cols', None)
     return s, c, rho, kap
 
 
@@ -186,6 +188,48 @@ def farkas_margin(lp, y):
     return float(yn @ lp.r - lhs_max)
 
 
+def rcm_order(row_cols):
+    """Reverse Cuthill-McKee order of rows given by their column sets; two rows are adjacent when they share a column.  Components are
+    started from the unvisited row of least degree (ties: lowest position), the breadth-first search appends the unvisited neighbours
+    by (degree, position), the whole order is reversed.  Integer work only: the HIP library's host code computes the same order
+    (asm_hip.hip: rcm_order).  Returns (order, bandwidth): positions into `row_cols`, largest distance between adjacent rows."""
+    nR = len(row_cols)
+    col_rows = {}
+    for i, cs in enumerate(row_cols):
+        for c in cs:
+            col_rows.setdefault(int(c), []).append(i)
+    nbr = []
+    for i, cs in enumerate(row_cols):
+        v = set()
+        for c in cs:
+            v.update(col_rows[int(c)])
+        v.discard(i)
+        nbr.append(v)
+    deg = [len(v) for v in nbr]
+    nbr = [sorted(v, key=lambda u: (deg[u], u)) for v in nbr]
+    seen = [False] * nR
+    order = []
+    for s0 in sorted(range(nR), key=lambda u: (deg[u], u)):
+        if seen[s0]:
+            continue
+        seen[s0] = True
+        head = len(order)
+        order.append(s0)
+        while head < len(order):
+            v = order[head]
+            head += 1
+            for u in nbr[v]:
+                if not seen[u]:
+                    seen[u] = True
+                    order.append(u)
+    order.reverse()
+    pos = [0] * nR
+    for q, i in enumerate(order):
+        pos[i] = q
+    bw = max((abs(pos[i] - pos[u]) for i in range(nR) for u in nbr[i]), default=0)
+    return np.array(order, np.int64), bw
+
+
 class NullSpace:
     """Equality elimination for the normal-phase LP (no slack columns): the rows E with rtype 0 hold with equality at every
     Newton step, so steps live in  p = pbar + Z u  with  Z  an orthonormal basis of  null(A_EF)  (F = columns with ub > lb;
@@ -207,6 +251,12 @@ class NullSpace:
     def __init__(self, lp, warm_J=None, warm_Z=None):
         A, n = lp.A, lp.n
         self.E = np.nonzero(lp.rtype == 0)[0]
+        # equality rows in reverse Cuthill-McKee order of their coupling graph (structural pattern): S0 and its factor are banded in
+        # that order - the HIP library's factorisation and substitutions stop at the band, this dense restatement only shares the
+        # order (which dependent row the pivot guard drops depends on it)
+        rc = getattr(lp, 'row_cols', None)
+        order, self.band = rcm_order([rc[i] if rc is not None and i < len(rc) else np.nonzero(A[i])[0] for i in self.E])
+        self.E = self.E[order]
         self.I = np.nonzero(lp.rtype != 0)[0]
         self.Fm = (lp.ub > lp.lb).astype(float)
         nE, nF = len(self.E), int(self.Fm.sum())

@@ -70,6 +70,10 @@ class QpModel:
         m, n = len(data.c_lb), len(data.c)
         assert n > 0 and m >= 0
         self.m, self.n = m, n
+        rc = [[] for _ in range(m)]
+        for r_, c_ in zip(self.j_row, self.j_col):
+            rc[r_].append(int(c_))
+        self.row_cols = [np.unique(np.array(v, np.int64)) for v in rc]
         self.kind = np.array([row_kind(data.c_lb[i], data.c_ub[i]) for i in range(m)], np.int64)
         if (self.kind == 9).any():
             raise ValueError("free constraint rows are not representable (subproblem.jl:143-197 adds no row)")
@@ -142,7 +146,9 @@ class QpModel:
         c_lb = d.c_lb - b
         r[:m] = np.where(self.kind == -1, c_ub, c_lb)
         r[m:] = c_ub[self.adj]
-        return L.LP(q, A, self.rtype, r, lb, ub, srow, scoef, w, slo)
+        lp = L.LP(q, A, self.rtype, r, lb, ub, srow, scoef, w, slo)
+        lp.row_cols = self.row_cols                 # structural pattern (j_row, j_col) of the m constraint rows (the adj rows are inequalities)
+        return lp
 
     def sub_optimize(self, x_k, Delta, feasibility=False):
         """subproblem.jl:229-542.  Returns (Xsol, lambda, mult_x_U, mult_x_L, p_slack, status, info)."""

@@ -216,3 +216,39 @@ def test_panel_wait_timeout_is_reported_once_and_the_handle_survives(hip_lib, ha
     L = np.zeros((N, N))
     assert hip_lib.asm_test_cholesky(handle, _d(S), N, _d(L)) == 0, hip_lib.asm_last_error(handle)      # no stale timeout
     assert np.abs(L - np.linalg.cholesky(S)).max() < 1e-10
+
+
+@pytest.mark.parametrize("N,band,nrhs", [(700, 90, 33), (2300, 267, 70), (3100, 1398, 130), (5000, 150, 40), (2245, 40, 137)])
+def test_banded_cholesky_and_solves(hip_lib, handle, N, band, nrhs):
+    """A banded SPD matrix (the S0 = A_EF A_EF' of the null-space form in reverse Cuthill-McKee order): with the band declared, the
+    factorisation, the single right-hand-side solve and the multi right-hand-side block substitution stop at the band - same factor
+    and solutions as the dense NumPy reference."""
+    from scipy.linalg import solve_triangular
+    rng = np.random.default_rng(N + band)
+    Bm = np.zeros((N, N))
+    for d in range(0, band // 2 + 1):                 # B has half-bandwidth band // 2 -> B B' has half-bandwidth <= band
+        v = rng.standard_normal(N - d)
+        Bm[np.arange(d, N), np.arange(0, N - d)] = v
+    S = Bm @ Bm.T + 0.5 * np.eye(N)
+    i, j = np.nonzero(S)
+    assert np.abs(i - j).max() <= band
+    assert hip_lib.asm_test_set_band(handle, band) == 0
+    try:
+        L = np.zeros((N, N))
+        assert hip_lib.asm_test_cholesky(handle, _d(S), N, _d(L)) == 0, hip_lib.asm_last_error(handle)
+        Lref = np.linalg.cholesky(S)
+        assert np.abs(L - Lref).max() / np.abs(Lref).max() < 1e-11
+        b = rng.standard_normal(N)
+        x = np.zeros(N)
+        assert hip_lib.asm_test_chol_solve(handle, _d(S), N, _d(b), _d(x)) == 0
+        assert np.abs(S @ x - b).max() < 1e-10 * max(1.0, np.abs(S).max() * np.abs(x).max())
+        R = rng.standard_normal((nrhs, N))
+        for backward in (0, 1):
+            X = np.zeros((nrhs, N))
+            assert hip_lib.asm_test_trsm_rows(handle, _d(S), N, _d(R), nrhs, backward, _d(X)) == 0, hip_lib.asm_last_error(handle)
+            ref = solve_triangular(Lref, R.T, lower=True).T
+            if backward:
+                ref = solve_triangular(Lref.T, ref.T, lower=False).T
+            assert np.abs(X - ref).max() / np.abs(ref).max() < 1e-9
+    finally:
+        assert hip_lib.asm_test_set_band(handle, 0) == 0
