@@ -52,6 +52,7 @@ const double RED_TAU = 100.0, RED_MIN_FRAC = 0.1;
 const int NS_MIN_E = 64;
 const double NS_MAX_RATIO = 0.3, NS_WARM_THR = 1e-6, NS_ZWARM_THR = 0.25, NS_BIG = 0.5e128, NS_RERR = 1e-6;
 const int NS_CMAX = 2;
+const int NS_MAX_SPLIT = 8;
 const double NS_SEL_THR[4] = {1e-2, 1e-4, 1e-7, 1e-10};
 const int PCG_MAXIT = 20;       // conjugate-gradient steps per Newton solve (preconditioner = the Cholesky factor)
 const double PCG_KAPPA = 1e-3;  // Newton-system residual tolerance relative to the current primal residual
@@ -229,7 +230,7 @@ struct asm_handle {
     int64_t ns_ldg = 0;
     int *d_nsEidx = nullptr, *d_nsEpos = nullptr, *d_nsIidx = nullptr, *d_nsIpos = nullptr, *d_nsJ = nullptr, *d_nscnt = nullptr;
     FacBuf ns_f0, ns_fN;            // factors of S0 = A_EF A_EF' (per LP) and of the k x k reduced matrix (per iteration)
-    double *d_nsLt = nullptr, *d_nsR = nullptr, *d_nsX = nullptr, *d_nsG = nullptr, *d_nsth = nullptr, *d_nsFm = nullptr, *d_nsv = nullptr, *d_nsYt = nullptr, *d_nsN0 = nullptr, *d_nsZT = nullptr;
+    double *d_nsLt = nullptr, *d_nsR = nullptr, *d_nsX = nullptr, *d_nsG = nullptr, *d_nsth = nullptr, *d_nsFm = nullptr, *d_nsv = nullptr, *d_nsYt = nullptr, *d_nsNp = nullptr, *d_nsN0 = nullptr, *d_nsZT = nullptr;
     FacBuf ns_fC;                   // factor of the Gram matrix of the active constraints in reduced coordinates (active-set solves)
     int ns_ccap = 0;                // most constraints it is sized for
     int64_t ns_npairs = 0;          // structural non-zeros of the lower triangle of S0 (banded S0 only)
@@ -618,7 +619,7 @@ struct Dev {
 
     void launch_syrk(int T, const double* A, int64_t ld, const int* idx, int64_t row0, int Ms, int K, const double* theta,
                      const double* diag, double* S, int64_t ldS, int64_t srow0, int mode, int MsB = -1,
-                     const unsigned char* nz = nullptr, int nzpitch = 0, double nzfrac = -1.0) {
+                     const unsigned char* nz = nullptr, int nzpitch = 0, double nzfrac = -1.0, int nsplit = 1, int64_t ksplit = 0) {
         int TS = 32 * T;
         int64_t nt = (Ms + TS - 1) / TS;
         int ntj = 0;
@@ -642,17 +643,17 @@ struct Dev {
         if (T == 4 && mode == 1 && !nz && !idx && !theta && K % (2 * ASM_UPD_KC) == 0 && use_upd)      // Cholesky updates: their own kernel
             hipLaunchKernelGGL(k_syrk_upd, dim3((unsigned)blocks), dim3(256), 0, cur, A, ld, row0, Ms, K, S, ldS, srow0, MsB, ntj);
         else if (T == 4 && mode == 1 && !nz && K % 16 == 0)      // 16-wide k-chunks, two workgroups per CU
-            hipLaunchKernelGGL((k_syrk<4, 8, 16, 4>), dim3((unsigned)blocks), dim3(512), 0, cur, A, ld, idx, row0, Ms, K, theta, diag, S,
-                               ldS, srow0, mode, MsB, ntj, nz, nzpitch);
+            hipLaunchKernelGGL((k_syrk<4, 8, 16, 4>), dim3((unsigned)blocks, (unsigned)nsplit), dim3(512), 0, cur, A, ld, idx, row0, Ms, K, theta, diag, S,
+                               ldS, srow0, mode, MsB, ntj, nz, nzpitch, ksplit);
         else if (T == 4)
-            hipLaunchKernelGGL((k_syrk<4, 8, 32, 2>), dim3((unsigned)blocks), dim3(512), 0, cur, A, ld, idx, row0, Ms, K, theta, diag, S,
-                               ldS, srow0, mode, MsB, ntj, nz, nzpitch);
+            hipLaunchKernelGGL((k_syrk<4, 8, 32, 2>), dim3((unsigned)blocks, (unsigned)nsplit), dim3(512), 0, cur, A, ld, idx, row0, Ms, K, theta, diag, S,
+                               ldS, srow0, mode, MsB, ntj, nz, nzpitch, ksplit);
         else if (T == 2)
-            hipLaunchKernelGGL((k_syrk<2, 4, 32, 1>), dim3((unsigned)blocks), dim3(256), 0, cur, A, ld, idx, row0, Ms, K, theta, diag, S,
-                               ldS, srow0, mode, MsB, ntj, nz, nzpitch);
+            hipLaunchKernelGGL((k_syrk<2, 4, 32, 1>), dim3((unsigned)blocks, (unsigned)nsplit), dim3(256), 0, cur, A, ld, idx, row0, Ms, K, theta, diag, S,
+                               ldS, srow0, mode, MsB, ntj, nz, nzpitch, ksplit);
         else
-            hipLaunchKernelGGL((k_syrk<1, 4, 32, 1>), dim3((unsigned)blocks), dim3(256), 0, cur, A, ld, idx, row0, Ms, K, theta, diag, S,
-                               ldS, srow0, mode, MsB, ntj, nz, nzpitch);
+            hipLaunchKernelGGL((k_syrk<1, 4, 32, 1>), dim3((unsigned)blocks, (unsigned)nsplit), dim3(256), 0, cur, A, ld, idx, row0, Ms, K, theta, diag, S,
+                               ldS, srow0, mode, MsB, ntj, nz, nzpitch, ksplit);
     }
 
     // S[0:Ms,0:Ms] (lower) = Ah[idx,:] diag(theta) Ah[idx,:]' + diag     idx == nullptr -> identity
@@ -1080,6 +1081,9 @@ struct Solver {
 
     // ------------------------------------------------------------ null-space form (oracle: class NullSpace / IPM.run use_ns)
     bool use_ns = false, ns_was_cold = false;
+    // ASM_NS_SPLIT=T,n : tile size and number of k slices of the reduced Newton matrix's build (tuning knob; default by size)
+    int ns_split_T = [] { const char* v = std::getenv("ASM_NS_SPLIT"); return v ? std::atoi(v) : 0; }();
+    int ns_split_n = [] { const char* v = std::getenv("ASM_NS_SPLIT"); const char* c = v ? std::strchr(v, ',') : nullptr; return c ? std::atoi(c + 1) : 0; }();
     bool ns_lp = false;       // this LP has a valid null-space basis (set up before the warm attempt: the active-set solves use it too)
     int ns_k = 0;
     SolveHint* cur_hint = nullptr;
@@ -1101,6 +1105,7 @@ struct Solver {
         ns_alloc_factor(h, h->ns_fN, cap);
         h->ns_fN.small = true;
         h->d_nsN0 = ns_dalloc(h, h->ns_fN.ld * h->ns_fN.ld);
+        h->d_nsNp = ns_dalloc(h, NS_MAX_SPLIT * h->ns_fN.ld * h->ns_fN.ld);       // split-K slices of the reduced Newton matrix
         h->d_nsZT = ns_dalloc(h, h->ldn * h->ns_fN.ld);        // transposed copy of the basis rows (right operand of the orthonormalisation product)
         int* dj = nullptr;
         dmalloc(&dj, cap);
@@ -1419,9 +1424,24 @@ struct Solver {
         hipLaunchKernelGGL(k_ns_theta, dim3((unsigned)((std::max<int64_t>(ldn, h->ns_nIp) + 255) / 256)), dim3(256), 0, h->stream, P, X, IPM_RHO_P, h->d_nsth, ldn, h->ns_nIp);
         dev.use_factor(h->ns_fN);
         int id = dev.begin(ASM_K_SYRK, (double)k * (k + 1) * h->ns_ldg, 8.0 * (k * (double)h->ns_ldg + 0.5 * k * (double)k));
-        dev.launch_syrk(Dev::pick_tile(k), h->d_nsG, h->ns_ldg, nullptr, 0, k, (int)h->ns_ldg, h->d_nsth, nullptr, h->ns_fN.S, h->ns_fN.ld, 0, 0);
-        dev.end(id);
-        hipLaunchKernelGGL(k_ns_copy_lower, dim3((unsigned)((k + 255) / 256), (unsigned)k), dim3(256), 0, h->stream, (const double*)h->ns_fN.S, h->ns_fN.ld, h->d_nsN0, h->ns_fN.ld, k);
+        // the k range (free columns + inequality rows, 19 000 at n = 11 192) is long and the matrix small (k = 519: 45 tiles of 64 x 64):
+        // split-K fills the chip; the slices are added in a fixed order while the unregularised copy N0 is made
+        // (measured at k = 519, k range 19 000: 32 x 32 tiles x 8 slices 1.19 ms per iteration, 64 x 64 x 8 1.21, 32 x 32 x 4 1.21, unsplit 1.40)
+        const int T = ns_split_T > 0 ? ns_split_T : Dev::pick_tile(k);
+        const int64_t ntile = ((k + 32 * T - 1) / (32 * T));
+        int nsplit = ns_split_n > 0 ? ns_split_n : (int)std::min<int64_t>(NS_MAX_SPLIT, std::max<int64_t>(1, 1224 / std::max<int64_t>(1, ntile * (ntile + 1) / 2)));
+        nsplit = (int)std::min<int64_t>(nsplit, std::max<int64_t>(1, h->ns_ldg / 512));
+        if (nsplit > 1) {
+            const int64_t pstride = h->ns_fN.ld * h->ns_fN.ld;
+            dev.launch_syrk(T, h->d_nsG, h->ns_ldg, nullptr, 0, k, (int)h->ns_ldg, h->d_nsth, nullptr, h->d_nsNp, h->ns_fN.ld, 0, 0, -1, nullptr, 0, -1.0, nsplit, pstride);
+            dev.end(id);
+            hipLaunchKernelGGL(k_ns_reduce_lower, dim3((unsigned)((k + 255) / 256), (unsigned)k), dim3(256), 0, h->stream, (const double*)h->d_nsNp, nsplit, pstride, h->ns_fN.ld,
+                               h->ns_fN.S, h->d_nsN0, k);
+        } else {
+            dev.launch_syrk(Dev::pick_tile(k), h->d_nsG, h->ns_ldg, nullptr, 0, k, (int)h->ns_ldg, h->d_nsth, nullptr, h->ns_fN.S, h->ns_fN.ld, 0, 0);
+            dev.end(id);
+            hipLaunchKernelGGL(k_ns_copy_lower, dim3((unsigned)((k + 255) / 256), (unsigned)k), dim3(256), 0, h->stream, (const double*)h->ns_fN.S, h->ns_fN.ld, h->d_nsN0, h->ns_fN.ld, k);
+        }
         dev.diag_prepare(k, 0, 1e-13, 1e-30);
         dev.chol(k, 1e-14, false);
         // dpbar = -e: the component of the iterate outside pbar + null(A_EF), split off once per LP and shrunk by (1 - a) with every step

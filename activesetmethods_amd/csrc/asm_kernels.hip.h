@@ -195,8 +195,18 @@ template <int T, int NW, int KC, int WPE>
 __global__ __launch_bounds__(64 * NW, WPE) void k_syrk(const double* __restrict__ A, int64_t ld, const int* __restrict__ idx, int64_t row0,
                                               int Ms, int K, const double* __restrict__ theta, const double* __restrict__ diag,
                                               double* __restrict__ S, int64_t ldS, int64_t srow0, int mode, int MsB, int ntj,
-                                              const unsigned char* __restrict__ nzflags, int nzpitch) {
+                                              const unsigned char* __restrict__ nzflags, int nzpitch, int64_t ksplit) {
     constexpr int TS = 32 * T;
+    if (gridDim.y > 1) {
+        // split-K (small matrices with a long k range: the k x k Newton matrix of the null-space form): slice blockIdx.y of the
+        // chunks, summed into its own copy of S (`ksplit` doubles apart); the caller adds the copies in a fixed order
+        const int per = ((K / KC + (int)gridDim.y - 1) / (int)gridDim.y) * KC;
+        const int k0s = (int)blockIdx.y * per;
+        A += k0s;
+        if (theta) theta += k0s;
+        K = max(0, min(per, K - k0s));
+        S += (int64_t)blockIdx.y * ksplit;
+    }
     // two LDS stages: the global loads of chunk c+1 are issued before the MFMAs of chunk c and written to the
     // other stage afterwards, so HBM/L2 latency hides under 16*T*T/4 matrix instructions; one barrier per chunk.
     __shared__ __attribute__((aligned(16))) double As[2][TS * (KC + 2)];

@@ -332,6 +332,19 @@ __global__ __launch_bounds__(256) void k_ns_copy_lower(const double* __restrict_
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j <= i && j < k) dst[(int64_t)i * ldd + j] = src[(int64_t)i * lds_ + j];
 }
+// lower triangle of the sum of the split-K slices (fixed order), written to the factor buffer and to the unregularised copy
+__global__ __launch_bounds__(256) void k_ns_reduce_lower(const double* __restrict__ parts, int nsplit, int64_t pstride, int64_t ld, double* __restrict__ S,
+                                                         double* __restrict__ N0, int k) {
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j <= i && j < k) {
+        const int64_t o = (int64_t)i * ld + j;
+        double v = parts[o];
+        for (int s_ = 1; s_ < nsplit; ++s_) v += parts[(int64_t)s_ * pstride + o];
+        S[o] = v;
+        N0[o] = v;
+    }
+}
 // x = a + b
 __global__ __launch_bounds__(256) void k_ns_add(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ x, int64_t len) {
     int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
