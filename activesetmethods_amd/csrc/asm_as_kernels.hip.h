@@ -23,7 +23,8 @@ struct AsPtrs {
     double scale_q;
     // derived from the current working set
     int *ksoft;                  // M : first basic slack of the row, -1 if none
-    int *Hidx, *hpos;            // hard rows (active, no basic slack) in ascending order / inverse map (-1)
+    int *Hidx, *hpos;            // hard rows (active, no basic slack) in the order of `rperm` (ascending when null) / inverse map (-1)
+    const int* rperm;            // M : the rows in reverse Cuthill-McKee order of their coupling graph (banded Gram matrices), or null
     int *Fidx, *fpos;            // free variables in ascending order / inverse map (-1)
     double *Fmask, *Hmask;       // 1.0 / 0.0 over the (padded) columns / rows: theta operands of the two Gram builds
     double *sl;                  // M : sum_k scoef_k slo_k of the row's slack columns (all slacks at their bound)
@@ -107,7 +108,8 @@ __global__ __launch_bounds__(1024) void k_as_setup(AsPtrs A, AsSets S, const dou
     __shared__ int sh_cnt[16];
     int baseH = 0, baseF = 0, any_soft = 0;
     for (int64_t i0 = 0; i0 < A.M; i0 += 1024) {
-        int64_t i = i0 + threadIdx.x;
+        const int64_t qpos = i0 + threadIdx.x;                              // position in the row order of the factorisations
+        const int64_t i = qpos < A.M ? (A.rperm ? (int64_t)A.rperm[qpos] : qpos) : qpos;
         bool hard = false;
         if (i < A.M) {
             int ks = -1;

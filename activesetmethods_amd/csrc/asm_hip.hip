@@ -33,6 +33,7 @@ namespace {
 const double INF = std::numeric_limits<double>::infinity();
 const double TOL_P = 1e-9, TOL_D = 1e-6;
 const int IPM_MAXIT = 60;
+const double IPM_GAP_DONE = 1e-3, IPM_DINF_FLOOR = 1e-6;      // stage complete with the dual residual on the solves' accuracy floor (oracle/lp_solver.py)
 const double JAM_PINF = 1e-6;    // below this a stagnating primal residual is rounding-level, not a jam (oracle/lp_solver.py)
 const int IPM_MCC = 2;           // Gondzio centrality correctors per iteration (oracle/lp_solver.py)
 const double MCC_DELTA = 0.3, MCC_BMIN = 0.1, MCC_BMAX = 10.0, MCC_GAMMA = 0.1;
@@ -235,6 +236,13 @@ struct asm_handle {
     int ns_ccap = 0;                // most constraints it is sized for
     int64_t ns_npairs = 0;          // structural non-zeros of the lower triangle of S0 (banded S0 only)
     int* d_nsS0pairs = nullptr;
+    // all M rows in reverse Cuthill-McKee order (sparse patterns whose bandwidth is below M / 2): the Gram matrices of row subsets taken in
+    // that order are banded with half-bandwidth <= row_band
+    int row_band = 0;
+    int *d_rowperm = nullptr, *d_rowpos = nullptr, *d_rowpairs = nullptr;      // position -> row, row -> position, structural pairs (row_i, row_j), pos_i >= pos_j
+    int64_t n_rowpairs = 0;
+    std::vector<int> row_perm_h;
+    int main_band_cur = 0;          // band of the matrix now in the main factor buffers (set by the banded builds, 0 after every other build)
     int main_band = 0;              // band of the matrix in the main factor buffers (test hook asm_test_set_band; 0 = dense)
     int ns_Zk = 0;                  // rows of the orthonormal basis of the previous LP still resident in d_nsG (0: none)
     int *d_nsqi = nullptr;          // sel | bpos | rpos | cnt
@@ -331,8 +339,10 @@ struct Dev {
     bool fsmall = false;
     int fband = 0;
     explicit Dev(asm_handle* hh) : h(hh), cur(hh->stream) { use_main(); }
-    void use_main() { fS = h->d_S; fld = h->Mp; fLinv = h->d_Linv; fBinv = h->d_Binv; fBinvT = h->d_BinvT; fwb = h->wb; fsmall = false; fband = h->main_band; }
+    void use_main() { fS = h->d_S; fld = h->Mp; fLinv = h->d_Linv; fBinv = h->d_Binv; fBinvT = h->d_BinvT; fwb = h->wb; fsmall = false; fband = h->main_band > 0 ? h->main_band : h->main_band_cur; }
     void use_factor(const FacBuf& f) { fS = f.S; fld = f.ld; fLinv = f.Linv; fBinv = f.Binv; fBinvT = f.BinvT; fwb = f.wb; fsmall = f.small; fband = f.band; }
+    // the matrix about to be built in the main buffers has this band (0 = dense)
+    void set_main_band(int b) { h->main_band_cur = b; if (fS == h->d_S) fband = h->main_band > 0 ? h->main_band : b; }
     // first row that the columns [.., c1) of a banded matrix / factor cannot reach (the order Ms when the matrix is dense)
     int rowlim(int Ms, int c1) const { return fband > 0 ? (int)std::min<int64_t>(Ms, round_up((int64_t)c1 + fband, 64)) : Ms; }
 
@@ -457,6 +467,7 @@ struct Dev {
     void gemv_n_dev(const double* A, const double* x, double* out) { launch_gemv_n(A, x, out); }
     void gemv_t_dev(const double* A, const double* y, double* out) { launch_gemv_t(A, y, out); }
     void syrk_dev(const int* idx_dev, int Ms, const double* theta_dev, const double* diag_dev) {
+        set_main_band(0);
         const bool skip = h->nz_valid && idx_dev == nullptr && Ms == (int)h->M && pick_tile(Ms) == h->nz_T;
         int id = begin(ASM_K_SYRK, (skip ? h->nz_fraction : 1.0) * (double)Ms * (Ms + 1) * h->ldn,
                        8.0 * (Ms * (double)h->ldn + 0.5 * Ms * (double)Ms));
@@ -466,7 +477,19 @@ struct Dev {
     }
     // S[0:Ms,0:Ms] (lower) = Ah[idx,:] diag(theta) Ah[idx,:]' + diag   with idx / theta / diag already on the device and the
     // chunk flags of the gathered row set (reduced row form of the interior-point system)
+    // S[0:Ms,0:Ms] (lower) of the same matrix for a row list in the handle's reverse Cuthill-McKee order (asm_handle::row_band): banded,
+    // built entry by entry from the structural pairs - cpos maps a row to its place in the list (-1: not in it).  The factorisation and the
+    // substitutions that follow stop at the band (main_band_cur).
+    void schur_banded_dev(const int* cpos_dev, int Ms, const double* theta_dev, const double* diag_dev) {
+        // the band plus what the blocked factorisation reads beyond it (an outer panel of CHOL_NBO columns, tile rounding)
+        const int64_t wz = std::min<int64_t>(round_up(h->row_band + 1, 64) + CHOL_NBO + 128, h->Mp);
+        hipLaunchKernelGGL(k_ns_zero_band, dim3((unsigned)((wz + 255) / 256), (unsigned)Ms), dim3(256), 0, h->stream, h->d_S, h->Mp, Ms, (int)wz);
+        hipLaunchKernelGGL(k_schur_sparse, dim3((unsigned)((h->n_rowpairs + 255) / 256)), dim3(256), 0, h->stream, (const int*)h->d_rowpairs, h->n_rowpairs, cpos_dev,
+                           h->d_sp_ptr, h->d_sp_col, sparse_vals(h->d_Ah), theta_dev, diag_dev, h->d_S, h->Mp);
+        set_main_band(h->row_band);
+    }
     void syrk_gathered_dev(const int* idx_dev, int Ms, const double* theta_dev, const double* diag_dev) {
+        set_main_band(0);
         const int nch = (int)(h->ldn / ASM_KC);
         const int T = pick_tile(Ms), TS = 32 * T;
         const int nt = (Ms + TS - 1) / TS;
@@ -552,6 +575,7 @@ struct Dev {
     }
     // S[0:n,0:n] (lower) = AhT diag(dinv) AhT' + diag(th)
     void syrk_col(const double* dinv_dev, const double* th_dev) {
+        set_main_band(0);
         ensure_AhT();
         const int n = (int)h->n;
         const int nch = (int)(h->ldT / ASM_KC);
@@ -658,6 +682,7 @@ struct Dev {
 
     // S[0:Ms,0:Ms] (lower) = Ah[idx,:] diag(theta) Ah[idx,:]' + diag     idx == nullptr -> identity
     void syrk(const int* idx_host, int Ms, const double* theta, const double* diag) {
+        set_main_band(0);
         h2d(h->d_theta, theta, h->n, h->ldn);
         if (diag) h2d(h->d_diag, diag, Ms, Ms);
         if (idx_host) {
@@ -1216,7 +1241,7 @@ struct Solver {
         if (h->ns_f0.band > 0) {
             // banded S0: the band is cleared (the last factor filled it) and the ~20 structural entries per row are written as merged
             // sparse dot products of the two rows - the dense rank-K build spends 3 ms on the zeros at n = 11 192
-            const int64_t wz = std::min<int64_t>(round_up(h->ns_f0.band + 1, 64) + 64, h->ns_f0.ld);
+            const int64_t wz = std::min<int64_t>(round_up(h->ns_f0.band + 1, 64) + CHOL_NBO + 128, h->ns_f0.ld);      // band + what the blocked factorisation reads beyond it
             hipLaunchKernelGGL(k_ns_zero_band, dim3((unsigned)((wz + 255) / 256), (unsigned)nE), dim3(256), 0, h->stream, h->ns_f0.S, h->ns_f0.ld, nE, (int)wz);
             hipLaunchKernelGGL(k_ns_s0_sparse, dim3((unsigned)((h->ns_npairs + 255) / 256)), dim3(256), 0, h->stream, (const int*)h->d_nsS0pairs, h->ns_npairs, h->d_sp_ptr,
                                h->d_sp_col, dev.sparse_vals(h->d_Ah), (const int*)h->d_nsEidx, (const double*)h->d_nsFm, h->ns_f0.S, h->ns_f0.ld);
@@ -1264,6 +1289,8 @@ struct Solver {
             std::vector<double> dg(n);
             for (int a = 0; a < 4 && !have; ++a) {
                 hipLaunchKernelGGL(k_ns_set_diag, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, h->stream, h->d_S, h->Mp, (int)n, (const double*)h->d_nsFm);
+                dev.use_main();
+                dev.set_main_band(0);
                 dev.launch_syrk(Dev::pick_tile(n), Yt, h->ns_nEp, nullptr, 0, (int)n, h->ns_nEp, nullptr, nullptr, h->d_S, h->Mp, 0, 1);
                 hipLaunchKernelGGL(k_ns_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_diag0, 1.0, n);
                 dev.chol((int)n, NS_SEL_THR[a]);
@@ -1587,7 +1614,10 @@ struct Solver {
         while (true) {
             ipm_measures();
             if (h->verbose) std::fprintf(stderr, "[asm] ipm %3d pinf %.3e dinf %.3e gap %.3e\n", ip.iters, ip.pinf, ip.dinf, ip.gap);
-            if (ip.pinf <= tol && ip.dinf <= tol && ip.gap <= tol) { if (ns_live()) ns_finish_y(); return ip.status = ASM_OPTIMAL; }
+            if (ip.pinf <= tol && ip.gap <= tol && (ip.dinf <= tol || (ip.gap <= IPM_GAP_DONE * tol && ip.dinf <= IPM_DINF_FLOOR))) {
+                if (ns_live()) ns_finish_y();
+                return ip.status = ASM_OPTIMAL;
+            }
             if (ip.iters >= 3 && ip.ymax > 1e3 * lp.scale_q) {
                 if (ns_live()) ns_finish_y();
                 down(ip.y, P.y, lp.M);
@@ -1742,6 +1772,7 @@ struct Solver {
         auto Si = [&]() { int* r_ = ia; ia += ls; return r_; };
         for (int k = 0; k < 6; ++k) { S_[k].rowst = Mi(); S_[k].bst = Ni(); S_[k].sst = Si(); }
         A.ksoft = Mi(); A.Hidx = Mi(); A.hpos = Mi(); A.Fidx = Ni(); A.fpos = Ni();
+        A.rperm = h->row_band > 0 ? h->d_rowperm : nullptr;
         A.cnt = ia;
     }
     // per LP: reference point of the unique-optimum polish (0 clipped into the box), slack offsets of the rows
@@ -1811,7 +1842,8 @@ struct Solver {
         }
         if (nH > 0 && nF > 0) {
             if (!(reuse_factor && part_factor)) {
-                dev.syrk_gathered_dev(A.Hidx, nH, A.Fmask, nullptr);
+                if (h->row_band > 0) dev.schur_banded_dev(A.hpos, nH, A.Fmask, nullptr);        // Hidx is in the banded row order (k_as_setup)
+                else dev.syrk_gathered_dev(A.Hidx, nH, A.Fmask, nullptr);
                 dev.diag_prepare(nH, 1, 0.0, 0.0);
                 dev.chol(nH, 1e-10);
                 part_factor = false;
@@ -2541,6 +2573,31 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
             h->d_nsv = ns_dalloc(h, 11 * h->ldn + 3 * h->Mp + 2 * h->ns_nEp);
         }
     }
+    // row order of the factorisations (see asm_handle::row_band)
+    h->row_band = 0; h->n_rowpairs = 0; h->row_perm_h.clear(); h->main_band_cur = 0;
+    h->d_rowperm = h->d_rowpos = h->d_rowpairs = nullptr;
+    if (h->sp_ok && !std::getenv("ASM_HIP_NO_BAND") && h->M >= 256) {
+        std::vector<int> all(h->M), pairs_pos;
+        for (int64_t i = 0; i < h->M; ++i) all[i] = (int)i;
+        int bw = 0;
+        const std::vector<int> ord = rcm_order(all, sp_ptr, sp_col, h->ldn, &bw, &pairs_pos);
+        if (2 * (int64_t)bw < h->M) {
+            h->row_band = std::max(bw, 1);
+            h->row_perm_h = ord;
+            std::vector<int> pos(h->M), pairs(pairs_pos.size());
+            for (int64_t q = 0; q < h->M; ++q) pos[ord[q]] = (int)q;
+            for (size_t t = 0; t < pairs_pos.size(); ++t) pairs[t] = ord[pairs_pos[t]];
+            h->n_rowpairs = (int64_t)pairs.size() / 2;
+            auto up = [&](const std::vector<int>& v) {
+                int* d = nullptr;
+                dmalloc(&d, (int64_t)v.size());
+                h->ns_bufs.push_back((void*)d);
+                HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
+                return d;
+            };
+            h->d_rowperm = up(ord); h->d_rowpos = up(pos); h->d_rowpairs = up(pairs);
+        }
+    }
     h->pin_len = std::max(std::max(h->ldn, h->Mp), h->nsp);
     HIPCHK(hipHostMalloc((void**)&h->h_pin, 2 * h->pin_len * sizeof(double)));
     HIPCHK(hipMemsetAsync(h->d_J, 0, h->Mp * h->ldn * sizeof(double), h->stream));
@@ -3249,6 +3306,7 @@ int asm_test_syrk_update(asm_handle* h, const double* Pm, int64_t Ms, int64_t K,
 
 static void test_load_S(asm_handle* h, const double* S, int64_t N) {
     test_alloc(h, N, 16);
+    h->main_band_cur = 0;
     for (int64_t i = 0; i < N; ++i)
         HIPCHK(hipMemcpy(h->d_S + i * h->Mp, S + i * N, N * sizeof(double), hipMemcpyHostToDevice));
 }

@@ -701,3 +701,26 @@ __global__ __launch_bounds__(256) void k_ns_s0_sparse(const int* __restrict__ pa
     }
     S[(int64_t)pi * ld + pj] = acc;
 }
+
+// Gram matrix of a row list in the handle's banded row order, entry by entry: pair (ri, rj) of rows that share a column -> place (cpos[ri], cpos[rj])
+// of the list (skipped when either row is not in it); weights theta over the columns, `diag` (indexed by place) added on the diagonal
+__global__ __launch_bounds__(256) void k_schur_sparse(const int* __restrict__ pairs, int64_t npairs, const int* __restrict__ cpos, const int* __restrict__ ptr,
+                                                      const int* __restrict__ col, const double* __restrict__ val, const double* __restrict__ theta,
+                                                      const double* __restrict__ diag, double* __restrict__ S, int64_t ld) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= npairs) return;
+    const int ri = pairs[2 * t], rj = pairs[2 * t + 1];
+    const int ci = cpos[ri], cj = cpos[rj];
+    if (ci < 0 || cj < 0) return;
+    int a = ptr[ri], b = ptr[rj];
+    const int ae = ptr[ri + 1], be = ptr[rj + 1];
+    double acc = 0.0;
+    while (a < ae && b < be) {
+        const int ca = col[a], cb = col[b];
+        if (ca == cb) { acc += val[a] * val[b] * theta[ca]; ++a; ++b; }
+        else if (ca < cb) ++a;
+        else ++b;
+    }
+    if (ri == rj && diag) acc += diag[ci];
+    S[(int64_t)max(ci, cj) * ld + min(ci, cj)] = acc;
+}

@@ -39,6 +39,8 @@ TOL_D = 1e-6      # dual feasibility of the accepted vertex (scaled units)
 IPM_TOL = 1e-8
 IPM_MAXIT = 60
 JAM_PINF = 1e-6       # a primal residual below this is rounding-level stagnation of a converging run, not a jam
+IPM_GAP_DONE = 1e-3   # a stage is also complete when the point is primal feasible, the gap is this factor below the tolerance and the dual
+IPM_DINF_FLOOR = 1e-6 # residual is below this floor: it then sits on the accuracy of the solves, and iterating on with mu underflowing only degrades it
 COL_MIN_M = 64        # column (Sherman-Morrison-Woodbury) form of the Newton system: smallest M, largest n/M, CG steps
 COL_MAX_RATIO = 0.8   # per solve beyond which the rest of the LP returns to the row form, pivot of fixed columns
 COL_MAX_CG = 6
@@ -84,6 +86,7 @@ class LP:
         self.slo = np.asarray(slo, float)
         self.ns = len(self.srow)
         self.row_cols = None          # structural pattern of the first rows (list of column arrays) when the builder knows it; else A != 0
+        self.row_pos = None           # position of every row in the order of the factorisations (row_order); None = natural order
 
 
 # ----------------------------------------------------------------------------- scaling
@@ -115,6 +118,7 @@ def scale_lp(lp):
     s = LP(qh / kap, Ah, lp.rtype, lp.r / rho, lp.lb / c, lp.ub / c,
            lp.srow, lp.scoef, wh / kap, lp.slo / rho[lp.srow])
     s.row_cols = getattr(lp, 'row_cols', None)
+    s.row_pos = getattr(lp, 'row_pos', None)
     return s, c, rho, kap
 
 
@@ -228,6 +232,33 @@ def rcm_order(row_cols):
         pos[i] = q
     bw = max((abs(pos[i] - pos[u]) for i in range(nR) for u in nbr[i]), default=0)
     return np.array(order, np.int64), bw
+
+
+ROW_ORDER_MIN_M = 256
+
+
+def row_order(row_cols, n):
+    """Position of every row in the order the factorisations take row subsets in, or None for the natural order: reverse Cuthill-McKee
+    (rcm_order) when the pattern is sparse (16 nnz <= M n, the rule of the sparse kernels), M >= ROW_ORDER_MIN_M and the order's
+    bandwidth is below M / 2 (asm_hip.hip: do_setup, row_band)."""
+    M = len(row_cols)
+    nnz = sum(len(c) for c in row_cols)
+    if M < ROW_ORDER_MIN_M or nnz == 0 or nnz * 16 > M * n:
+        return None
+    order, bw = rcm_order(row_cols)
+    if 2 * bw >= M:
+        return None
+    pos = np.empty(M, np.int64)
+    pos[order] = np.arange(M)
+    return pos
+
+
+def ordered_rows(lp, idx):
+    """Row indices `idx` in the order of the factorisations (lp.row_pos; natural when absent)."""
+    rp = getattr(lp, 'row_pos', None)
+    if rp is None or len(idx) == 0:
+        return idx
+    return idx[np.argsort(rp[idx], kind='stable')]
 
 
 class NullSpace:
@@ -434,7 +465,7 @@ class IPM:
         while True:
             pinf, dinf, gap = self.measures()
             self.log.append((self.iters, pinf, dinf, gap))
-            if pinf <= tol and dinf <= tol and gap <= tol:
+            if pinf <= tol and gap <= tol and (dinf <= tol or (gap <= IPM_GAP_DONE * tol and dinf <= IPM_DINF_FLOOR)):
                 if self.ns_live():
                     self.ns_finish_y()
                 self.status = OPTIMAL
@@ -801,7 +832,7 @@ def eqp(lp, sets, p_ref, y_ref, refine=4):
         if not soft[i]:
             soft[i] = True
             y[i] = lp.w[k] * lp.scoef[k]
-    H = np.nonzero((rowst == 1) & ~soft)[0]
+    H = ordered_rows(lp, np.nonzero((rowst == 1) & ~soft)[0])
     nfact = 0
     if len(H) > 0 and len(F) > 0:
         AHF = A[np.ix_(H, F)]
@@ -955,7 +986,7 @@ def _face_primal_solve(lp, W, sl, stats):
     s = lp.slo.copy()
     soft, _, ksoft = _soft_rows(lp, sst)
     hard = (rowst == 1) & ~soft
-    H = np.nonzero(hard)[0]
+    H = ordered_rows(lp, np.nonzero(hard)[0])
     u = np.zeros(M)
     if len(H) > 0 and len(F) > 0:
         AHF = A[np.ix_(H, F)]
@@ -1071,7 +1102,7 @@ def _face_primal_anchored(lp, part, anchor, sl, stats):
     Fm = F0.astype(float)
     soft0, _, ksoft0 = _soft_rows(lp, sst0)
     hard0 = (rowst0 == 1) & ~soft0
-    H0 = np.nonzero(hard0)[0]
+    H0 = ordered_rows(lp, np.nonzero(hard0)[0])
     pfix = np.where(bst0 < 0, lp.lb, np.where(bst0 > 0, lp.ub, 0.0))
     Lc = None
     if len(H0) > 0 and F0.any():
@@ -1203,7 +1234,7 @@ def face_dual(lp, part, stats):
         F = np.nonzero(bst == 0)[0]
         soft, ysoft, _ = _soft_rows(lp, sst)
         hard = (rowst == 1) & ~soft
-        H = np.nonzero(hard)[0]
+        H = ordered_rows(lp, np.nonzero(hard)[0])
         y = ysoft.copy()
         if len(H) > 0 and len(F) > 0:
             AHF = A[np.ix_(H, F)]

@@ -79,6 +79,10 @@ class QpModel:
             raise ValueError("free constraint rows are not representable (subproblem.jl:143-197 adds no row)")
         self.adj = np.nonzero(self.kind == 2)[0]
         self.M = m + len(self.adj)
+        # row order of the factorisations (lp_solver.row_order): all M rows in reverse Cuthill-McKee order of their coupling graph when the
+        # pattern is sparse and that order has a bandwidth below M / 2 - the HIP library's factorisations stop at the band; this dense
+        # restatement only shares the order (the pivot guard drops the LATER of two dependent rows)
+        self.row_pos = L.row_order(self.row_cols + [self.row_cols[v] for v in self.adj], n)
         # LP row types
         rtype = np.zeros(self.M, np.int64)
         rtype[:m] = np.where(self.kind == 0, 0, np.where(self.kind == -1, -1, 1))
@@ -148,6 +152,7 @@ class QpModel:
         r[m:] = c_ub[self.adj]
         lp = L.LP(q, A, self.rtype, r, lb, ub, srow, scoef, w, slo)
         lp.row_cols = self.row_cols                 # structural pattern (j_row, j_col) of the m constraint rows (the adj rows are inequalities)
+        lp.row_pos = self.row_pos
         return lp
 
     def sub_optimize(self, x_k, Delta, feasibility=False):
