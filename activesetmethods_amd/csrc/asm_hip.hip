@@ -239,7 +239,7 @@ struct asm_handle {
     // all M rows in reverse Cuthill-McKee order (sparse patterns whose bandwidth is below M / 2): the Gram matrices of row subsets taken in
     // that order are banded with half-bandwidth <= row_band
     int row_band = 0;
-    int *d_rowperm = nullptr, *d_rowpos = nullptr, *d_rowpairs = nullptr;      // position -> row, row -> position, structural pairs (row_i, row_j), pos_i >= pos_j
+    int *d_rowperm = nullptr, *d_rowpos = nullptr, *d_rowpairs = nullptr, *d_cpos = nullptr;      // position -> row, row -> position, structural pairs (row_i, row_j), pos_i >= pos_j
     int64_t n_rowpairs = 0;
     std::vector<int> row_perm_h;
     int main_band_cur = 0;          // band of the matrix now in the main factor buffers (set by the banded builds, 0 after every other build)
@@ -1539,6 +1539,7 @@ struct Solver {
     }
 
     bool use_red = false;     // reduced row form: factor of the rows redE, diagonal on the rows redI
+    bool use_perm = false;    // full row form with the rows in the handle's banded order (row_band > 0): solves gather / scatter through d_rowperm
     std::vector<int> redE, redI;
     int nE = 0, nI = 0;
     vec tmpM2;
@@ -1553,6 +1554,13 @@ struct Solver {
             hipLaunchKernelGGL(k_red_gather, dim3((unsigned)((nE + 255) / 256)), dim3(256), 0, h->stream, h->d_idx, nE, in, h->d_rce);
             dev.chol_solve_dev(h->d_rce, h->d_rze, nE);
             hipLaunchKernelGGL(k_red_scatter, dim3(gm), dim3(256), 0, h->stream, h->d_idx, nE, h->d_rze, h->d_idxI, nI, h->d_rdI, in, out);
+            return;
+        }
+        if (use_perm) {
+            hipLaunchKernelGGL(k_red_gather, dim3(gm), dim3(256), 0, h->stream, (const int*)h->d_rowperm, M, in, h->d_rce);
+            dev.chol_solve_dev(h->d_rce, h->d_rze, M);
+            hipLaunchKernelGGL(k_red_scatter, dim3(gm), dim3(256), 0, h->stream, (const int*)h->d_rowperm, M, (const double*)h->d_rze, (const int*)h->d_rowperm, 0,
+                               (const double*)h->d_rze, in, out);
             return;
         }
         if (!use_col) { dev.chol_solve_dev(in, out, M); return; }
@@ -1636,6 +1644,7 @@ struct Solver {
             // column form (oracle: IPM.run): K = Th + Ah' D^-1 Ah (n x n) while its Sherman-Morrison-Woodbury preconditioner
             // keeps the CG short, the row form S = Ah Th^-1 Ah' + D (M x M) otherwise
             use_red = false;
+            use_perm = false;
             // null-space form (oracle: IPM.run): set up once per LP, k x k factorisation per iteration
             use_ns = false;
             if (ip.ns_ok && !ip.ns_off) {
@@ -1660,7 +1669,8 @@ struct Solver {
                     down(tmpM2, h->d_sdiag, lp.M);
                     HIPCHK(hipStreamSynchronize(h->stream));
                     redE.clear(); redI.clear();
-                    for (int64_t i = 0; i < lp.M; ++i) {
+                    for (int64_t q = 0; q < lp.M; ++q) {                 // kept rows in the order of the factorisations
+                        const int64_t i = h->row_band > 0 ? h->row_perm_h[q] : q;
                         if (tmpM[i] > RED_TAU * tmpM2[i]) redI.push_back((int)i);
                         else redE.push_back((int)i);
                     }
@@ -1676,10 +1686,25 @@ struct Solver {
                     HIPCHK(hipMemcpyAsync(h->d_idxI, redI.data(), nI * sizeof(int), hipMemcpyHostToDevice, h->stream));
                     HIPCHK(hipMemcpyAsync(h->d_diag, dE_.data(), nE * sizeof(double), hipMemcpyHostToDevice, h->stream));
                     HIPCHK(hipMemcpyAsync(h->d_rdI, dI_.data(), nI * sizeof(double), hipMemcpyHostToDevice, h->stream));
-                    HIPCHK(hipStreamSynchronize(h->stream));      // the host vectors go out of scope
-                    dev.syrk_gathered_dev(h->d_idx, nE, P.thp_inv, h->d_diag);
+                    if (h->row_band > 0) {
+                        std::vector<int> cp(lp.M, -1);
+                        for (int a = 0; a < nE; ++a) cp[redE[a]] = a;
+                        HIPCHK(hipMemcpyAsync(h->d_cpos, cp.data(), lp.M * sizeof(int), hipMemcpyHostToDevice, h->stream));
+                        HIPCHK(hipStreamSynchronize(h->stream));
+                        dev.schur_banded_dev(h->d_cpos, nE, P.thp_inv, h->d_diag);
+                    } else {
+                        HIPCHK(hipStreamSynchronize(h->stream));      // the host vectors go out of scope
+                        dev.syrk_gathered_dev(h->d_idx, nE, P.thp_inv, h->d_diag);
+                    }
                     dev.diag_prepare(nE, 0, 1e-13, 1e-30);
                     dev.chol(nE);
+                } else if (h->row_band > 0) {
+                    // full row form, rows in the banded order: S is built entry by entry, factor and substitutions stop at the band
+                    use_perm = true;
+                    hipLaunchKernelGGL(k_red_gather, dim3((unsigned)((lp.M + 255) / 256)), dim3(256), 0, h->stream, (const int*)h->d_rowperm, M, (const double*)P.dS, h->d_diag);
+                    dev.schur_banded_dev(h->d_rowpos, M, P.thp_inv, h->d_diag);
+                    dev.diag_prepare(M, 0, 1e-13, 1e-30);
+                    dev.chol(M);
                 } else {
                     dev.syrk_dev(nullptr, M, P.thp_inv, P.dS);
                     dev.diag_prepare(M, 0, 1e-13, 1e-30);
@@ -2575,7 +2600,7 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     }
     // row order of the factorisations (see asm_handle::row_band)
     h->row_band = 0; h->n_rowpairs = 0; h->row_perm_h.clear(); h->main_band_cur = 0;
-    h->d_rowperm = h->d_rowpos = h->d_rowpairs = nullptr;
+    h->d_rowperm = h->d_rowpos = h->d_rowpairs = h->d_cpos = nullptr;
     if (h->sp_ok && !std::getenv("ASM_HIP_NO_BAND") && h->M >= 256) {
         std::vector<int> all(h->M), pairs_pos;
         for (int64_t i = 0; i < h->M; ++i) all[i] = (int)i;
@@ -2596,6 +2621,8 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
                 return d;
             };
             h->d_rowperm = up(ord); h->d_rowpos = up(pos); h->d_rowpairs = up(pairs);
+            h->d_cpos = up(pos);                      // place of every row in the current row list of the interior-point factor (rewritten per iteration)
+            if (!h->d_rce) { dmalloc(&h->d_rce, h->Mp); dmalloc(&h->d_rze, h->Mp); }
         }
     }
     h->pin_len = std::max(std::max(h->ldn, h->Mp), h->nsp);

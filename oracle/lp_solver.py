@@ -569,7 +569,7 @@ class IPM:
             elif use_red:
                 self.red_iters += 1
                 self.__dict__.setdefault('red_sizes', []).append(int((~drop).sum()))
-                E = np.nonzero(~drop)[0]
+                E = ordered_rows(lp, np.nonzero(~drop)[0])
                 Idx = np.nonzero(drop)[0]
                 SE = dsyrk(1.0, A[E] * np.sqrt(thp_inv), lower=True)
                 edx = np.arange(len(E))
@@ -590,10 +590,22 @@ class IPM:
                 S[idx, idx] += dS
                 diag0 = S[idx, idx].copy()
                 S[idx, idx] += 1e-13 * diag0 + 1e-30
-                L = chol_guard(S, diag0)
+                row_pos = getattr(lp, 'row_pos', None)
+                if row_pos is None:
+                    L = chol_guard(S, diag0)
 
-                def precond(r):
-                    return chol_solve(L, r)
+                    def precond(r):
+                        return chol_solve(L, r)
+                else:
+                    # rows in the order of the factorisations (row_order): the same matrix, symmetrically permuted
+                    perm = np.argsort(row_pos, kind='stable')
+                    Sf = np.tril(S) + np.tril(S, -1).T
+                    L = chol_guard(Sf[np.ix_(perm, perm)], diag0[perm])
+
+                    def precond(r):
+                        z = np.empty(M)
+                        z[perm] = chol_solve(L, r[perm])
+                        return z
             self.iters += 1
             done += 1
             cg_max = [0]
