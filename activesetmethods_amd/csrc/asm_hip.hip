@@ -591,6 +591,7 @@ struct Dev {
         if (h->M == 0) return;
         const int nch = (int)(h->ldn / ASM_KC);
         if (h->dense_fast || nch > ASM_MAXCHUNKS || h->nnz * 8 > h->M * h->n) return;     // dense pattern: nothing to skip
+        if (h->row_band > 0) return;      // banded row order: the full-row Schur matrix is built from its structural entries, not by k_syrk
         h->nz_T = pick_tile(h->M);
         const int TS = 32 * h->nz_T;
         const int nt = (int)((h->M + TS - 1) / TS);
@@ -877,6 +878,16 @@ struct Dev {
         int64_t R = std::min<int64_t>((h->M + 31) / 32, ASM_TMAXCHUNKS);
         int64_t chunk = (h->M + R - 1) / R;
         R = (h->M + chunk - 1) / chunk;
+        if (h->sp_ok) {                      // sparse pattern: the same maxima over the stored entries only
+            const double* vJ = sparse_vals(h->d_J);
+            int id = begin(ASM_K_SCALE, 0.0, 8.0 * 3.0 * h->sp_nnz);
+            hipLaunchKernelGGL(k_sp_row_absmax, dim3((unsigned)((h->M + 255) / 256)), dim3(256), 0, h->stream, (const int*)h->d_sp_ptr, vJ, h->d_rho, h->M);
+            hipLaunchKernelGGL(k_sp_col_relmax, dim3((unsigned)((h->ldn + 255) / 256)), dim3(256), 0, h->stream, (const int*)h->d_sc_ptr, (const int*)h->d_sc_row,
+                               (const int*)h->d_sc_pos, vJ, (const double*)h->d_rho, h->d_vecN, h->n, h->ldn);
+            end(id);
+            d2h(rel, h->d_vecN, h->n);
+            return;
+        }
         int id = begin(ASM_K_SCALE, 0.0, 8.0 * 2.0 * h->M * h->ldn);
         hipLaunchKernelGGL(k_row_absmax, dim3((unsigned)((h->M + 3) / 4)), dim3(256), 0, h->stream, h->d_J, h->ldn, h->d_rho, h->M, h->ldn);
         hipLaunchKernelGGL(k_col_relmax_stage1, dim3((unsigned)((h->ldn + 255) / 256), (unsigned)R), dim3(256), 0, h->stream, h->d_J,
@@ -892,6 +903,16 @@ struct Dev {
         h->ahT_valid = false;
         if (h->M == 0) return;
         h2d(h->d_c, c, h->n, h->ldn);
+        if (h->sp_ok) {
+            const double* vJ = sparse_vals(h->d_J);
+            int id = begin(ASM_K_SCALE, 0.0, 8.0 * 4.0 * h->sp_nnz);
+            hipLaunchKernelGGL(k_sp_scale_rows, dim3((unsigned)((h->M + 255) / 256)), dim3(256), 0, h->stream, (const int*)h->d_sp_ptr, (const int*)h->d_sp_col,
+                               (const int64_t*)h->d_sp_off, vJ, (const double*)h->d_c, h->d_Ah, h->d_spv_Ah, h->d_rho, h->M);
+            end(id);
+            h->spv_Ah_valid = true;
+            d2h(rho, h->d_rho, h->M);
+            return;
+        }
         int id = begin(ASM_K_SCALE, 0.0, 8.0 * 3.0 * h->M * h->ldn);
         hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)h->M), dim3(256), 0, h->stream, h->d_J, h->d_c, h->d_Ah, h->d_rho, h->n,
                            h->ldn);

@@ -1090,6 +1090,44 @@ __global__ __launch_bounds__(256) void k_col_relmax_stage2(const double* __restr
     out[j] = mx;
 }
 
+// The same three scaling passes on the CSR / CSC pattern of a sparse Jacobian (values gathered in pattern order: v[k] = J[off[k]]): the
+// maxima are order-independent, so the results are those of the dense kernels - which spend 0.9 ms per pass on the zeros at 18 637 x 11 192.
+__global__ __launch_bounds__(256) void k_sp_row_absmax(const int* __restrict__ ptr, const double* __restrict__ v, double* __restrict__ out, int64_t M) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    double mx = 0.0;
+    for (int k = ptr[i]; k < ptr[i + 1]; ++k) mx = fmax(mx, fabs(v[k]));
+    out[i] = mx > 0.0 ? mx : 1.0;
+}
+__global__ __launch_bounds__(256) void k_sp_col_relmax(const int* __restrict__ cptr, const int* __restrict__ crow, const int* __restrict__ cpos,
+                                                       const double* __restrict__ v, const double* __restrict__ rmax, double* __restrict__ out,
+                                                       int64_t n, int64_t ncols) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= ncols) return;
+    double mx = 0.0;
+    if (j < n)
+        for (int q = cptr[j]; q < cptr[j + 1]; ++q) mx = fmax(mx, fabs(v[cpos[q]]) / rmax[crow[q]]);
+    out[j] = mx;
+}
+// rho_i = pow2(max |J_ij c_j|), Ah_ij = J_ij c_j / rho_i at the pattern's entries (the rest of the dense copy is zero and stays zero), and the
+// same values in pattern order (vAh)
+__global__ __launch_bounds__(256) void k_sp_scale_rows(const int* __restrict__ ptr, const int* __restrict__ col, const int64_t* __restrict__ off,
+                                                       const double* __restrict__ vJ, const double* __restrict__ c, double* __restrict__ Ah,
+                                                       double* __restrict__ vAh, double* __restrict__ rho, int64_t M) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    double mx = 0.0;
+    for (int k = ptr[i]; k < ptr[i + 1]; ++k) mx = fmax(mx, fabs(vJ[k] * c[col[k]]));
+    const double r = pow2_round_dev(mx);
+    rho[i] = r;
+    const double inv = 1.0 / r;
+    for (int k = ptr[i]; k < ptr[i + 1]; ++k) {
+        const double a = vJ[k] * c[col[k]] * inv;
+        Ah[off[k]] = a;
+        vAh[k] = a;
+    }
+}
+
 // FP64 matrix-core peak probe: back-to-back v_mfma_f64_16x16x4_f64 on 8 independent accumulators per wavefront,
 // operands in registers, no memory traffic.  Used only to measure the roofline denominator on the box at hand.
 template <int NACC>
