@@ -52,6 +52,8 @@ PROTOTYPES = {
     "asm_eval_jacobian_values": (C.c_int, [_P, _D]),
     "asm_slp_norms": (C.c_int, [_P, _D, _D, _D, _D]),
     "asm_slp_merit": (C.c_int, [_P, C.c_int, C.c_double, _D, _D, _D, C.c_int, C.c_double, _D]),
+    "asm_slp_line_search": (C.c_int, [_P, _D, _D, _D, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _D, _D,
+                                      C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "asm_test_syrk": (C.c_int, [_P, _D, C.c_int64, C.c_int64, _I32, C.c_int64, _D, _D, _D, C.c_int]),
     "asm_test_syrk_update": (C.c_int, [_P, _D, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _D, C.c_int]),
     "asm_test_cholesky": (C.c_int, [_P, _D, C.c_int64, _D]),

@@ -3303,6 +3303,49 @@ int asm_slp_merit(asm_handle* h, int mode, double alpha, const double* p, const 
     });
 }
 
+// compute_alpha (slp_line_search.jl:222-244) with the trial evaluations on the device: alpha = 1, tau, tau^2, ... until
+//   phi(alpha) <= phi0 + eta alpha D      (accepted: *ok = 1)      or      alpha < min_alpha with the test still failing (*ok = 0).
+// The trials are pure function evaluations, so they are launched eight at a time without waiting for the verdict of the earlier ones
+// (one read-back per eight); nu, the slacks and p are uploaded once.  Same alpha, same merit values as calling asm_slp_merit per trial.
+int asm_slp_line_search(asm_handle* h, const double* p, const double* nu, const double* p_slack, int feasibility, double prim_infeas, double phi0,
+                        double D, double eta, double tau, double min_alpha, double* alpha_out, double* phi_out, int* trials_out, int* ok_out) {
+    return guarded(h, [&] {
+        if (!h->ev_ready || !h->inputs_ready || !p || !alpha_out || !ok_out || (h->m > 0 && (!nu || !p_slack)) || !(tau > 0.0 && tau < 1.0))
+            throw std::logic_error("asm_slp_line_search: asm_eval_functions first / bad argument");
+        HIPCHK(hipSetDevice(h->device));
+        const int64_t n = h->n, m = h->m;
+        double* v = h->d_ev_vecs + 2 * m + 2 * n + m + 2 * n;    // nu | ps | p
+        double *nud = v, *psd = v + m, *pd = psd + 2 * m, *outd = pd + n + h->ldn + h->Mp;
+        double* st = h->h_ev;
+        if (m) { std::memcpy(st, nu, m * sizeof(double)); std::memcpy(st + m, p_slack, 2 * m * sizeof(double)); }
+        std::memcpy(st + 3 * m, p, n * sizeof(double));
+        HIPCHK(hipMemcpyAsync(nud, st, (3 * m + n) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        const SlpVecs V = ev_vecs(h, nullptr, nullptr, nullptr, nullptr, nullptr);
+        constexpr int CH = 8;
+        double alpha = 1.0, a[CH];
+        int trials = 0;
+        *ok_out = -1;
+        while (*ok_out < 0) {
+            for (int t = 0; t < CH; ++t) {
+                a[t] = alpha;
+                hipLaunchKernelGGL(k_axpy_out, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->d_ev_x, alpha, (const double*)pd, h->d_ev_xt, n);
+                ev_launch(h, h->d_ev_xt, h->d_ev_Et, h->d_ev_f + 1, false);
+                hipLaunchKernelGGL(k_slp_merit, dim3(1), dim3(1024), 0, h->stream, V, (const double*)h->d_ev_Et, (const double*)nud, (const double*)psd, (const double*)pd, alpha,
+                                   feasibility, prim_infeas, (const double*)(h->d_ev_f + 1), 0, outd + t);
+                alpha *= tau;
+            }
+            HIPCHK(hipMemcpyAsync(st, outd, CH * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            for (int t = 0; t < CH && *ok_out < 0; ++t) {
+                trials += 1;
+                if (!(st[t] > phi0 + eta * a[t] * D)) { *ok_out = 1; *alpha_out = a[t]; if (phi_out) *phi_out = st[t]; }
+                else if (a[t] < min_alpha) { *ok_out = 0; *alpha_out = a[t]; if (phi_out) *phi_out = st[t]; }
+            }
+        }
+        if (trials_out) *trials_out = trials;
+    });
+}
+
 // --------------------------------------------------------------------------------- kernel test hooks
 static void test_alloc(asm_handle* h, int64_t M, int64_t K) {
     // minimal "problem" so that the generic buffers exist: dense pattern M x K

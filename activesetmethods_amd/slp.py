@@ -185,6 +185,9 @@ class AbstractSlpOptimizer:
     def compute_phi(self, x, alpha, p):
         pr = self.problem
         if self._fm is not None:
+            # the device evaluator holds the iterate of the last eval_functions(): the merit is taken there, not at an arbitrary x
+            if x is not self.x:
+                raise ValueError("compute_phi with the device evaluator is defined at the current iterate self.x only")
             return self.optimizer.slp_merit(0, alpha, p, self.nu, self.p_slack, self.feasibility_restoration, self.prim_infeas)
         xp = x + alpha * p
         E = self.E if alpha == 0.0 else pr.eval_g(xp, np.zeros(pr.m))
@@ -243,6 +246,13 @@ class SlpLS(AbstractSlpOptimizer):
 
     def compute_alpha(self):                                     # slp_line_search.jl:222-244
         o = self.options
+        if self._fm is not None:
+            # the trial points are evaluated on the device, eight per read-back (same alpha as the loop below)
+            self.alpha, _, self.ls_trials, ok = self.optimizer.slp_line_search(self.p, self.nu, self.p_slack, self.feasibility_restoration, self.prim_infeas,
+                                                                               self.phi, self.directional_derivative, o.eta, o.tau, o.min_alpha)
+            if not ok and self.feasibility_restoration:
+                self.ret = -3
+            return ok
         self.alpha = 1.0
         while self.compute_phi(self.x, self.alpha, self.p) > self.phi + o.eta * self.alpha * self.directional_derivative:
             if self.alpha < o.min_alpha:

@@ -231,6 +231,14 @@ class HipSubOptimizer:
 
     def slp_merit(self, mode, alpha, p, nu, p_slack, feasibility, prim_infeas):
         """mode 0: compute_phi(x, alpha, p) (slp.jl:79-115); mode 1: compute_derivative (slp.jl:122-147)."""
+        ps = self._flat_slacks(p_slack)
+        out = C.c_double(0.0)
+        p, nu = _f64(p), _f64(nu)
+        self._check(self._lib.asm_slp_merit(self._h, int(mode), float(alpha), _lib.dptr(p), _lib.dptr(nu), _lib.dptr(ps), int(bool(feasibility)),
+                                            float(prim_infeas) if np.isfinite(prim_infeas) else 0.0, C.byref(out)))
+        return out.value
+
+    def _flat_slacks(self, p_slack):
         ps = getattr(p_slack, "raw", None)
         if ps is None:
             ps = np.full(2 * max(self.m, 1), np.nan)
@@ -239,11 +247,19 @@ class HipSubOptimizer:
                 ps[2 * i] = v[0]
                 if len(v) > 1:
                     ps[2 * i + 1] = v[1]
-        out = C.c_double(0.0)
+        return ps
+
+    def slp_line_search(self, p, nu, p_slack, feasibility, prim_infeas, phi0, D, eta, tau, min_alpha):
+        """compute_alpha (slp_line_search.jl:222-244) with the trial points evaluated on the device (asm_slp_line_search).
+        Returns (alpha, phi(alpha), trials, ok)."""
+        ps = self._flat_slacks(p_slack)
         p, nu = _f64(p), _f64(nu)
-        self._check(self._lib.asm_slp_merit(self._h, int(mode), float(alpha), _lib.dptr(p), _lib.dptr(nu), _lib.dptr(ps), int(bool(feasibility)),
-                                            float(prim_infeas) if np.isfinite(prim_infeas) else 0.0, C.byref(out)))
-        return out.value
+        alpha, phi = C.c_double(0.0), C.c_double(0.0)
+        trials, ok = C.c_int(0), C.c_int(0)
+        self._check(self._lib.asm_slp_line_search(self._h, _lib.dptr(p), _lib.dptr(nu), _lib.dptr(ps), int(bool(feasibility)),
+                                                  float(prim_infeas) if np.isfinite(prim_infeas) else 0.0, float(phi0), float(D), float(eta), float(tau),
+                                                  float(min_alpha), C.byref(alpha), C.byref(phi), C.byref(trials), C.byref(ok)))
+        return alpha.value, phi.value, trials.value, bool(ok.value)
 
     # per-iteration reductions on the resident Jacobian (common.jl:35-44, slp.jl:54-66)
     def kt_residuals(self, df, lam, mult_x_U, mult_x_L):

@@ -180,6 +180,12 @@ int asm_slp_norms(asm_handle* h, const double* lambda, const double* mult_x_U, c
 int asm_slp_merit(asm_handle* h, int mode, double alpha, const double* p, const double* nu, const double* p_slack,
                   int feasibility, double prim_infeas, double* out);
 
+/* compute_alpha (slp_line_search.jl:222-244): backtracking alpha = 1, tau, tau^2, ... on the merit function, the trial points evaluated on
+ * the device eight at a time (same alpha and merit values as one asm_slp_merit call per trial).  *ok = 1: Armijo test passed at *alpha;
+ * *ok = 0: alpha fell below min_alpha with the test still failing (*alpha is that last trial, as the reference leaves it). */
+int asm_slp_line_search(asm_handle* h, const double* p, const double* nu, const double* p_slack, int feasibility, double prim_infeas, double phi0,
+                        double D, double eta, double tau, double min_alpha, double* alpha, double* phi_alpha, int* trials, int* ok);
+
 /* Test hook: the matrices loaded by asm_test_cholesky / asm_test_chol_solve / asm_test_trsm_rows are banded with this half-bandwidth
  * (0 = dense): factorisation and substitutions stop at the band, as they do for S0 = A_EF A_EF' of the null-space form (its equality
  * rows are put in reverse Cuthill-McKee order at set-up). */

@@ -199,3 +199,43 @@ def test_acopf_slp_run_device_evaluation_matches_host_evaluation():
         assert a["status"] == b["status"] and a["fr"] == b["fr"]
         assert rel_err(a["p"], b["p"]) < 1e-8
     assert rel_err(md.x, mh.x) < 1e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fr", [False, True])
+def test_device_line_search_equals_trial_by_trial_merit(fr):
+    """asm_slp_line_search (trial points evaluated eight per read-back) against the loop of slp_line_search.jl:222-244 built from
+    asm_slp_merit calls: same alpha, same merit value, same number of trials - for steps that are accepted at once, after a few
+    reductions, after more than one batch of eight, and never (alpha < min_alpha)."""
+    import activesetmethods_amd as A
+    from activesetmethods_amd import acopf
+    case = acopf.synthetic_case("case118", 1, 1.0)
+    pr = acopf.function_model(case).to_problem("case118 ls")
+    mdl = A.Model.from_problem(pr, A.Parameters(algorithm="Line Search", max_iter=50, device_eval=True))
+    slp = A.SlpLS(mdl)
+    slp.run(max_lp_solves=3)
+    slp.eval_functions()
+    opt = slp.optimizer
+    rng = np.random.default_rng(11)
+    nu = np.abs(rng.standard_normal(pr.m)) + 0.1
+    ps = np.abs(rng.standard_normal(2 * pr.m))
+    both = (pr.g_L > -np.inf) & (pr.g_U < np.inf)
+    ps[1::2][~both] = np.nan
+    prim = 0.37
+    eta, tau, min_alpha = 0.4, 0.9, 1e-6
+    for scale, dd in ((1e-3, -1.0), (0.3, -5.0), (3.0, -50.0), (3.0, -1e9), (0.5, 1e3)):
+        p = scale * rng.standard_normal(pr.n)
+        phi0 = opt.slp_merit(0, 0.0, p, nu, type("S", (), {"raw": ps})(), fr, prim)
+        alpha, trials, ok, phi_a = 1.0, 0, None, None
+        while True:
+            phi_a = opt.slp_merit(0, alpha, p, nu, type("S", (), {"raw": ps})(), fr, prim)
+            trials += 1
+            if not (phi_a > phi0 + eta * alpha * dd):
+                ok = True
+                break
+            if alpha < min_alpha:
+                ok = False
+                break
+            alpha *= tau
+        got = opt.slp_line_search(p, nu, type("S", (), {"raw": ps})(), fr, prim, phi0, dd, eta, tau, min_alpha)
+        assert got[3] == ok and got[0] == alpha and got[2] == trials and got[1] == phi_a, (scale, dd, got, alpha, phi_a, trials, ok)
