@@ -40,6 +40,7 @@ PROTOTYPES = {
     "asm_sublp_active_set": (C.c_int, [_P, _I32, _I32, _I32, _I64, _I64]),
     "asm_sublp_reset_warm": (C.c_int, [_P]),
     "asm_sublp_ns_basis": (C.c_int, [_P, _I32, _I64]),
+    "asm_sublp_row_order": (C.c_int, [_P, _I32, _I64, _I32, _I64, _I64]),
     "asm_sublp_last_stats": (C.c_int, [_P, C.POINTER(SolveStats)]),
     "asm_kernel_stats_get": (C.c_int, [_P, C.POINTER(KernelStats)]),
     "asm_kernel_stats_reset": (C.c_int, [_P]),

@@ -241,7 +241,7 @@ struct asm_handle {
     int row_band = 0;
     int *d_rowperm = nullptr, *d_rowpos = nullptr, *d_rowpairs = nullptr, *d_cpos = nullptr;      // position -> row, row -> position, structural pairs (row_i, row_j), pos_i >= pos_j
     int64_t n_rowpairs = 0;
-    std::vector<int> row_perm_h;
+    std::vector<int> row_perm_h, ns_eidx_h;      // host copies: rows by position (all rows; the equality rows of the null-space form)
     int main_band_cur = 0;          // band of the matrix now in the main factor buffers (set by the banded builds, 0 after every other build)
     int main_band = 0;              // band of the matrix in the main factor buffers (test hook asm_test_set_band; 0 = dense)
     int ns_Zk = 0;                  // rows of the orthonormal basis of the previous LP still resident in d_nsG (0: none)
@@ -2605,6 +2605,7 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
                 eidx.swap(e2);
                 for (int q = 0; q < nE; ++q) epos[eidx[q]] = q;
             }
+            h->ns_eidx_h = eidx;
             h->d_nsEidx = ialloc(eidx, nE); h->d_nsEpos = ialloc(epos, h->M); h->d_nsIidx = ialloc(iidx, h->ns_nI); h->d_nsIpos = ialloc(ipos, h->M);
             h->d_nscnt = ialloc({}, 16);
             ns_alloc_factor(h, h->ns_f0, h->ns_nEp);
@@ -3080,6 +3081,16 @@ int asm_sublp_ns_basis(const asm_handle* h, int32_t* J, int64_t* k) {
     const std::vector<int>& v = h->hint[0].ns_J;
     *k = (int64_t)v.size();
     if (J) for (size_t a = 0; a < v.size(); ++a) J[a] = v[a];
+    return ASM_OK;
+}
+
+int asm_sublp_row_order(const asm_handle* h, int32_t* perm, int64_t* band, int32_t* e_rows, int64_t* n_e, int64_t* e_band) {
+    if (!h || !band || !n_e || !e_band) return ASM_ERR_ARG;
+    *band = h->row_band;
+    if (perm && h->row_band > 0) for (int64_t q = 0; q < h->M; ++q) perm[q] = h->row_perm_h[q];
+    *n_e = h->ns_cap ? h->ns_nE : 0;
+    *e_band = h->ns_cap ? h->ns_f0.band : 0;
+    if (e_rows && h->ns_cap) for (int q = 0; q < h->ns_nE; ++q) e_rows[q] = h->ns_eidx_h[q];
     return ASM_OK;
 }
 

@@ -170,6 +170,18 @@ class HipSubOptimizer:
         self._check(self._lib.asm_sublp_ns_basis(self._h, J.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(k)))
         return J[:int(k.value)].astype(np.int64)
 
+    def row_order(self):
+        """(perm, band, e_rows, e_band): the rows by position in the order of the factorisations (None when the natural order is in use), the
+        half-bandwidth, the equality rows of the null-space form in their own order and its band (asm_sublp_row_order)."""
+        band, n_e, e_band = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.asm_sublp_row_order(self._h, None, C.byref(band), None, C.byref(n_e), C.byref(e_band)))
+        d = self.data
+        M = self.m + int(((d.c_lb > -np.inf) & (d.c_ub < np.inf) & (d.c_lb < d.c_ub)).sum())      # one extra <= row per range constraint
+        perm = np.zeros(max(M, 1), np.int32); e = np.zeros(max(int(n_e.value), 1), np.int32)
+        self._check(self._lib.asm_sublp_row_order(self._h, perm.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(band),
+                                                  e.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(n_e), C.byref(e_band)))
+        return (perm[:M].astype(np.int64) if band.value > 0 else None), int(band.value), e[:int(n_e.value)].astype(np.int64), int(e_band.value)
+
     def last_stats(self):
         s = _lib.SolveStats()
         self._check(self._lib.asm_sublp_last_stats(self._h, C.byref(s)))

@@ -102,6 +102,12 @@ int asm_sublp_reset_warm(asm_handle* h);
  * counterpart of a simplex basis (its complement holds a basis of the equality rows).  k = 0 when the form is not in use.
  * J may be NULL to query k. */
 int asm_sublp_ns_basis(const asm_handle* h, int32_t* J, int64_t* k);
+/* Observability of the row order of the factorisations (nothing in the reference; oracle/lp_solver.py: rcm_order, row_order): the M rows
+ * of the internal LP (m constraint rows, then the extra <= rows of the range constraints) by position in the reverse Cuthill-McKee
+ * order of their coupling graph (perm[q] = row at position q; *band = half-bandwidth of their Gram matrix in that order, 0 = natural
+ * order in use and perm untouched) and the hard equality rows of the null-space form in their own order (e_rows, *n_e of them, *e_band;
+ * *n_e = 0 when the form is not available).  perm / e_rows may be NULL. */
+int asm_sublp_row_order(const asm_handle* h, int32_t* perm, int64_t* band, int32_t* e_rows, int64_t* n_e, int64_t* e_band);
 
 /* Statistics of the last solve / accumulated device-kernel timing. */
 typedef struct {

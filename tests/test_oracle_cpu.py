@@ -298,3 +298,38 @@ def test_reduced_active_set_solve_agrees_with_the_full_one():
     p2, _, y2, _ = L.eqp_ns(s, nsp, out['sets'])
     assert np.abs(p1 - p2).max() <= 1e-10 * max(1.0, np.abs(p1).max())
     assert np.abs(y1 - y2).max() <= 1e-9 * max(1.0, np.abs(y1).max())
+
+
+def test_rcm_order_is_a_bandwidth_reducing_permutation():
+    """rcm_order on a shuffled banded pattern and on a grid graph: a permutation, the reported bandwidth is the bandwidth of the
+    permuted pattern, close to the hidden band (shuffled band) and to SciPy's reverse Cuthill-McKee (grid); deterministic; row_order
+    keeps the natural order for dense or small patterns."""
+    import scipy.sparse as sps
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    from oracle import lp_solver as L
+    rng = np.random.default_rng(3)
+    n = 400
+    hid = rng.permutation(n)                              # row i of the hidden banded matrix is stored as row hid[i]
+    cols_of = [None] * n
+    for i in range(n):
+        cols_of[hid[i]] = np.unique(np.clip(np.arange(i - 3, i + 4), 0, n - 1))      # shares columns with hidden neighbours within 6
+    order, bw = L.rcm_order(cols_of)
+    assert sorted(order.tolist()) == list(range(n))
+    pos = np.empty(n, int); pos[order] = np.arange(n)
+    real = max(abs(pos[a] - pos[b]) for a in range(n) for b in range(n) if len(np.intersect1d(cols_of[a], cols_of[b])) > 0)
+    assert real == bw and bw <= 12
+    order2, bw2 = L.rcm_order(cols_of)
+    assert np.array_equal(order, order2) and bw == bw2
+    g = 20                                                 # rows = edges of a 20 x 20 grid graph, columns = its vertices
+    edges = [(r * g + c, r * g + c + 1) for r in range(g) for c in range(g - 1)] + [(r * g + c, (r + 1) * g + c) for r in range(g - 1) for c in range(g)]
+    rows_cols = [np.array(e) for e in edges]
+    order, bw = L.rcm_order(rows_cols)
+    A = sps.csr_matrix((np.ones(2 * len(edges)), (np.repeat(np.arange(len(edges)), 2), np.array(edges).ravel())))
+    S = (A @ A.T).tocsr()
+    ps = reverse_cuthill_mckee(S, symmetric_mode=True)
+    c = S[ps][:, ps].tocoo()
+    assert bw <= 1.5 * np.abs(c.row - c.col).max() and bw < len(edges) // 4
+    assert L.row_order(rows_cols[:100], g * g) is None                                  # fewer than ROW_ORDER_MIN_M rows
+    assert L.row_order([np.arange(50)] * 300, 50) is None                               # dense pattern
+    rp = L.row_order(rows_cols, g * g)
+    assert rp is not None and np.array_equal(np.argsort(rp), order)

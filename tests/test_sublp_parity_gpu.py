@@ -542,3 +542,30 @@ def test_null_space_campaign():
         checked += 1
         opt.close()
     assert checked >= 6
+
+
+def test_row_order_is_the_oracles():
+    """The order the factorisations take rows in is part of the answer in degenerate cases (the pivot guard drops the later of two
+    dependent rows): the library's host code and the oracle compute the same reverse Cuthill-McKee orders and bandwidths - all rows of the
+    internal LP, and the equality rows of the null-space form - on the ACOPF pattern (banded) and on a dense pattern (natural order)."""
+    from activesetmethods_amd import acopf
+    from activesetmethods_amd.subproblem import HipSubOptimizer, QpData
+    from oracle import lp_solver as L, subproblem as OS
+    pr = acopf.acopf_problem(acopf.synthetic_case("case300", 1, 0.5), "case300")
+    sp = _acopf_subproblem(pr, np.asarray(pr.x0, float).copy(), 1000.0)
+    opt = HipSubOptimizer(QpData(sp['df'], sp['f'], sp['dE'], sp['E'], sp['c_lb'], sp['c_ub'], sp['v_lb'], sp['v_ub']), sp['j_row'], sp['j_col'])
+    perm, band, e_rows, e_band = opt.row_order()
+    opt.close()
+    J = OS.compute_jacobian_matrix(pr.m, pr.n, np.asarray(sp['j_row']) - 1, np.asarray(sp['j_col']) - 1, sp['dE'])
+    qp = OS.QpModel(OS.QpData(sp['df'], sp['f'], J[0], sp['E'], sp['c_lb'], sp['c_ub'], sp['v_lb'], sp['v_ub'], J[1]), sp['j_row'], sp['j_col'])
+    assert qp.row_pos is not None and perm is not None
+    assert np.array_equal(np.argsort(qp.row_pos), perm)
+    order_all, bw_all = L.rcm_order(qp.row_cols + [qp.row_cols[v] for v in qp.adj])
+    assert band == bw_all and np.array_equal(order_all, perm) and 0 < band < len(perm) // 2
+    Erows = np.nonzero(qp.rtype == 0)[0]
+    order_e, bw_e = L.rcm_order([qp.row_cols[i] for i in Erows])
+    assert np.array_equal(Erows[order_e], e_rows) and e_band == bw_e and 0 < e_band < len(Erows) // 2
+    spd = random_subproblem(5, 40, 30)                      # dense pattern, small: natural order on both sides
+    opt2, _ = hip_solve(spd)
+    assert opt2.row_order()[0] is None and opt2.row_order()[1] == 0
+    opt2.close()
