@@ -35,11 +35,14 @@ __device__ __forceinline__ double fn_value(const FnStore& F, int64_t r, const do
     return v;
 }
 // eval_constraint + eval_constraint_jacobian of the affine / quadratic rows (MOI_wrapper.jl:875-944): one thread per row
+// (blockIdx.y = trial point of a batched line search: x and E advance by ldx / ldE per trial; the Jacobian is only written for one point)
 __global__ __launch_bounds__(256) void k_fn_rows(FnStore F, const double* __restrict__ x, double* __restrict__ E, double* __restrict__ dE,
-                                                 int write_jac) {
+                                                 int write_jac, int64_t ldx, int64_t ldE) {
 #pragma clang fp contract(off)
     int64_t r = blockIdx.x * 256 + threadIdx.x;
     if (r >= F.n_rows) return;
+    x += blockIdx.y * ldx;
+    E += blockIdx.y * ldE;
     E[r] = fn_value(F, r, x);
     if (!write_jac) return;
     int64_t o = F.jac_off[r];
@@ -52,9 +55,9 @@ __global__ __launch_bounds__(256) void k_fn_rows(FnStore F, const double* __rest
     }
 }
 // eval_objective (one thread: the sum is sequential in the reference) and its sense scale (MOI_wrapper.jl:1046-1049)
-__global__ void k_fn_objective(FnStore F, const double* __restrict__ x, double* __restrict__ f_out) {
+__global__ void k_fn_objective(FnStore F, const double* __restrict__ x, double* __restrict__ f_out, int64_t ldx) {
 #pragma clang fp contract(off)
-    if (threadIdx.x == 0 && blockIdx.x == 0) f_out[0] = F.objective_scale * fn_value(F, F.n_rows, x);
+    if (threadIdx.x == 0) f_out[blockIdx.x] = F.objective_scale * fn_value(F, F.n_rows, x + blockIdx.x * ldx);      // blockIdx.x = trial point
 }
 // fill_gradient! (MOI_wrapper.jl:827-850): one thread per variable sums its contributions in term order
 __global__ __launch_bounds__(256) void k_fn_gradient(FnStore F, const double* __restrict__ x, double* __restrict__ df) {
@@ -73,10 +76,12 @@ __global__ __launch_bounds__(256) void k_fn_gradient(FnStore F, const double* __
 // j0 in 4 groups x 5 sub-blocks of nl (d/d flow variable, vm_f, vm_t, va_f, va_t).
 __global__ __launch_bounds__(256) void k_nlp_acopf_ohm(const int64_t* __restrict__ ipar, const double* __restrict__ dpar,
                                                        const double* __restrict__ x, double* __restrict__ E, double* __restrict__ dE,
-                                                       int64_t r0, int64_t j0, int write_jac) {
+                                                       int64_t r0, int64_t j0, int write_jac, int64_t ldx, int64_t ldE) {
     const int64_t nl = ipar[0];
     int64_t l = blockIdx.x * 256 + threadIdx.x;
     if (l >= nl) return;
+    x += blockIdx.y * ldx;
+    E += blockIdx.y * ldE;
     const int64_t va0 = ipar[1], vm0 = ipar[2], pf0 = ipar[3], pt0 = ipar[4], qf0 = ipar[5], qt0 = ipar[6];
     const int64_t fb = ipar[7 + l], tb = ipar[7 + nl + l];
     const double kffp = dpar[l], kffq = dpar[nl + l], kttp = dpar[2 * nl + l], kttq = dpar[3 * nl + l];
@@ -112,9 +117,12 @@ __global__ __launch_bounds__(256) void k_nlp_acopf_ohm(const int64_t* __restrict
 // ---- NLP block 2: dense quadratic rows  g_i = sum_j A_ij x_j + 1/2 Q_ij x_j^2 ,  J_ij = A_ij + Q_ij x_j  (row-major pattern).
 // dpar: A (m x n) then Q (m x n); one wavefront per row.
 __global__ __launch_bounds__(256) void k_nlp_dense_quadratic(const double* __restrict__ dpar, int64_t mrows, int64_t n, const double* __restrict__ x,
-                                                             double* __restrict__ E, double* __restrict__ dE, int64_t r0, int64_t j0, int write_jac) {
+                                                             double* __restrict__ E, double* __restrict__ dE, int64_t r0, int64_t j0, int write_jac,
+                                                             int64_t ldx, int64_t ldE) {
     int64_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= mrows) return;
+    x += blockIdx.y * ldx;
+    E += blockIdx.y * ldE;
     const int lane = threadIdx.x & 63;
     const double* Ar = dpar + i * n;
     const double* Qr = dpar + mrows * n + i * n;
@@ -131,6 +139,13 @@ __global__ __launch_bounds__(256) void k_nlp_dense_quadratic(const double* __res
 __global__ __launch_bounds__(256) void k_axpy_out(const double* __restrict__ x, double alpha, const double* __restrict__ p, double* __restrict__ out, int64_t n) {
     int64_t j = blockIdx.x * 256 + threadIdx.x;
     if (j < n) out[j] = x[j] + alpha * p[j];
+}
+// the trial points of a batched line search: out[t] = x + alpha[t] p, t = blockIdx.y
+struct TrialAlphas { double a[8]; };
+__global__ __launch_bounds__(256) void k_axpy_trials(const double* __restrict__ x, TrialAlphas al, const double* __restrict__ p, double* __restrict__ out, int64_t n,
+                                                     int64_t ldx) {
+    int64_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j < n) out[blockIdx.y * ldx + j] = x[j] + al.a[blockIdx.y] * p[j];
 }
 
 // ---- per-iteration reductions (one 1024-thread workgroup, fixed order)
@@ -184,9 +199,15 @@ __global__ __launch_bounds__(1024) void k_slp_norms(SlpVecs V, double* __restric
 //   mode 1 (derivative): normal  df . p - nu . viol(E)                  restoration  sum(slacks) - nu . viol(E - viol(E))
 __global__ __launch_bounds__(1024) void k_slp_merit(SlpVecs V, const double* __restrict__ Et, const double* __restrict__ nu, const double* __restrict__ ps,
                                                     const double* __restrict__ p, double alpha, int feasibility, double prim_infeas, const double* __restrict__ f_trial,
-                                                    int mode, double* __restrict__ out) {
+                                                    int mode, double* __restrict__ out, TrialAlphas al, int64_t ldE) {
     __shared__ double sh[16];
     double pen = 0.0, ssum = 0.0, dfp = 0.0;
+    if (gridDim.x > 1) {              // batched line search: one workgroup per trial point
+        alpha = al.a[blockIdx.x];
+        Et += blockIdx.x * ldE;
+        f_trial += blockIdx.x;
+        out += blockIdx.x;
+    }
     for (int64_t i = threadIdx.x; i < V.m; i += 1024) {
         const double lo = V.g_L[i], up = V.g_U[i], e = V.E[i];
         const double viol = fmax(0.0, fmax(e - up, lo - e));

@@ -2907,19 +2907,21 @@ T* ev_upload(asm_handle* h, const T* src, int64_t count) {
     return d;
 }
 // kernels of one evaluation at the point in `xd`: values into Ed (m), objective into fd, optionally gradient / Jacobian values
-void ev_launch(asm_handle* h, const double* xd, double* Ed, double* fd, bool full) {
+// `ntrial` > 1 (values only): the trial points of a batched line search, xd / Ed / fd advancing by ldx / ldE / 1 per point
+void ev_launch(asm_handle* h, const double* xd, double* Ed, double* fd, bool full, int ntrial = 1, int64_t ldx = 0, int64_t ldE = 0) {
     const FnStore& F = h->ev_F;
+    const unsigned nt = (unsigned)ntrial;
     if (F.n_rows > 0)
-        hipLaunchKernelGGL(k_fn_rows, dim3((unsigned)((F.n_rows + 255) / 256)), dim3(256), 0, h->stream, F, xd, Ed, h->d_dE, full ? 1 : 0);
-    hipLaunchKernelGGL(k_fn_objective, dim3(1), dim3(64), 0, h->stream, F, xd, fd);
+        hipLaunchKernelGGL(k_fn_rows, dim3((unsigned)((F.n_rows + 255) / 256), nt), dim3(256), 0, h->stream, F, xd, Ed, h->d_dE, full ? 1 : 0, ldx, ldE);
+    hipLaunchKernelGGL(k_fn_objective, dim3(nt), dim3(64), 0, h->stream, F, xd, fd, ldx);
     if (full) hipLaunchKernelGGL(k_fn_gradient, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, F, xd, h->d_ev_df);
     if (h->ev_nlp_kind == 1) {
         const int64_t nl = h->ev_nlp_rows / 4;
-        hipLaunchKernelGGL(k_nlp_acopf_ohm, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, h->stream, (const int64_t*)h->d_ev_ipar, (const double*)h->d_ev_dpar,
-                           xd, Ed, h->d_dE, F.n_rows, h->ev_fn_nnz, full ? 1 : 0);
+        hipLaunchKernelGGL(k_nlp_acopf_ohm, dim3((unsigned)((nl + 255) / 256), nt), dim3(256), 0, h->stream, (const int64_t*)h->d_ev_ipar, (const double*)h->d_ev_dpar,
+                           xd, Ed, h->d_dE, F.n_rows, h->ev_fn_nnz, full ? 1 : 0, ldx, ldE);
     } else if (h->ev_nlp_kind == 2) {
-        hipLaunchKernelGGL(k_nlp_dense_quadratic, dim3((unsigned)((h->ev_nlp_rows + 3) / 4)), dim3(256), 0, h->stream, (const double*)h->d_ev_dpar,
-                           h->ev_nlp_rows, h->n, xd, Ed, h->d_dE, F.n_rows, h->ev_fn_nnz, full ? 1 : 0);
+        hipLaunchKernelGGL(k_nlp_dense_quadratic, dim3((unsigned)((h->ev_nlp_rows + 3) / 4), nt), dim3(256), 0, h->stream, (const double*)h->d_ev_dpar,
+                           h->ev_nlp_rows, h->n, xd, Ed, h->d_dE, F.n_rows, h->ev_fn_nnz, full ? 1 : 0, ldx, ldE);
     }
 }
 SlpVecs ev_vecs(asm_handle* h, const double* lam, const double* mU, const double* mL, const double* jtl, const double* rown) {
@@ -3190,7 +3192,8 @@ int asm_eval_setup(asm_handle* h, int64_t n_rows, const int64_t* aff_ptr, const 
         const int64_t n = h->n, m = std::max<int64_t>(h->m, 1);
         auto dalloc = [&](int64_t cnt) { double* d = nullptr; HIPCHK(hipMalloc((void**)&d, std::max<int64_t>(cnt, 1) * sizeof(double))); h->ev_bufs.push_back((void*)d);
                                           HIPCHK(hipMemset(d, 0, std::max<int64_t>(cnt, 1) * sizeof(double))); return d; };
-        h->d_ev_x = dalloc(n); h->d_ev_xt = dalloc(n); h->d_ev_df = dalloc(n); h->d_ev_E = dalloc(m); h->d_ev_Et = dalloc(m); h->d_ev_f = dalloc(8);
+        h->d_ev_x = dalloc(n); h->d_ev_xt = dalloc(8 * round_up(n, 32)); h->d_ev_df = dalloc(n); h->d_ev_E = dalloc(m); h->d_ev_Et = dalloc(8 * round_up(std::max<int64_t>(m, 1), 32));
+        h->d_ev_f = dalloc(16);      // xt / Et / f[1..8]: eight trial points of the batched line search
         // bounds for the reductions + staging area: [g_L, g_U, x_L, x_U | lam, mU, mL, nu, ps(2m), p, jtl(ldn), rown(Mp), out(8)]
         h->d_ev_vecs = dalloc(2 * m + 2 * n + 2 * m + 2 * n + 2 * m + n + h->ldn + h->Mp + 16);
         HIPCHK(hipMemcpy(h->d_ev_vecs, h->c_lb.data(), h->m * sizeof(double), hipMemcpyHostToDevice));
@@ -3307,7 +3310,7 @@ int asm_slp_merit(asm_handle* h, int mode, double alpha, const double* p, const 
             ft = h->d_ev_f + 1;
         }
         hipLaunchKernelGGL(k_slp_merit, dim3(1), dim3(1024), 0, h->stream, ev_vecs(h, nullptr, nullptr, nullptr, nullptr, nullptr), Et, (const double*)nud,
-                           (const double*)psd, (const double*)pd, alpha, feasibility, prim_infeas, ft, mode, outd);
+                           (const double*)psd, (const double*)pd, alpha, feasibility, prim_infeas, ft, mode, outd, TrialAlphas(), (int64_t)0);
         HIPCHK(hipMemcpyAsync(st, outd, sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         *out = st[0];
@@ -3337,14 +3340,14 @@ int asm_slp_line_search(asm_handle* h, const double* p, const double* nu, const 
         int trials = 0;
         *ok_out = -1;
         while (*ok_out < 0) {
-            for (int t = 0; t < CH; ++t) {
-                a[t] = alpha;
-                hipLaunchKernelGGL(k_axpy_out, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->d_ev_x, alpha, (const double*)pd, h->d_ev_xt, n);
-                ev_launch(h, h->d_ev_xt, h->d_ev_Et, h->d_ev_f + 1, false);
-                hipLaunchKernelGGL(k_slp_merit, dim3(1), dim3(1024), 0, h->stream, V, (const double*)h->d_ev_Et, (const double*)nud, (const double*)psd, (const double*)pd, alpha,
-                                   feasibility, prim_infeas, (const double*)(h->d_ev_f + 1), 0, outd + t);
-                alpha *= tau;
-            }
+            // eight trial points per set of launches (trial index in the grid): x + alpha_t p, the function values there, the merit values
+            TrialAlphas al;
+            for (int t = 0; t < CH; ++t) { a[t] = al.a[t] = alpha; alpha *= tau; }
+            const int64_t ldx = round_up(n, 32), ldE = round_up(std::max<int64_t>(m, 1), 32);
+            hipLaunchKernelGGL(k_axpy_trials, dim3((unsigned)((n + 255) / 256), CH), dim3(256), 0, h->stream, (const double*)h->d_ev_x, al, (const double*)pd, h->d_ev_xt, n, ldx);
+            ev_launch(h, h->d_ev_xt, h->d_ev_Et, h->d_ev_f + 1, false, CH, ldx, ldE);
+            hipLaunchKernelGGL(k_slp_merit, dim3(CH), dim3(1024), 0, h->stream, V, (const double*)h->d_ev_Et, (const double*)nud, (const double*)psd, (const double*)pd, 0.0,
+                               feasibility, prim_infeas, (const double*)(h->d_ev_f + 1), 0, outd, al, ldE);
             HIPCHK(hipMemcpyAsync(st, outd, CH * sizeof(double), hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
             for (int t = 0; t < CH && *ok_out < 0; ++t) {

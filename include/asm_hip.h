@@ -187,7 +187,8 @@ int asm_slp_merit(asm_handle* h, int mode, double alpha, const double* p, const 
                   int feasibility, double prim_infeas, double* out);
 
 /* compute_alpha (slp_line_search.jl:222-244): backtracking alpha = 1, tau, tau^2, ... on the merit function, the trial points evaluated on
- * the device eight at a time (same alpha and merit values as one asm_slp_merit call per trial).  *ok = 1: Armijo test passed at *alpha;
+ * the device eight at a time - one set of launches with the trial index in the grid (same alpha and merit values as one asm_slp_merit call per
+ * trial).  *ok = 1: Armijo test passed at *alpha;
  * *ok = 0: alpha fell below min_alpha with the test still failing (*alpha is that last trial, as the reference leaves it). */
 int asm_slp_line_search(asm_handle* h, const double* p, const double* nu, const double* p_slack, int feasibility, double prim_infeas, double phi0,
                         double D, double eta, double tau, double min_alpha, double* alpha, double* phi_alpha, int* trials, int* ok);
