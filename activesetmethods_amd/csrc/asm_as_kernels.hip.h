@@ -102,6 +102,12 @@ __global__ __launch_bounds__(256) void k_as_sl(AsPtrs A) {
     A.sl[i] = a;
 }
 
+// s = max(src, slo)
+__global__ __launch_bounds__(256) void k_as_smax(const double* __restrict__ src, const double* __restrict__ slo, double* __restrict__ dst, int64_t ns) {
+    int64_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k < ns) dst[k] = fmax(src[k], slo[k]);
+}
+
 // Everything an equality-constrained solve derives from its working set: soft rows and their known multiplier, the ordered
 // lists of hard rows and free variables with their inverse maps and masks, the bound-active part of p.  One workgroup.
 __global__ __launch_bounds__(1024) void k_as_setup(AsPtrs A, AsSets S, const double* __restrict__ p_ref, int64_t ldn, int64_t ldT) {

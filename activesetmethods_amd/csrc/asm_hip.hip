@@ -53,6 +53,7 @@ const double RED_TAU = 100.0, RED_MIN_FRAC = 0.1;
 const int NS_MIN_E = 64;
 const double NS_MAX_RATIO = 0.3, NS_WARM_THR = 1e-6, NS_ZWARM_THR = 0.25, NS_BIG = 0.5e128, NS_RERR = 1e-6;
 const int NS_CMAX = 2;
+const double IPM_ACCEPT = 1e-10;
 const int NS_MAX_SPLIT = 8;
 const double NS_SEL_THR[4] = {1e-2, 1e-4, 1e-7, 1e-10};
 const int PCG_MAXIT = 20;       // conjugate-gradient steps per Newton solve (preconditioner = the Cholesky factor)
@@ -2307,6 +2308,20 @@ struct Solver {
                 as_copy_sets(0, 3);
                 if (eqp_loop(d_zero, nullptr, 2)) { h->stats.path = 3; return ASM_OPTIMAL; }
             }
+        }
+        // last resort (oracle: solve_scaled, 'ipm-conv'): an iterate converged to IPM_ACCEPT in all three measures is an optimal point of the
+        // LP to that accuracy; it is handed out through the active-set arena (clipped into the box, partition of the last identification)
+        if (have_sets && ip.pinf <= IPM_ACCEPT && ip.dinf <= IPM_ACCEPT && ip.gap <= IPM_ACCEPT) {
+            hipLaunchKernelGGL(k_as_clip0, dim3((unsigned)((lp.n + 255) / 256)), dim3(256), 0, h->stream, A.lb, A.ub, (const double*)P.p, A.p, lp.n);
+            dcopy(A.y, P.y, lp.M);
+            if (lp.ns) hipLaunchKernelGGL(k_as_smax, dim3((unsigned)((lp.ns + 255) / 256)), dim3(256), 0, h->stream, (const double*)P.s, A.slo, A.s, lp.ns);
+            dev.gemv_n_dev(h->d_Ah, A.p, A.t);
+            dev.gemv_t_dev(h->d_Ah, A.y, A.tN);
+            hipLaunchKernelGGL(k_as_finish, dim3(1), dim3(1024), 0, h->stream, A, S_[3], S_[1], S_[2], 0, TOL_P, TOL_D);
+            as_read();
+            final_sets = 3;
+            h->stats.path = 10;
+            return ASM_OPTIMAL;
         }
         // no active-set solve passed the LP optimality test: the interior iterate is not returned as a solution
         // (status OTHER; the SLP caller stops with a warning, slp_line_search.jl:127-133)

@@ -486,7 +486,7 @@ def main():
             out["kernels_ms"] = {k: round(v["ms"], 3) for k, v in ks.items()}
         timed = trace[-args.steps:] if trace else []
         names = {0: "warm", 1: "ipm0+ln", 2: "ipm1+ln", 3: "ipm2+ln", 4: "ipm+face", 5: "ipm-unpolished", 6: "ipm-infeasible",
-                 7: "phase1-infeasible", 8: "ipm~+ln", 9: "ipm+ref"}
+                 7: "phase1-infeasible", 8: "ipm~+ln", 9: "ipm+ref", 10: "ipm-conv"}
         hist = {}
         for r in timed:
             key = names.get(r["stats"]["path"], str(r["stats"]["path"])) + ("/fr" if r["fr"] else "")
@@ -503,7 +503,7 @@ def main():
             "null_space_dimension": max([r["stats"].get("ns_dim", 0) for r in timed], default=0),
             "factorisations_per_lp_all_sizes": _mean([r["stats"]["nfact"] for r in timed])}
         out["lp_outcomes"] = {"paths": hist, "unpolished": sum(1 for r in timed if r["stats"]["polished"] != 1),
-                              "non_canonical_answers": sum(1 for r in timed if r["stats"]["path"] == 9),     # 'ipm+ref': projection of the iterate
+                              "non_canonical_answers": sum(1 for r in timed if r["stats"]["path"] in (9, 10)),     # 'ipm+ref': projection of the iterate; 'ipm-conv': the converged iterate itself
                               "status_other": sum(1 for r in timed if r["status"] not in (1, 2)),
                               "restoration_lps": sum(1 for r in timed if r["fr"]),
                               "slp_status_last": int(state["slp"].ret) if state.get("slp") is not None else None,

@@ -113,7 +113,8 @@ int asm_sublp_row_order(const asm_handle* h, int32_t* perm, int64_t* band, int32
 typedef struct {
     int32_t path;          /* 0 warm, 1 ipm stage0+polish, 2 stage1, 3 stage2, 4 ipm+face (non-unique optimum: least-norm point of the optimal
                             * face + basic multipliers), 5 unpolished (status OTHER), 6 infeasible (IPM duals), 7 infeasible (phase-1 duals),
-                            * 8 jammed ipm + polish, 9 ipm+ref (non-unique optimum, projection of the iterate: fallback of 4) */
+                            * 8 jammed ipm + polish, 9 ipm+ref (non-unique optimum, projection of the iterate: fallback of 4),
+                            * 10 ipm-conv (no active-set solve passed its test, the iterate converged to 1e-10 in all measures is the answer) */
     int32_t polished;
     int32_t ipm_iters;
     int32_t nfact;         /* Cholesky factorisations */

@@ -62,6 +62,7 @@ NS_SEL_THR = (1e-2, 1e-4, 1e-7, 1e-10)    # for re-using the previous LP's basis
 NS_WARM_THR = 1e-6
 NS_RERR = 1e-6        # relative residual of a reduced solve beyond which the LP returns to the row form; smallest Gram pivot for
 NS_ZWARM_THR = 0.25   # re-using the previous LP's basis
+IPM_ACCEPT = 1e-10    # an iterate this converged is returned when no active-set solve confirms a partition (solve_scaled)
 NS_CMAX = 2           # reduced active-set solve: at most NS_CMAX * k active bounds + inequality rows, else the attempt is abandoned
 CHOL_NB = 64
 PIV_BIG = 1e128
@@ -1452,6 +1453,12 @@ def solve_scaled(lp, warm=None, stats=None, hint=None):
             if ok:
                 stats['path'] = 'ipm%d+ln' % (len(IPM_STAGES) - 1)
                 return OPTIMAL, p, s, y, sets
+    # last resort before giving up: an iterate converged to IPM_ACCEPT in all three measures IS an optimal point of the LP to that
+    # accuracy (near-degenerate vertices can leave every active-set solve 1e-6 short of its own test): it is returned as it stands,
+    # bound-active components snapped by the identified partition - not a canonical answer ('ipm-conv', counted like 'ipm+ref')
+    if sets0 is not None and max(ip.log[-1][1:]) <= IPM_ACCEPT:
+        stats['path'] = 'ipm-conv'
+        return OPTIMAL, np.clip(ip.p, lp.lb, lp.ub), np.maximum(ip.s, lp.slo), ip.y, sets0
     stats['path'] = 'ipm-unpolished'
     stats['polished'] = 0
     if sets0 is None:

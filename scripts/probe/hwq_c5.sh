@@ -1,6 +1,7 @@
-for cfg in "16 4" "16 8" "8 4" "4 4"; do
+# C5 throughput against the number of HIP hardware queues and of scenario streams per GPU
+for cfg in "4 4" "6 4" "8 4" "8 4" "8 5" "8 6" "12 4" "12 6"; do
   set -- $cfg
-  GPU_MAX_HW_QUEUES=$1 python bench.py --workload c5 --steps 24 --concurrency $2 --no-cpu-baseline > gpurun_out/hwq_$1_$2.log 2>&1
+  GPU_MAX_HW_QUEUES=$1 python bench.py --workload c5 --steps 48 --concurrency $2 --no-cpu-baseline > gpurun_out/hwq_$1_$2.log 2>&1
   python - <<PY
 import json
 for l in open("gpurun_out/hwq_$1_$2.log"):

@@ -162,7 +162,7 @@ def test_restoration_sequence_does_not_drift():
     mo, so = _oracle_run(pr, algorithm="Trust Region", max_iter=12)
     assert len(sh.trace) == len(so.trace) and sum(1 for r in so.trace if r['fr']) >= 10
     names = {0: 'warm', 1: 'ipm0+ln', 2: 'ipm1+ln', 3: 'ipm2+ln', 4: 'ipm+face', 5: 'ipm-unpolished', 6: 'ipm-infeasible', 7: 'phase1-infeasible',
-             8: 'ipm~+ln', 9: 'ipm+ref'}
+             8: 'ipm~+ln', 9: 'ipm+ref', 10: 'ipm-conv'}
     assert [names[r['stats']['path']] for r in sh.trace] == [r['stats']['path'] for r in so.trace]
     assert all(r['stats']['path'] != 'ipm+ref' for r in so.trace)
     _compare_traces(so, sh)
@@ -250,7 +250,7 @@ def test_case300_sized_lp_parity_normal_and_restoration():
     base = dict(n=pr.n, m=pr.m, j_row=pr.j_row, j_col=pr.j_col, dE=pr.eval_jac_g(x, np.zeros(pr.nnz)), df=pr.eval_grad_f(x, np.zeros(pr.n)),
                 f=pr.eval_f(x), E=pr.eval_g(x, np.zeros(pr.m)), x_k=x, c_lb=pr.g_L, c_ub=pr.g_U, v_lb=pr.x_L, v_ub=pr.x_U)
     names = {0: 'warm', 1: 'ipm0+ln', 2: 'ipm1+ln', 3: 'ipm2+ln', 4: 'ipm+face', 5: 'ipm-unpolished', 6: 'ipm-infeasible', 7: 'phase1-infeasible',
-             8: 'ipm~+ln', 9: 'ipm+ref'}
+             8: 'ipm~+ln', 9: 'ipm+ref', 10: 'ipm-conv'}
     # normal phase, Line-Search radius
     sp = dict(base, delta=1000.0)
     qp, o_out = oracle_solve(sp)
@@ -301,3 +301,32 @@ def test_case300_scenario_batch_all_converge():
     assert all(s.ret == 0 for s in slps)
     assert all(r['status'] in (1, 2) and r['stats']['polished'] == 1 for s in slps for r in s.trace)
     assert stats["inf_pr"] <= 0.01 and stats["inf_du"] <= 0.01
+
+
+def test_converged_iterate_last_resort_scenario_27():
+    """case300-sized scenario 27 (the one of the first 64 scenarios of the C5 batch that used to stop with an unpolished LP): at LP 51
+    the interior-point iterate converges to 1e-13 in all three measures, but the vertex is so nearly degenerate that every active-set solve
+    misses its own primal test by ~1e-6.  The converged iterate is then the answer ('ipm-conv', path 10: counted as non-canonical), the
+    run goes on and terminates with status 0.  The oracle takes the same path on that LP and agrees on the step."""
+    import activesetmethods_amd as A
+    from activesetmethods_amd import acopf
+    from tests.util import oracle_solve, rel_err
+    base = acopf.synthetic_case("case300", 1, 0.5)
+    case = acopf.scenario_case(base, 27)
+    pr = acopf.acopf_problem(case, "case300-sized scenario 27")                       # host callbacks: to rebuild the LP for the oracle
+    prd = acopf.function_model(case).to_problem("case300-sized scenario 27")          # the batch's own model (device evaluator)
+    slp = A.optimize(A.Model.from_problem(prd, A.Parameters(algorithm="Line Search", max_iter=200, device_eval=True)))
+    slp.optimizer.close()
+    assert slp.ret == 0
+    assert all(r['status'] == 1 for r in slp.trace)
+    conv = [k for k, r in enumerate(slp.trace) if r['stats']['path'] == 10]
+    assert 1 <= len(conv) <= 2 and all(r['stats']['path'] in (0, 1, 2, 3, 4, 10) for r in slp.trace), [r['stats']['path'] for r in slp.trace]
+    for k in conv[:1]:
+        rec = slp.trace[k]
+        x = rec['x']
+        sp = dict(n=pr.n, m=pr.m, j_row=pr.j_row, j_col=pr.j_col, dE=pr.eval_jac_g(x, np.zeros(pr.nnz)), df=pr.eval_grad_f(x, np.zeros(pr.n)),
+                  f=pr.eval_f(x), E=pr.eval_g(x, np.zeros(pr.m)), x_k=x.copy(), c_lb=pr.g_L, c_ub=pr.g_U, v_lb=pr.x_L, v_ub=pr.x_U, delta=rec['delta'])
+        qp, o_out = oracle_solve(sp)
+        assert o_out[5] == 1 and o_out[6]['stats']['path'] == 'ipm-conv', o_out[6]['stats']
+        assert abs(sp['df'] @ (o_out[0] - rec['p'])) <= 1e-8 * max(1.0, abs(sp['df'] @ rec['p']))
+        assert rel_err(rec['p'], o_out[0]) < 1e-6

@@ -74,7 +74,7 @@ def test_warm_sequence_matches():
 
 
 PATH_NAMES = {0: 'warm', 1: 'ipm0+ln', 2: 'ipm1+ln', 3: 'ipm2+ln', 4: 'ipm+face', 5: 'ipm-unpolished', 6: 'ipm-infeasible',
-              7: 'phase1-infeasible', 8: 'ipm~+ln', 9: 'ipm+ref'}
+              7: 'phase1-infeasible', 8: 'ipm~+ln', 9: 'ipm+ref', 10: 'ipm-conv'}
 
 
 @pytest.mark.parametrize("seed,n,m,density,dup,nrange", [(41, 600, 380, 0.012, 0.2, 5), (42, 900, 700, 0.006, 0.0, 8)])
