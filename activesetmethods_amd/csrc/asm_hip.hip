@@ -53,6 +53,7 @@ const double RED_TAU = 100.0, RED_MIN_FRAC = 0.1;
 const int NS_MIN_E = 64;
 const double NS_MAX_RATIO = 0.3, NS_WARM_THR = 1e-6, NS_ZWARM_THR = 0.25, NS_BIG = 0.5e128, NS_RERR = 1e-6;
 const int NS_CMAX = 2;
+const int64_t RCM_MAX_PAIRS = 50000000;      // sum over the columns of (rows in the column)^2 beyond which no row order is computed
 const double IPM_ACCEPT = 1e-10;
 const int NS_MAX_SPLIT = 8;
 const double NS_SEL_THR[4] = {1e-2, 1e-4, 1e-7, 1e-10};
@@ -118,6 +119,18 @@ static std::vector<int> rcm_order(const std::vector<int>& rows, const std::vecto
     std::vector<std::vector<int>> col_rows((size_t)ncols);
     for (int i = 0; i < nR; ++i)
         for (int k = sp_ptr[rows[i]]; k < sp_ptr[rows[i] + 1]; ++k) col_rows[sp_col[k]].push_back(i);
+    // a column shared by very many rows makes the coupling graph (and its Gram matrix) dense: no order then (oracle: RCM_MAX_PAIRS)
+    {
+        int64_t npair = 0;
+        for (const auto& v : col_rows) npair += (int64_t)v.size() * (int64_t)v.size();
+        if (npair > RCM_MAX_PAIRS) {
+            std::vector<int> id(nR);
+            for (int i = 0; i < nR; ++i) id[i] = i;
+            if (bandwidth) *bandwidth = nR;
+            if (pairs) pairs->clear();
+            return id;
+        }
+    }
     std::vector<std::vector<int>> nbr((size_t)nR);
     for (int i = 0; i < nR; ++i) {
         std::vector<int>& v = nbr[i];

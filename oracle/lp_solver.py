@@ -203,6 +203,8 @@ def rcm_order(row_cols):
     for i, cs in enumerate(row_cols):
         for c in cs:
             col_rows.setdefault(int(c), []).append(i)
+    if sum(len(v) * len(v) for v in col_rows.values()) > RCM_MAX_PAIRS:      # a column shared by very many rows: dense coupling graph
+        return np.arange(nR, dtype=np.int64), nR
     nbr = []
     for i, cs in enumerate(row_cols):
         v = set()
@@ -236,6 +238,7 @@ def rcm_order(row_cols):
 
 
 ROW_ORDER_MIN_M = 256
+RCM_MAX_PAIRS = 50000000   # sum over the columns of (rows in the column)^2 beyond which no order is computed (natural order, bandwidth = #rows)
 
 
 def row_order(row_cols, n):
