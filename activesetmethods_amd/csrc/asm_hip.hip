@@ -450,7 +450,7 @@ struct Dev {
         }
         if (const double* v = sparse_vals(A)) {
             int id = begin(ASM_K_GEMV, 2.0 * h->sp_nnz, 24.0 * h->sp_nnz + 12.0 * h->n);
-            hipLaunchKernelGGL(k_spmv_t, dim3((unsigned)((h->ldn + 255) / 256)), dim3(256), 0, h->stream, h->d_sc_ptr, h->d_sc_row, h->d_sc_pos, v,
+            hipLaunchKernelGGL(k_spmv_t, dim3((unsigned)((h->ldn * 8 + 255) / 256)), dim3(256), 0, h->stream, h->d_sc_ptr, h->d_sc_row, h->d_sc_pos, v,
                                y, out, h->n, h->ldn);
             end(id);
             return;
