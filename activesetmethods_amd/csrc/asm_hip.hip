@@ -257,6 +257,8 @@ struct asm_handle {
     int64_t n_rowpairs = 0;
     std::vector<int> row_perm_h, ns_eidx_h;      // host copies: rows by position (all rows; the equality rows of the null-space form)
     int main_band_cur = 0;          // band of the matrix now in the main factor buffers (set by the banded builds, 0 after every other build)
+    double* d_redpart = nullptr;    // partial results / arrival counter of the multi-workgroup interior-point reductions
+    unsigned* d_redcnt = nullptr;
     int main_band = 0;              // band of the matrix in the main factor buffers (test hook asm_test_set_band; 0 = dense)
     int ns_Zk = 0;                  // rows of the orthonormal basis of the previous LP still resident in d_nsG (0: none)
     int *d_nsqi = nullptr;          // sel | bpos | rpos | cnt
@@ -948,6 +950,8 @@ struct SLP {
 };
 
 struct Solver {
+    // workgroups of the interior-point reductions (k_ipm_measures / _steps / _muaff): 1024 elements per workgroup and sweep, at most IPM_RED_MAXWG
+    unsigned red_grid() const { return (unsigned)std::min<int64_t>(IPM_RED_MAXWG, std::max<int64_t>(1, (std::max(std::max(lp.n, lp.M), lp.ns) + 4095) / 4096)); }
     static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     asm_handle* h;
     Dev dev;
@@ -1015,6 +1019,7 @@ struct Solver {
         dirA.ds = Sv(); dirA.dmus = Sv(); dirC.ds = Sv(); dirC.dmus = Sv();
         P.scal = a;
         P.hscal = h->d_hscal; P.hseq = h->d_hseq;
+        P.rpart = h->d_redpart; P.rcnt = h->d_redcnt;
         P.rtype = h->d_ipm_i; P.rs0 = h->d_ipm_i + lm; P.rs1 = h->d_ipm_i + 2 * lm; P.srow = h->d_ipm_i + 3 * lm;
     }
     void up(const double* dst, const vec& v) {
@@ -1093,11 +1098,11 @@ struct Solver {
         const unsigned pub = pub_next();
         if (ns_live()) {
             // null-space form: the equality rows' multipliers are carried as 0, the dual residual that counts is Z'rdp (oracle: IPM.measures)
-            hipLaunchKernelGGL(k_ipm_measures, dim3(1), dim3(1024), 0, h->stream, P, 0u);
+            hipLaunchKernelGGL(k_ipm_measures, dim3(red_grid()), dim3(1024), 0, h->stream, P, 0u);
             hipLaunchKernelGGL(k_gemv_n, dim3((unsigned)((ip.ns_k + 3) / 4)), dim3(256), 0, h->stream, (const double*)h->d_nsG, h->ns_ldg, (const double*)P.rdp, nsv(12), (int64_t)ip.ns_k, h->ldn);
             hipLaunchKernelGGL(k_ns_dinf, dim3(1), dim3(1024), 0, h->stream, P, (const double*)nsv(12), ip.ns_k, pub);
         } else {
-            hipLaunchKernelGGL(k_ipm_measures, dim3(1), dim3(1024), 0, h->stream, P, pub);
+            hipLaunchKernelGGL(k_ipm_measures, dim3(red_grid()), dim3(1024), 0, h->stream, P, pub);
         }
         read_scal(pub);
         ip.pinf = h->h_scal[SC_PINF];
@@ -1751,11 +1756,11 @@ struct Solver {
             cg_max = 0;
             cg_fail = false;
             if (use_ns) ns_newton(0, dirA, dirA); else ipm_solve(0, dirA, dirA);
-            hipLaunchKernelGGL(k_ipm_steps, dim3(1), dim3(1024), 0, h->stream, P, dirA, 0u);
-            hipLaunchKernelGGL(k_ipm_muaff, dim3(1), dim3(1024), 0, h->stream, P, dirA);
+            hipLaunchKernelGGL(k_ipm_steps, dim3(red_grid()), dim3(1024), 0, h->stream, P, dirA, 0u);
+            hipLaunchKernelGGL(k_ipm_muaff, dim3(red_grid()), dim3(1024), 0, h->stream, P, dirA);
             if (use_ns) ns_newton(1, dirA, dirC); else ipm_solve(1, dirA, dirC);
             unsigned pub = pub_next();
-            hipLaunchKernelGGL(k_ipm_steps, dim3(1), dim3(1024), 0, h->stream, P, dirC, pub);
+            hipLaunchKernelGGL(k_ipm_steps, dim3(red_grid()), dim3(1024), 0, h->stream, P, dirC, pub);
             read_scal(pub);
             double ap = h->h_scal[SC_AP], ad = h->h_scal[SC_AD];
             // Gondzio multiple centrality correctors (oracle: IPM.run): dirA is free again and receives the candidate
@@ -1765,7 +1770,7 @@ struct Solver {
                 ipm_solve(2, dirC, dirA, tp, td);
                 hipLaunchKernelGGL(k_ipm_diradd, dim3(grid_all()), dim3(256), 0, h->stream, P, dirA, dirC);
                 pub = pub_next();
-                hipLaunchKernelGGL(k_ipm_steps, dim3(1), dim3(1024), 0, h->stream, P, dirA, pub);
+                hipLaunchKernelGGL(k_ipm_steps, dim3(red_grid()), dim3(1024), 0, h->stream, P, dirA, pub);
                 read_scal(pub);
                 const double ap2 = h->h_scal[SC_AP], ad2 = h->h_scal[SC_AD];
                 if (!(ap2 >= ap && ad2 >= ad && ap2 + ad2 >= ap + ad + MCC_GAMMA * MCC_DELTA)) break;
@@ -2364,6 +2369,7 @@ void free_device(asm_handle* h) {
     h->d_Binv = h->d_wpart = h->d_BinvT = h->d_wt = nullptr; F(h->d_ipm); F(h->d_ipm_i); F(h->d_nz);
     h->d_nz = nullptr; h->nz_valid = false; h->nz_frac_cache[0] = h->nz_frac_cache[1] = -1.0;
     F(h->d_idxI); F(h->d_rdI); F(h->d_rce); F(h->d_rze); F(h->d_sdiag);
+    F(h->d_redpart); F(h->d_redcnt); h->d_redpart = nullptr; h->d_redcnt = nullptr;
     h->d_idxI = nullptr; h->d_rdI = h->d_rce = h->d_rze = h->d_sdiag = nullptr;
     F(h->d_AhT); F(h->d_cdinv); F(h->d_cth); F(h->d_cu); F(h->d_ct); F(h->d_cv); F(h->d_cw); F(h->d_nzT);
     h->d_AhT = h->d_cdinv = h->d_cth = h->d_cu = h->d_ct = h->d_cv = h->d_cw = nullptr; h->d_nzT = nullptr;
@@ -2581,6 +2587,9 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
             iv[3 * h->Mp + k] = r_;
         }
         HIPCHK(hipMemcpy(h->d_ipm_i, iv.data(), iv.size() * sizeof(int), hipMemcpyHostToDevice));
+        dmalloc(&h->d_redpart, IPM_RED_MAXWG * IPM_RED_SLOTS);
+        dmalloc(&h->d_redcnt, 4);
+        HIPCHK(hipMemsetAsync(h->d_redcnt, 0, 4 * sizeof(unsigned), h->stream));
         HIPCHK(hipHostMalloc((void**)&h->h_scal, 64 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
         HIPCHK(hipHostMalloc((void**)&h->h_seq, 64, hipHostMallocMapped | hipHostMallocCoherent));
         HIPCHK(hipHostGetDevicePointer((void**)&h->d_hscal, h->h_scal, 0));

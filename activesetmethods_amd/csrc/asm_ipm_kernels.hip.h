@@ -17,6 +17,8 @@ struct IpmPtrs {
     double* scal;                             // device scalars, see enum below
     double* hscal;                            // the same block in host-mapped pinned memory (written by scal_publish, read by the host)
     unsigned* hseq;                           // its sequence word (host-mapped): the host spins on it instead of copy + stream synchronise
+    double* rpart;                            // partial results of the multi-workgroup reductions (IPM_RED_SLOTS per workgroup)
+    unsigned* rcnt;                           // their arrival counter (0 between launches)
     int64_t n, M, ns, ncomp;
     double scale_q;
 };
@@ -68,6 +70,31 @@ __device__ __forceinline__ double blk_reduce_min(double v, double* sh) {
     __syncthreads();
     return out;
 }
+
+// Reductions over O(M + n) elements that the host (or the next kernel) needs as scalars: several workgroups reduce their share, store
+// IPM_RED_SLOTS partial values each (agent-scope stores: visible across the XCDs' L2s) and count themselves in; the last one to arrive
+// combines the partials IN WORKGROUP ORDER (sums stay deterministic), writes the scalars and publishes them.  One workgroup: as before.
+#define IPM_RED_SLOTS 8
+#define IPM_RED_MAXWG 64
+__device__ __forceinline__ void red_store(const IpmPtrs& P, int slot, double v) {
+    __hip_atomic_store(P.rpart + (int64_t)blockIdx.x * IPM_RED_SLOTS + slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double red_load(const IpmPtrs& P, int wg, int slot) {
+    return __hip_atomic_load(P.rpart + (int64_t)wg * IPM_RED_SLOTS + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// true in every thread of the workgroup that arrives last (all others are done with this launch); called by all threads
+__device__ __forceinline__ bool red_last_arrival(const IpmPtrs& P, bool* sh_flag) {
+    if (gridDim.x == 1) return true;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned t = __hip_atomic_fetch_add(P.rcnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        *sh_flag = (t == gridDim.x - 1);
+        if (*sh_flag) __hip_atomic_store(P.rcnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return *sh_flag;
+}
 __device__ __forceinline__ double blk_reduce_sum(double v, double* sh) {
     v = wave_sum(v);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
@@ -94,8 +121,10 @@ __device__ __forceinline__ double slack_sum(const IpmPtrs& P, int64_t i, const d
 // residuals + convergence measures; act = Ah p and aty = Ah' y were produced by the gemv kernels
 __global__ __launch_bounds__(1024) void k_ipm_measures(IpmPtrs P, unsigned pub) {
     __shared__ double sh[16];
+    __shared__ bool last;
     double pinf = 0.0, dinf = 0.0, mu = 0.0, ymax = 0.0, rpmax = 0.0;
-    for (int64_t i = threadIdx.x; i < P.M; i += 1024) {
+    const int64_t t0 = (int64_t)blockIdx.x * 1024 + threadIdx.x, stride = (int64_t)gridDim.x * 1024;
+    for (int64_t i = t0; i < P.M; i += stride) {
         bool ineq = P.rtype[i] != 0;
         double sg = (double)P.rtype[i];
         double a = P.act[i] + (P.ns ? slack_sum(P, i, P.s) : 0.0);
@@ -106,14 +135,14 @@ __global__ __launch_bounds__(1024) void k_ipm_measures(IpmPtrs P, unsigned pub) 
         if (ineq) mu += P.g[i] * P.pi[i];
         ymax = fmax(ymax, fabs(P.y[i]));
     }
-    for (int64_t j = threadIdx.x; j < P.n; j += 1024) {
+    for (int64_t j = t0; j < P.n; j += stride) {
         bool fr = P.ub[j] > P.lb[j];
         double rd = fr ? P.q[j] - P.aty[j] - P.muL[j] + P.muU[j] : 0.0;
         P.rdp[j] = rd;
         dinf = fmax(dinf, fabs(rd));
         if (fr) mu += P.tL[j] * P.muL[j] + P.tU[j] * P.muU[j];
     }
-    for (int64_t k = threadIdx.x; k < P.ns; k += 1024) {
+    for (int64_t k = t0; k < P.ns; k += stride) {
         double rd = P.w[k] - P.scoef[k] * P.y[P.srow[k]] - P.mus[k];
         P.rds[k] = rd;
         dinf = fmax(dinf, fabs(rd));
@@ -124,6 +153,17 @@ __global__ __launch_bounds__(1024) void k_ipm_measures(IpmPtrs P, unsigned pub) 
     ymax = blk_reduce_max(ymax, sh);
     rpmax = blk_reduce_max(rpmax, sh);
     mu = blk_reduce_sum(mu, sh);
+    if (gridDim.x > 1) {
+        if (threadIdx.x == 0) { red_store(P, 0, pinf); red_store(P, 1, dinf); red_store(P, 2, ymax); red_store(P, 3, rpmax); red_store(P, 4, mu); }
+        if (!red_last_arrival(P, &last)) return;
+        if (threadIdx.x == 0) {
+            pinf = dinf = ymax = rpmax = mu = 0.0;
+            for (int w = 0; w < (int)gridDim.x; ++w) {
+                pinf = fmax(pinf, red_load(P, w, 0)); dinf = fmax(dinf, red_load(P, w, 1)); ymax = fmax(ymax, red_load(P, w, 2));
+                rpmax = fmax(rpmax, red_load(P, w, 3)); mu += red_load(P, w, 4);
+            }
+        }
+    }
     if (threadIdx.x == 0) {
         P.scal[SC_PINF] = pinf;
         P.scal[SC_DINF] = dinf / P.scale_q;
@@ -327,26 +367,34 @@ __device__ __forceinline__ double ratio(double x, double dx) { return dx < 0.0 ?
 // step lengths to the boundary (ap primal, ad dual), each capped at 1
 __global__ __launch_bounds__(1024) void k_ipm_steps(IpmPtrs P, IpmDir D, unsigned pub) {
     __shared__ double sh[16];
+    __shared__ bool last;
     double ap = 1e300, ad = 1e300;
-    for (int64_t j = threadIdx.x; j < P.n; j += 1024) {
+    const int64_t t0 = (int64_t)blockIdx.x * 1024 + threadIdx.x, stride = (int64_t)gridDim.x * 1024;
+    for (int64_t j = t0; j < P.n; j += stride) {
         if (!(P.ub[j] > P.lb[j])) continue;
         ap = fmin(ap, fmin(ratio(P.tL[j], D.dp[j]), ratio(P.tU[j], -D.dp[j])));
         ad = fmin(ad, fmin(ratio(P.muL[j], D.dmuL[j]), ratio(P.muU[j], D.dmuU[j])));
     }
-    for (int64_t k = threadIdx.x; k < P.ns; k += 1024) {
+    for (int64_t k = t0; k < P.ns; k += stride) {
         ap = fmin(ap, ratio(P.ts[k], D.ds[k]));
         ad = fmin(ad, ratio(P.mus[k], D.dmus[k]));
     }
-    for (int64_t i = threadIdx.x; i < P.M; i += 1024) {
+    for (int64_t i = t0; i < P.M; i += stride) {
         if (P.rtype[i] == 0) continue;
         ap = fmin(ap, ratio(P.g[i], D.dg[i]));
         ad = fmin(ad, ratio(P.pi[i], D.dpi[i]));
     }
-    ap = fmin(1.0, blk_reduce_min(ap, sh));
-    ad = fmin(1.0, blk_reduce_min(ad, sh));
+    ap = blk_reduce_min(ap, sh);
+    ad = blk_reduce_min(ad, sh);
+    if (gridDim.x > 1) {
+        if (threadIdx.x == 0) { red_store(P, 0, ap); red_store(P, 1, ad); }
+        if (!red_last_arrival(P, &last)) return;
+        if (threadIdx.x == 0)
+            for (int w = 0; w < (int)gridDim.x; ++w) { ap = fmin(ap, red_load(P, w, 0)); ad = fmin(ad, red_load(P, w, 1)); }
+    }
     if (threadIdx.x == 0) {
-        P.scal[SC_AP] = ap;
-        P.scal[SC_AD] = ad;
+        P.scal[SC_AP] = fmin(1.0, ap);
+        P.scal[SC_AD] = fmin(1.0, ad);
     }
     scal_publish(P, pub);
 }
@@ -354,16 +402,26 @@ __global__ __launch_bounds__(1024) void k_ipm_steps(IpmPtrs P, IpmDir D, unsigne
 // mu_aff -> sigma = (mu_aff/mu)^3 -> sm = sigma mu
 __global__ __launch_bounds__(1024) void k_ipm_muaff(IpmPtrs P, IpmDir A) {
     __shared__ double sh[16];
+    __shared__ bool last;
     const double ap = P.scal[SC_AP], ad = P.scal[SC_AD];
     double acc = 0.0;
-    for (int64_t j = threadIdx.x; j < P.n; j += 1024) {
+    const int64_t t0 = (int64_t)blockIdx.x * 1024 + threadIdx.x, stride = (int64_t)gridDim.x * 1024;
+    for (int64_t j = t0; j < P.n; j += stride) {
         if (!(P.ub[j] > P.lb[j])) continue;
         acc += (P.tL[j] + ap * A.dp[j]) * (P.muL[j] + ad * A.dmuL[j]) + (P.tU[j] - ap * A.dp[j]) * (P.muU[j] + ad * A.dmuU[j]);
     }
-    for (int64_t k = threadIdx.x; k < P.ns; k += 1024) acc += (P.ts[k] + ap * A.ds[k]) * (P.mus[k] + ad * A.dmus[k]);
-    for (int64_t i = threadIdx.x; i < P.M; i += 1024)
+    for (int64_t k = t0; k < P.ns; k += stride) acc += (P.ts[k] + ap * A.ds[k]) * (P.mus[k] + ad * A.dmus[k]);
+    for (int64_t i = t0; i < P.M; i += stride)
         if (P.rtype[i] != 0) acc += (P.g[i] + ap * A.dg[i]) * (P.pi[i] + ad * A.dpi[i]);
     acc = blk_reduce_sum(acc, sh);
+    if (gridDim.x > 1) {
+        if (threadIdx.x == 0) red_store(P, 0, acc);
+        if (!red_last_arrival(P, &last)) return;
+        if (threadIdx.x == 0) {
+            acc = 0.0;
+            for (int w = 0; w < (int)gridDim.x; ++w) acc += red_load(P, w, 0);
+        }
+    }
     if (threadIdx.x == 0) {
         double mu = P.scal[SC_MU];
         double mu_aff = acc / (double)P.ncomp;
