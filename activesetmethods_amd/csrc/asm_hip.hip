@@ -950,6 +950,13 @@ struct SLP {
 };
 
 struct Solver {
+    // out = A x for a k x ncols matrix of few, long rows (the basis Zt): one workgroup per row when that fills the chip better
+    void gemv_rows(const double* A, int64_t ld, const double* x, double* out, int64_t rows, int64_t ncols) {
+        if (rows <= 2048 && ncols >= 2048)
+            hipLaunchKernelGGL(k_gemv_n_wide, dim3((unsigned)rows), dim3(256), 0, h->stream, A, ld, x, out, rows, ncols);
+        else
+            hipLaunchKernelGGL(k_gemv_n, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, h->stream, A, ld, x, out, rows, ncols);
+    }
     // workgroups of the interior-point reductions (k_ipm_measures / _steps / _muaff): 1024 elements per workgroup and sweep, at most IPM_RED_MAXWG
     unsigned red_grid() const { return (unsigned)std::min<int64_t>(IPM_RED_MAXWG, std::max<int64_t>(1, (std::max(std::max(lp.n, lp.M), lp.ns) + 4095) / 4096)); }
     static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -1099,7 +1106,7 @@ struct Solver {
         if (ns_live()) {
             // null-space form: the equality rows' multipliers are carried as 0, the dual residual that counts is Z'rdp (oracle: IPM.measures)
             hipLaunchKernelGGL(k_ipm_measures, dim3(red_grid()), dim3(1024), 0, h->stream, P, 0u);
-            hipLaunchKernelGGL(k_gemv_n, dim3((unsigned)((ip.ns_k + 3) / 4)), dim3(256), 0, h->stream, (const double*)h->d_nsG, h->ns_ldg, (const double*)P.rdp, nsv(12), (int64_t)ip.ns_k, h->ldn);
+            gemv_rows((const double*)h->d_nsG, h->ns_ldg, (const double*)P.rdp, nsv(12), (int64_t)ip.ns_k, h->ldn);
             hipLaunchKernelGGL(k_ns_dinf, dim3(1), dim3(1024), 0, h->stream, P, (const double*)nsv(12), ip.ns_k, pub);
         } else {
             hipLaunchKernelGGL(k_ipm_measures, dim3(red_grid()), dim3(1024), 0, h->stream, P, pub);
@@ -1404,8 +1411,8 @@ struct Solver {
         hipLaunchKernelGGL(k_nseq_pbar, dim3(gN), dim3(256), 0, h->stream, A, (const double*)pfix, (const double*)x, (const double*)d_zero, Q.pbar, vz, ldn);
         dev.gemv_n_dev(h->d_Ah, Q.pbar, Q.tbar);
         HIPCHK(hipMemsetAsync(Q.u0, 0, 2 * Q.ldc * sizeof(double), h->stream));      // u0 and qh (contiguous)
-        hipLaunchKernelGGL(k_gemv_n, dim3((unsigned)((k + 3) / 4)), dim3(256), 0, h->stream, (const double*)h->d_nsG, h->ns_ldg, (const double*)vz, Q.u0, (int64_t)k, ldn);
-        hipLaunchKernelGGL(k_gemv_n, dim3((unsigned)((k + 3) / 4)), dim3(256), 0, h->stream, (const double*)h->d_nsG, h->ns_ldg, (const double*)A.q, Q.qh, (int64_t)k, ldn);
+        gemv_rows((const double*)h->d_nsG, h->ns_ldg, (const double*)vz, Q.u0, (int64_t)k, ldn);
+        gemv_rows((const double*)h->d_nsG, h->ns_ldg, (const double*)A.q, Q.qh, (int64_t)k, ldn);
     }
     // Equality-constrained solve on the working set `cur` in reduced coordinates (oracle: eqp_ns).  Leaves p, y, t = Ah p, tN = Ah' y
     // for the tail kernel like as_solve.  False: more active constraints than the buffers hold (the caller uses as_solve).
@@ -1517,7 +1524,7 @@ struct Solver {
             ip.ns_e_ready = true;
             double *d0 = nsv(2), *zz = nsv(3), *tk = nsv(12);
             hipLaunchKernelGGL(k_ns_e0, dim3(gN), dim3(256), 0, h->stream, P, (const double*)nsq().pbar, d0, ldn);
-            hipLaunchKernelGGL(k_gemv_n, dim3((unsigned)((k + 3) / 4)), dim3(256), 0, h->stream, (const double*)h->d_nsG, h->ns_ldg, (const double*)d0, tk, (int64_t)k, ldn);
+            gemv_rows((const double*)h->d_nsG, h->ns_ldg, (const double*)d0, tk, (int64_t)k, ldn);
             ns_gemv_t_dense(tk, k, zz);
             hipLaunchKernelGGL(k_ns_e1, dim3(gN), dim3(256), 0, h->stream, P, (const double*)d0, (const double*)zz, e, ldn);
         }
@@ -1544,7 +1551,7 @@ struct Solver {
         hipLaunchKernelGGL(k_ns_bi, dim3(gM), dim3(256), 0, h->stream, P, X, thI, res, bI, yM);
         dev.gemv_t_dev(h->d_Ah, yM, atw);
         hipLaunchKernelGGL(k_ns_ht, dim3(gN), dim3(256), 0, h->stream, th, (const double*)P.hp, (const double*)atw, (const double*)kdpb, res, ht, v, n, ldn);
-        hipLaunchKernelGGL(k_gemv_n, dim3((unsigned)((k + 3) / 4)), dim3(256), 0, h->stream, (const double*)h->d_nsG, h->ns_ldg, (const double*)v, ru, (int64_t)k, ldn);
+        gemv_rows((const double*)h->d_nsG, h->ns_ldg, (const double*)v, ru, (int64_t)k, ldn);
         if (k <= ASM_SMALL_USE) {
             // solve, refinement sweep on the unregularised matrix and the residual check in ONE one-workgroup launch
             hipLaunchKernelGGL(k_ns_reduced_solve, dim3(1), dim3(1024), 0, h->stream, (const double*)h->ns_fN.S, h->ns_fN.ld, (const double*)h->ns_fN.Linv,

@@ -118,6 +118,28 @@ __global__ __launch_bounds__(256) void k_gemv_n(const double* __restrict__ A, in
     if (lane == 0) out[i] = acc;
 }
 
+// the same product for FEW LONG rows (the k x n basis of the null-space form: 519 rows of 11 192): one workgroup per row, so that four times
+// as many wavefronts keep loads in flight (one wavefront per row: 28 us = 1.6 TB/s for 46 MB)
+__global__ __launch_bounds__(256) void k_gemv_n_wide(const double* __restrict__ A, int64_t ld, const double* __restrict__ x,
+                                                     double* __restrict__ out, int64_t M, int64_t ncols) {
+    __shared__ double red[4];
+    const int64_t i = blockIdx.x;
+    const double2* row = reinterpret_cast<const double2*>(A + i * ld);
+    const double2* xv = reinterpret_cast<const double2*>(x);
+    double acc = 0.0;
+    const int64_t n2 = ncols >> 1;
+    for (int64_t j = threadIdx.x; j < n2; j += 256) {
+        double2 a = row[j];
+        double2 b = xv[j];
+        acc = fma(a.x, b.x, acc);
+        acc = fma(a.y, b.y, acc);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[i] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // partial[r][j] = sum_{i in row chunk r} A[i,j] y[i]   ; second stage sums the chunks in order (deterministic).
 #define ASM_TMAXCHUNKS 128
 __global__ __launch_bounds__(256) void k_gemv_t_stage1(const double* __restrict__ A, int64_t ld, const double* __restrict__ y,
