@@ -756,8 +756,11 @@ struct Dev {
     // block chain of one outer panel [K0, K1): 64-wide potrf / panel solve steps whose rank-64 updates stay inside a
     // 512-wide inner panel; the rest of the outer panel is updated once per inner panel with K = 512
     void chol_chain(int Ms, double thr, int K0, int K1, bool beside_updates = false) {
-        for (int I0 = K0; I0 < K1; I0 += CHOL_NBI) {
-            const int I1 = std::min(I0 + CHOL_NBI, K1);
+        for (int I0 = K0, Inext = K0; I0 < K1; I0 = Inext) {
+            // a remainder of at most two 64-wide steps joins the last inner panel (k = 519: one launch of nine steps instead of a panel launch, an
+            // in-panel update and a second panel launch for the last seven columns)
+            const int I1 = (K1 - I0 <= CHOL_NBI + 2 * ASM_NB) ? K1 : std::min(I0 + CHOL_NBI, K1);
+            Inext = I1;
             const int Mi = rowlim(Ms, I1);           // banded factor: the rows below are out of this inner panel's reach
             if (h->fused_panel) {
                 // the <= 8 steps of this inner panel in one dataflow launch (k_chol_panel): row tiles are owned by workgroups,

@@ -889,7 +889,7 @@ __global__ __launch_bounds__(256) void k_pnl_wait_probe(unsigned* flag, unsigned
     pnl_wait(flag, epoch, tmo);
 }
 #define ASM_PNL_LDS (2 * ASM_NB * ASM_XP + 4 * 16 * 17 + 2 * ASM_NB)
-#define ASM_PNL_NS 8        // most 64-wide steps of one panel launch (flag words: NS for the diagonal blocks + NS * NS for the panel tiles)
+#define ASM_PNL_NS 10       // most 64-wide steps of one panel launch: eight, or up to ten when the last inner panel absorbs a short remainder (flag words: NS for the diagonal blocks + NS * NS for the panel tiles)
 // Register budget: two wavefronts per SIMD = 256 registers per lane, AGPRs included.  The panel kernel runs beside k_syrk_upd
 // (256 per wavefront, two per SIMD): a panel wavefront must fit into the slot ONE retiring update wavefront frees.  Left to
 // itself the compiler takes 256 VGPRs + 56 AGPRs (occupancy 1 is allowed for a 256-thread kernel), such a wavefront fits
