@@ -256,6 +256,9 @@ struct asm_handle {
     int *d_rowperm = nullptr, *d_rowpos = nullptr, *d_rowpairs = nullptr, *d_cpos = nullptr;      // position -> row, row -> position, structural pairs (row_i, row_j), pos_i >= pos_j
     int64_t n_rowpairs = 0;
     std::vector<int> row_perm_h, ns_eidx_h;      // host copies: rows by position (all rows; the equality rows of the null-space form)
+    int col_band = 0;               // the same for the n columns (column form of the restoration-phase Newton system)
+    int *d_colperm = nullptr, *d_colpos = nullptr, *d_colpairs = nullptr;
+    int64_t n_colpairs = 0;
     int main_band_cur = 0;          // band of the matrix now in the main factor buffers (set by the banded builds, 0 after every other build)
     double* d_redpart = nullptr;    // partial results / arrival counter of the multi-workgroup interior-point reductions
     unsigned* d_redcnt = nullptr;
@@ -501,8 +504,18 @@ struct Dev {
         const int64_t wz = std::min<int64_t>(round_up(h->row_band + 1, 64) + CHOL_NBO + 128, h->Mp);
         hipLaunchKernelGGL(k_ns_zero_band, dim3((unsigned)((wz + 255) / 256), (unsigned)Ms), dim3(256), 0, h->stream, h->d_S, h->Mp, Ms, (int)wz);
         hipLaunchKernelGGL(k_schur_sparse, dim3((unsigned)((h->n_rowpairs + 255) / 256)), dim3(256), 0, h->stream, (const int*)h->d_rowpairs, h->n_rowpairs, cpos_dev,
-                           h->d_sp_ptr, h->d_sp_col, sparse_vals(h->d_Ah), theta_dev, diag_dev, h->d_S, h->Mp);
+                           h->d_sp_ptr, h->d_sp_col, sparse_vals(h->d_Ah), theta_dev, diag_dev, h->d_S, h->Mp, (const int*)nullptr);
         set_main_band(h->row_band);
+    }
+    // K = diag + Ah' diag(dinv) Ah (n x n, lower) with the COLUMNS in their reverse Cuthill-McKee order (asm_handle::col_band): the column form
+    // of the restoration-phase Newton system, banded and built from the structural column pairs; `diag_place` is indexed by position
+    void schur_banded_cols_dev(const double* dinv_dev, const double* diag_place) {
+        const int n = (int)h->n;
+        const int64_t wz = std::min<int64_t>(round_up(h->col_band + 1, 64) + CHOL_NBO + 128, h->Mp);
+        hipLaunchKernelGGL(k_ns_zero_band, dim3((unsigned)((wz + 255) / 256), (unsigned)n), dim3(256), 0, h->stream, h->d_S, h->Mp, n, (int)wz);
+        hipLaunchKernelGGL(k_schur_sparse, dim3((unsigned)((h->n_colpairs + 255) / 256)), dim3(256), 0, h->stream, (const int*)h->d_colpairs, h->n_colpairs,
+                           (const int*)h->d_colpos, h->d_sc_ptr, h->d_sc_row, sparse_vals(h->d_Ah), dinv_dev, diag_place, h->d_S, h->Mp, (const int*)h->d_sc_pos);
+        set_main_band(h->col_band);
     }
     void syrk_gathered_dev(const int* idx_dev, int Ms, const double* theta_dev, const double* diag_dev) {
         set_main_band(0);
@@ -1616,7 +1629,15 @@ struct Solver {
         if (!use_col) { dev.chol_solve_dev(in, out, M); return; }
         hipLaunchKernelGGL(k_col_scale, dim3(gm), dim3(256), 0, h->stream, h->d_cdinv, in, h->d_cu, lp.M);      // u = D^-1 r
         dev.gemv_t_dev(h->d_Ah, h->d_cu, h->d_ct);                                                                 // Ah' u
-        dev.chol_solve_dev(h->d_ct, h->d_cv, (int)lp.n);                                                           // K^-1
+        if (h->col_band > 0) {                                                                                     // K^-1 (columns in banded order)
+            const unsigned gn = (unsigned)((lp.n + 255) / 256);
+            hipLaunchKernelGGL(k_red_gather, dim3(gn), dim3(256), 0, h->stream, (const int*)h->d_colperm, (int)lp.n, (const double*)h->d_ct, h->d_rce);
+            dev.chol_solve_dev(h->d_rce, h->d_rze, (int)lp.n);
+            hipLaunchKernelGGL(k_red_scatter, dim3(gn), dim3(256), 0, h->stream, (const int*)h->d_colperm, (int)lp.n, (const double*)h->d_rze, (const int*)h->d_colperm, 0,
+                               (const double*)h->d_rze, (const double*)h->d_ct, h->d_cv);
+        } else {
+            dev.chol_solve_dev(h->d_ct, h->d_cv, (int)lp.n);                                                       // K^-1
+        }
         dev.gemv_n_dev(h->d_Ah, h->d_cv, h->d_cw);                                                                 // Ah v
         hipLaunchKernelGGL(k_col_finish, dim3(gm), dim3(256), 0, h->stream, h->d_cdinv, h->d_cu, h->d_cw, out, lp.M);
     }
@@ -1707,7 +1728,13 @@ struct Solver {
             } else if (use_col) {
                 ip.col_iters += 1;
                 hipLaunchKernelGGL(k_ipm_col_prep, dim3(grid_all()), dim3(256), 0, h->stream, P, IPM_RHO_P, COL_FIXED, h->d_cdinv, h->d_cth);
-                dev.syrk_col(h->d_cdinv, h->d_cth);
+                if (h->col_band > 0) {
+                    // columns in their banded order: K built from the structural column pairs, factor and substitutions stop at the band
+                    hipLaunchKernelGGL(k_red_gather, dim3((unsigned)((lp.n + 255) / 256)), dim3(256), 0, h->stream, (const int*)h->d_colperm, (int)lp.n, (const double*)h->d_cth, h->d_diag);
+                    dev.schur_banded_cols_dev(h->d_cdinv, h->d_diag);
+                } else {
+                    dev.syrk_col(h->d_cdinv, h->d_cth);
+                }
                 dev.diag_prepare((int)lp.n, 0, 1e-13, 1e-30);
                 dev.chol((int)lp.n);
             } else {
@@ -2691,6 +2718,30 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
             };
             h->d_rowperm = up(ord); h->d_rowpos = up(pos); h->d_rowpairs = up(pairs);
             h->d_cpos = up(pos);                      // place of every row in the current row list of the interior-point factor (rewritten per iteration)
+            if (!h->d_rce) { dmalloc(&h->d_rce, h->Mp); dmalloc(&h->d_rze, h->Mp); }
+        }
+    }
+    // column order of the column form (K = Th + A' D^-1 A couples two columns when they share a row)
+    h->col_band = 0; h->n_colpairs = 0; h->d_colperm = h->d_colpos = h->d_colpairs = nullptr;
+    if (h->sp_ok && h->col_capable && !std::getenv("ASM_HIP_NO_BAND") && n >= 256) {
+        std::vector<int> all(n), pairs_pos;
+        for (int64_t j = 0; j < n; ++j) all[j] = (int)j;
+        int bw = 0;
+        const std::vector<int> ord = rcm_order(all, sc_ptr, sc_row, h->Mp, &bw, &pairs_pos);
+        if (2 * (int64_t)bw < n) {
+            h->col_band = std::max(bw, 1);
+            std::vector<int> pos(n), pairs(pairs_pos.size());
+            for (int64_t q = 0; q < n; ++q) pos[ord[q]] = (int)q;
+            for (size_t t = 0; t < pairs_pos.size(); ++t) pairs[t] = ord[pairs_pos[t]];
+            h->n_colpairs = (int64_t)pairs.size() / 2;
+            auto up = [&](const std::vector<int>& v) {
+                int* d = nullptr;
+                dmalloc(&d, (int64_t)v.size());
+                h->ns_bufs.push_back((void*)d);
+                HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
+                return d;
+            };
+            h->d_colperm = up(ord); h->d_colpos = up(pos); h->d_colpairs = up(pairs);
             if (!h->d_rce) { dmalloc(&h->d_rce, h->Mp); dmalloc(&h->d_rze, h->Mp); }
         }
     }

@@ -706,7 +706,9 @@ __global__ __launch_bounds__(256) void k_ns_s0_sparse(const int* __restrict__ pa
 // of the list (skipped when either row is not in it); weights theta over the columns, `diag` (indexed by place) added on the diagonal
 __global__ __launch_bounds__(256) void k_schur_sparse(const int* __restrict__ pairs, int64_t npairs, const int* __restrict__ cpos, const int* __restrict__ ptr,
                                                       const int* __restrict__ col, const double* __restrict__ val, const double* __restrict__ theta,
-                                                      const double* __restrict__ diag, double* __restrict__ S, int64_t ld) {
+                                                      const double* __restrict__ diag, double* __restrict__ S, int64_t ld, const int* __restrict__ vpos) {
+    // vpos: the lists (ptr, col) are the CSC side of the pattern (Gram matrix of COLUMNS: the column form's K = Th + A' D^-1 A) and entry a of
+    // a list has its value at val[vpos[a]]; null: CSR, values in list order
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= npairs) return;
     const int ri = pairs[2 * t], rj = pairs[2 * t + 1];
@@ -717,7 +719,7 @@ __global__ __launch_bounds__(256) void k_schur_sparse(const int* __restrict__ pa
     double acc = 0.0;
     while (a < ae && b < be) {
         const int ca = col[a], cb = col[b];
-        if (ca == cb) { acc += val[a] * val[b] * theta[ca]; ++a; ++b; }
+        if (ca == cb) { acc += (vpos ? val[vpos[a]] * val[vpos[b]] : val[a] * val[b]) * theta[ca]; ++a; ++b; }
         else if (ca < cb) ++a;
         else ++b;
     }
