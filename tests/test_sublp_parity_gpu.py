@@ -569,3 +569,40 @@ def test_row_order_is_the_oracles():
     opt2, _ = hip_solve(spd)
     assert opt2.row_order()[0] is None and opt2.row_order()[1] == 0
     opt2.close()
+
+
+@pytest.mark.parametrize("seed,n,m,neq,nrange", [(501, 400, 600, 120, 30), (502, 300, 700, 40, 60), (503, 500, 520, 300, 0), (504, 350, 640, 0, 40)])
+def test_banded_row_order_parity(seed, n, m, neq, nrange):
+    """Sub-problems whose coupling graph is banded after reordering (tests/util.banded_subproblem, rows stored in random order): the
+    library takes row lists in reverse Cuthill-McKee order and factors banded matrices - active-set solves, interior-point row forms
+    (full and reduced), the column form of the restoration phase, the null-space form's S0 where it applies.  Normal phase, a perturbed
+    re-solve on the same handle, then (infeasible variant) the infeasibility verdict and the restoration LP: status, path, working
+    sets, 1e-10 against the oracle on every call; the order in use is the oracle's."""
+    from tests.util import banded_subproblem
+    sp = banded_subproblem(seed, n, m, neq, nrange)
+    qp, o1 = oracle_solve(sp)
+    opt, h1 = hip_solve(sp)
+    perm, band, _, _ = opt.row_order()
+    assert perm is not None and 0 < band < m // 2 and qp.row_pos is not None and np.array_equal(np.argsort(qp.row_pos), perm)
+    st = opt.last_stats()
+    assert o1[5] == h1[5] == 1 and PATH_NAMES[st['path']] == o1[6]['stats']['path'], (st, o1[6]['stats'])
+    _compare(o1, h1, opt, None)
+    rng = np.random.default_rng(seed + 1)
+    sp2 = dict(sp); sp2['dE'] = sp['dE'] * (1.0 + 1e-2 * rng.standard_normal(len(sp['dE']))); sp2['df'] = sp['df'] + 0.2 * rng.standard_normal(n)
+    qp, o2 = oracle_solve(sp2, False, qp)
+    opt, h2 = hip_solve(sp2, False, opt)
+    st = opt.last_stats()
+    assert o2[5] == h2[5] == 1 and PATH_NAMES[st['path']] == o2[6]['stats']['path'], (st, o2[6]['stats'])
+    _compare(o2, h2, opt, None)
+    opt.close()
+    spi = banded_subproblem(seed, n, m, neq, nrange, infeasible=True)
+    qp, oi = oracle_solve(spi)
+    opt, hi = hip_solve(spi)
+    assert oi[5] == hi[5] == 2                                   # INFEASIBLE on both sides
+    qp, orr = oracle_solve(spi, True, qp)
+    opt, hr = hip_solve(spi, True, opt)
+    st = opt.last_stats()
+    assert orr[5] == hr[5] == 1 and PATH_NAMES[st['path']] == orr[6]['stats']['path'], (st, orr[6]['stats'])
+    assert st['ipm_iters'] == orr[6]['stats']['ipm_iters'] and st['col_iters'] == orr[6]['stats'].get('col_iters', 0), (st, orr[6]['stats'])
+    _compare(orr, hr, opt, None)
+    opt.close()

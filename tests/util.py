@@ -132,3 +132,42 @@ EDGE_CASE_ANSWERS = {      # worked by hand from the LP each case poses
     "zero_radius": ([0.0, 0.0], [0.0]),
     "cancelling_duplicates": ([-0.4, -0.05], [0.5]),   # 2 p2 = -0.1 ; 1 - 2 lambda = 0
 }
+
+
+def banded_subproblem(seed, n=400, m=600, neq=120, nrange=30, width=6, per_row=4, delta=0.5, infeasible=False):
+    """A sparse sub-problem whose rows couple locally (row i touches columns near i n / m), stored in a random row order: the coupling
+    graph has a small bandwidth that only a reordering finds - the shape on which the library factors banded matrices (reverse
+    Cuthill-McKee order of the rows / columns).  m >= 256 rows so that the order is used."""
+    rng = np.random.default_rng(seed)
+    shuffle = rng.permutation(m)                            # row i of the hidden chain is stored as row shuffle[i]
+    rows, cols, vals = [], [], []
+    for i in range(m):
+        c0 = int(i * n / m)
+        cand = np.arange(max(0, c0 - width), min(n, c0 + width + 1))
+        cs = rng.choice(cand, min(per_row, len(cand)), replace=False)
+        for c in cs:
+            rows.append(shuffle[i]); cols.append(int(c)); vals.append(rng.standard_normal() * 0.5 + (1.5 if c == c0 else 0.0))
+    rows, cols, vals = np.array(rows), np.array(cols), np.array(vals)
+    order = np.lexsort((cols, rows))
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    J = np.zeros((m, n))
+    np.add.at(J, (rows, cols), vals)
+    x_k = rng.uniform(-0.3, 0.3, n)
+    v_lb = -np.ones(n); v_ub = np.ones(n)
+    p_star = rng.uniform(-0.2, 0.2, n)
+    E = rng.standard_normal(m) * 0.05
+    act = E + J @ p_star
+    kinds = rng.permutation(m)
+    c_lb = np.full(m, -INF); c_ub = np.full(m, INF)
+    eq = kinds[:neq]; rg = kinds[neq:neq + nrange]; rest = kinds[neq + nrange:]
+    c_lb[eq] = act[eq]; c_ub[eq] = act[eq]
+    c_lb[rg] = act[rg] - rng.uniform(0, 0.1, len(rg)); c_ub[rg] = act[rg] + rng.uniform(0, 0.1, len(rg))
+    half = len(rest) // 2
+    c_ub[rest[:half]] = act[rest[:half]] + rng.uniform(0, 0.05, half)
+    c_lb[rest[half:]] = act[rest[half:]] - rng.uniform(0, 0.05, len(rest) - half)
+    if infeasible:                                          # contradictory bounds on a few rows: the normal-phase LP is infeasible
+        bad = rest[:8]
+        c_ub[bad] = act[bad] - 5.0
+    df = rng.standard_normal(n)
+    return dict(n=n, m=m, j_row=rows + 1, j_col=cols + 1, dE=vals, df=df, f=0.1, E=E, x_k=x_k,
+                c_lb=c_lb, c_ub=c_ub, v_lb=v_lb, v_ub=v_ub, delta=delta, J=J)
