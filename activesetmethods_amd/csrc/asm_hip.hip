@@ -350,6 +350,7 @@ struct Dev {
     asm_handle* h;
     hipStream_t cur;                 // stream the factorisation kernels are launched on (h->stream, or the look-ahead stream)
     double* solve_w = nullptr;       // buffer the wide-block substitution runs in (default d_vecM2)
+    const double* solve_src = nullptr;   // one-block systems: the right-hand side the forward product reads (no copy into solve_w first)
     // the factor the Cholesky / substitution launches work on: matrix (lower triangle, pitch fld), inverses of its 64-wide diagonal
     // blocks, explicit inverses of its wide diagonal blocks and their transposes.  Default: the handle's main buffers.
     double *fS, *fLinv, *fBinv, *fBinvT;
@@ -661,10 +662,14 @@ struct Dev {
             hipLaunchKernelGGL(k_small_solve, dim3(1), dim3(1024), 0, h->stream, (const double*)fS, fld, (const double*)fLinv, Ms, rhs_dev, out_dev);
             return;
         }
-        if (out_dev != rhs_dev) HIPCHK(hipMemcpyAsync(out_dev, rhs_dev, Ms * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        // a system of one wide block only READS its right-hand side (forward diagonal product); with more blocks the panel updates work in place
+        const bool one_block = Ms <= fwb;
+        if (out_dev != rhs_dev && !one_block) HIPCHK(hipMemcpyAsync(out_dev, rhs_dev, Ms * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         int id = begin(ASM_K_TRSV, 2.0 * Ms * (double)Ms, 8.0 * Ms * (double)Ms);
         solve_w = out_dev;
+        solve_src = one_block ? rhs_dev : nullptr;
         solve_launches(Ms);
+        solve_src = nullptr;
         solve_w = h->d_vecM2;
         end(id);
     }
@@ -869,7 +874,7 @@ struct Dev {
         const int nB = (Ms + WB - 1) / WB;
         for (int B = 0; B < nB; ++B) {
             int b1 = std::min((B + 1) * WB, Ms);
-            hipLaunchKernelGGL((k_wtrsv_fwd_diag<WB>), dim3(WB / 4), dim3(256), 0, h->stream, fBinv, B, Ms, w, z);
+            hipLaunchKernelGGL((k_wtrsv_fwd_diag<WB>), dim3(WB / 4), dim3(256), 0, h->stream, fBinv, B, Ms, (const double*)(solve_src ? solve_src : w), z);
             const int Me = rowlim(Ms, b1);
             int rem = Me - b1;
             if (rem > 0)
