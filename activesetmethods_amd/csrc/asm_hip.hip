@@ -3016,7 +3016,7 @@ void ev_launch(asm_handle* h, const double* xd, double* Ed, double* fd, bool ful
     const unsigned nt = (unsigned)ntrial;
     if (F.n_rows > 0)
         hipLaunchKernelGGL(k_fn_rows, dim3((unsigned)((F.n_rows + 255) / 256), nt), dim3(256), 0, h->stream, F, xd, Ed, h->d_dE, full ? 1 : 0, ldx, ldE);
-    hipLaunchKernelGGL(k_fn_objective, dim3(nt), dim3(64), 0, h->stream, F, xd, fd, ldx);
+    hipLaunchKernelGGL(k_fn_objective, dim3(nt), dim3(256), 0, h->stream, F, xd, fd, ldx);
     if (full) hipLaunchKernelGGL(k_fn_gradient, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, F, xd, h->d_ev_df);
     if (h->ev_nlp_kind == 1) {
         const int64_t nl = h->ev_nlp_rows / 4;
