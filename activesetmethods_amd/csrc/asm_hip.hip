@@ -260,6 +260,8 @@ struct asm_handle {
     int *d_colperm = nullptr, *d_colpos = nullptr, *d_colpairs = nullptr;
     int64_t n_colpairs = 0;
     int main_band_cur = 0;          // band of the matrix now in the main factor buffers (set by the banded builds, 0 after every other build)
+    double* d_AhTg = nullptr;       // transposed copy of a dense Ah for the products Ah'y (ldn rows of pitch Mp; made once per LP)
+    bool ahTg_valid = false;
     double* d_redpart = nullptr;    // partial results / arrival counter of the multi-workgroup interior-point reductions
     unsigned* d_redcnt = nullptr;
     int main_band = 0;              // band of the matrix in the main factor buffers (test hook asm_test_set_band; 0 = dense)
@@ -458,6 +460,22 @@ struct Dev {
             int id = begin(ASM_K_GEMV, 2.0 * h->sp_nnz, 24.0 * h->sp_nnz + 12.0 * h->n);
             hipLaunchKernelGGL(k_spmv_t, dim3((unsigned)((h->ldn * 8 + 255) / 256)), dim3(256), 0, h->stream, h->d_sc_ptr, h->d_sc_row, h->d_sc_pos, v,
                                y, out, h->n, h->ldn);
+            end(id);
+            return;
+        }
+        if (A == h->d_Ah && (int64_t)h->ldn * h->Mp <= ((int64_t)1 << 27)) {
+            // dense LP matrix of moderate size: through a transposed copy (made once per LP), one row-wise launch
+            if (!h->d_AhTg) {
+                dmalloc(&h->d_AhTg, h->ldn * h->Mp);
+                HIPCHK(hipMemsetAsync(h->d_AhTg, 0, h->ldn * h->Mp * sizeof(double), h->stream));
+            }
+            if (!h->ahTg_valid) {
+                hipLaunchKernelGGL(k_transpose_dense, dim3((unsigned)((h->n + 63) / 64), (unsigned)((h->M + 63) / 64)), dim3(256), 0, h->stream, h->d_Ah,
+                                   h->ldn, h->M, h->n, h->d_AhTg, h->Mp);
+                h->ahTg_valid = true;
+            }
+            int id = begin(ASM_K_GEMV, 2.0 * h->M * h->n, 8.0 * h->M * h->ldn);
+            hipLaunchKernelGGL(k_gemv_n_exact, dim3((unsigned)((h->ldn + 3) / 4)), dim3(256), 0, h->stream, (const double*)h->d_AhTg, h->Mp, y, out, h->ldn, h->M);
             end(id);
             return;
         }
@@ -938,6 +956,7 @@ struct Dev {
     void scale(const double* c, double* rho) {
         h->spv_Ah_valid = false;
         h->ahT_valid = false;
+        h->ahTg_valid = false;
         if (h->M == 0) return;
         h2d(h->d_c, c, h->n, h->ldn);
         if (h->sp_ok) {
@@ -2412,6 +2431,7 @@ void free_device(asm_handle* h) {
     h->d_nz = nullptr; h->nz_valid = false; h->nz_frac_cache[0] = h->nz_frac_cache[1] = -1.0;
     F(h->d_idxI); F(h->d_rdI); F(h->d_rce); F(h->d_rze); F(h->d_sdiag);
     F(h->d_redpart); F(h->d_redcnt); h->d_redpart = nullptr; h->d_redcnt = nullptr;
+    F(h->d_AhTg); h->d_AhTg = nullptr; h->ahTg_valid = false;
     h->d_idxI = nullptr; h->d_rdI = h->d_rce = h->d_rze = h->d_sdiag = nullptr;
     F(h->d_AhT); F(h->d_cdinv); F(h->d_cth); F(h->d_cu); F(h->d_ct); F(h->d_cv); F(h->d_cw); F(h->d_nzT);
     h->d_AhT = h->d_cdinv = h->d_cth = h->d_cu = h->d_ct = h->d_cv = h->d_cw = nullptr; h->d_nzT = nullptr;

@@ -140,6 +140,20 @@ __global__ __launch_bounds__(256) void k_gemv_n_wide(const double* __restrict__ 
     if (threadIdx.x == 0) out[i] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// out[i] = sum_{j < ncols} A[i,j] x[j] with ncols exact (entries of x beyond ncols are not touched): one wavefront per row.  The transposed
+// product A'y of a DENSE matrix through its transposed copy - one launch of 5 us instead of the two-stage column reduction (13 us at 500 x 1000).
+__global__ __launch_bounds__(256) void k_gemv_n_exact(const double* __restrict__ A, int64_t ld, const double* __restrict__ x,
+                                                      double* __restrict__ out, int64_t rows, int64_t ncols) {
+    int64_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const double* row = A + i * ld;
+    double acc = 0.0;
+    for (int64_t j = lane; j < ncols; j += 64) acc = fma(row[j], x[j], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) out[i] = acc;
+}
+
 // partial[r][j] = sum_{i in row chunk r} A[i,j] y[i]   ; second stage sums the chunks in order (deterministic).
 #define ASM_TMAXCHUNKS 128
 __global__ __launch_bounds__(256) void k_gemv_t_stage1(const double* __restrict__ A, int64_t ld, const double* __restrict__ y,
