@@ -907,8 +907,13 @@ struct Dev {
                 np = (rem + ASM_WBROWS - 1) / ASM_WBROWS;
                 hipLaunchKernelGGL((k_wtrsv_bwd_panel<WB>), dim3((unsigned)np), dim3(256), 0, h->stream, fS, fld, B, Me, w, h->d_wpart);
             }
-            hipLaunchKernelGGL((k_wtrsv_bwd_reduce<WB>), dim3(WB / ASM_NB), dim3(256), 0, h->stream, B, Ms, z, h->d_wpart, np, h->d_wt);
-            hipLaunchKernelGGL((k_wtrsv_bwd_diag<WB>), dim3(WB / 4), dim3(256), 0, h->stream, fBinvT, B, Ms, h->d_wt, w);
+            if (np > 0) {
+                hipLaunchKernelGGL((k_wtrsv_bwd_reduce<WB>), dim3(WB / ASM_NB), dim3(256), 0, h->stream, B, Ms, z, h->d_wpart, np, h->d_wt);
+                hipLaunchKernelGGL((k_wtrsv_bwd_diag<WB>), dim3(WB / 4), dim3(256), 0, h->stream, fBinvT, B, Ms, h->d_wt, w, WB);
+            } else {
+                // last wide block (the only one of a small system): nothing to subtract, the diagonal product reads z itself
+                hipLaunchKernelGGL((k_wtrsv_bwd_diag<WB>), dim3(WB / 4), dim3(256), 0, h->stream, fBinvT, B, Ms, (const double*)(z + (int64_t)B * WB), w, Ms - B * WB);
+            }
         }
     }
     void assemble() {

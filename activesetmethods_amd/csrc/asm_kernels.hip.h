@@ -1431,7 +1431,7 @@ __global__ __launch_bounds__(256) void k_wtrsv_bwd_reduce(int B, int Ms, const d
 // x_B = X_B' t  through the transposed block inverse (row c of XT = column c of X): one wavefront per unknown
 template <int WB>
 __global__ __launch_bounds__(256) void k_wtrsv_bwd_diag(const double* __restrict__ BinvT, int B, int Ms, const double* __restrict__ t,
-                                                        double* __restrict__ x) {
+                                                        double* __restrict__ x, int tlen) {
     const int b0 = B * WB;
     const double* XT = BinvT + (int64_t)B * WB * WB;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1441,8 +1441,8 @@ __global__ __launch_bounds__(256) void k_wtrsv_bwd_diag(const double* __restrict
 #pragma unroll
     for (int u = 0; u < WB / 64; ++u) {
         int c = u * 64 + lane;
-        const double xv = XT[(int64_t)row * WB + c], tv = t[c];          // unconditional, as in k_wtrsv_fwd_diag (t has WB entries)
-        v[u] = (c >= row) ? xv * tv : 0.0;
+        const double xv = XT[(int64_t)row * WB + c], tv = t[min(c, tlen - 1)];          // unconditional, as in k_wtrsv_fwd_diag (t has tlen valid entries)
+        v[u] = (c >= row && c < tlen) ? xv * tv : 0.0;
     }
     double acc = 0.0;
 #pragma unroll
