@@ -2313,7 +2313,7 @@ struct Solver {
         }
         const bool prefer_ref = hint.prefer_ref;
         ipm_init();
-        const double tols[3] = {1e-8, 1e-10, 1e-12};
+        const double tols[3] = {1e-9, 1e-10, 1e-12};      // oracle: IPM_STAGES
         const int more[3] = {IPM_MAXIT, 6, 6};
         bool have_sets = false;
         for (int stage = 0; stage < 3; ++stage) {
