@@ -1352,7 +1352,7 @@ struct Solver {
         if (k > h->ns_kcap && h->ns_kcap > 0) return false;
         ns_reserve((int)k);
         hipLaunchKernelGGL(k_transpose_dense, dim3((unsigned)((nE + 63) / 64), (unsigned)((nE + 63) / 64)), dim3(256), 0, h->stream, (const double*)h->ns_f0.S, h->ns_f0.ld,
-                           (int64_t)nE, (int64_t)nE, h->d_nsLt, h->ns_f0.ld);
+                           (int64_t)nE, (int64_t)nE, h->d_nsLt, h->ns_f0.ld, (int64_t)(h->ns_f0.band > 0 ? h->ns_f0.band : nE));
         std::vector<int>& J = cur_hint->ns_J;
         bool have = false;
         ns_was_cold = false;

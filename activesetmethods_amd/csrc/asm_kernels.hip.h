@@ -1505,10 +1505,13 @@ __global__ __launch_bounds__(256) void k_spmv_t(const int* __restrict__ cptr, co
 
 // out[j][i] = A[i][j]   (64 x 64 LDS tiles; A is rows x ld_in, out is cols x ld_out) - transposed copy of the scaled LP
 // matrix for the column form of the Newton system
+// band >= 0: square lower-triangular input (a Cholesky factor) whose entries beyond `band` sub-diagonals are zero (band = rows: dense): only
+// the tiles that hold factor entries are moved - the transposed factor is read in its upper band only (Dev::trsm_rows, backward pass)
 __global__ __launch_bounds__(256) void k_transpose_dense(const double* __restrict__ A, int64_t ld_in, int64_t rows, int64_t cols,
-                                                         double* __restrict__ out, int64_t ld_out) {
+                                                         double* __restrict__ out, int64_t ld_out, int64_t band = -1) {
     __shared__ double tile[64 * 65];
     const int64_t i0 = (int64_t)blockIdx.y * 64, j0 = (int64_t)blockIdx.x * 64;
+    if (band >= 0 && (j0 > i0 + 63 || i0 > j0 + 63 + band)) return;
     _Pragma("unroll") for (int e_it = 0; e_it < 16; ++e_it) {
         const int e = threadIdx.x + 256 * e_it;
         int r = e >> 6, c = e & 63;
