@@ -330,3 +330,28 @@ def test_converged_iterate_last_resort_scenario_27():
         assert o_out[5] == 1 and o_out[6]['stats']['path'] == 'ipm-conv', o_out[6]['stats']
         assert abs(sp['df'] @ (o_out[0] - rec['p'])) <= 1e-8 * max(1.0, abs(sp['df'] @ rec['p']))
         assert rel_err(rec['p'], o_out[0]) < 1e-6
+
+
+def test_scenario_batch_is_independent_of_the_stream_pool():
+    """Eight case300-sized scenarios solved one after the other and three at a time (each in-flight scenario on its own handle = HIP stream):
+    the same iterates, bit for bit - x, multipliers, iteration and LP counts of every scenario.  (The reductions of the kernels are
+    fixed-order; nothing of one scenario's solve depends on what else the GPU is doing.)"""
+    import activesetmethods_amd as A
+    from activesetmethods_amd import acopf, batch
+    base = acopf.synthetic_case("case300", 1, 0.5)
+
+    def make_model(sidx):
+        pr = acopf.function_model(acopf.scenario_case(base, sidx)).to_problem("case300-sized scenario %d" % sidx)
+        return A.Model.from_problem(pr, A.Parameters(algorithm="Line Search", max_iter=100, device_eval=True))
+
+    def run(model):
+        slp = A.optimize(model)
+        slp.optimizer.close()
+        return slp, model
+
+    seq, _ = batch.solve_batch(make_model, 8, rank=0, world=1, run=lambda m: run(m)[0], concurrency=1)
+    par, _ = batch.solve_batch(make_model, 8, rank=0, world=1, run=lambda m: run(m)[0], concurrency=3)
+    for a, b in zip(seq, par):
+        assert a.ret == b.ret == 0 and a.iter == b.iter and a.lp_solves == b.lp_solves
+        assert np.array_equal(a.x, b.x) and np.array_equal(a.lam, b.lam)
+        assert [r['stats']['path'] for r in a.trace] == [r['stats']['path'] for r in b.trace]
