@@ -57,7 +57,8 @@ __device__ __forceinline__ int blk_compact_pos(bool flag, int& base, int* sh_cnt
 }
 
 // optimal-partition guess from the interior-point iterate (oracle: identify)
-__global__ __launch_bounds__(256) void k_as_identify(IpmPtrs P, AsSets S) {
+__global__ __launch_bounds__(256) void k_as_identify(AsmBt abt, IpmPtrs P, AsSets S) {
+    ASM_BARGS(abt, P, S);
     int64_t t = blockIdx.x * 256 + threadIdx.x;
     const double sq = P.scale_q;
     if (t < P.n) {
@@ -83,14 +84,15 @@ __global__ __launch_bounds__(256) void k_as_identify(IpmPtrs P, AsSets S) {
 }
 
 // out = src (0 when src is null) clipped into [lb, ub]: reference points of the two projections (oracle: zero_p, np.clip(ip.p))
-__global__ __launch_bounds__(256) void k_as_clip0(const double* __restrict__ lb, const double* __restrict__ ub, const double* __restrict__ src,
-                                                  double* __restrict__ out, int64_t n) {
+__global__ __launch_bounds__(256) void k_as_clip0(AsmBt abt, const double* __restrict__ lb, const double* __restrict__ ub, const double* __restrict__ src, double* __restrict__ out, int64_t n) {
+    ASM_BARGS(abt, lb, ub, src, out, n);
     int64_t j = blockIdx.x * 256 + threadIdx.x;
     if (j < n) out[j] = fmin(fmax(src ? src[j] : 0.0, lb[j]), ub[j]);
 }
 
 // sl[i] = sum of scoef*slo over the row's slack columns (once per LP)
-__global__ __launch_bounds__(256) void k_as_sl(AsPtrs A) {
+__global__ __launch_bounds__(256) void k_as_sl(AsmBt abt, AsPtrs A) {
+    ASM_BARGS(abt, A);
     int64_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= A.M) return;
     double a = 0.0;
@@ -103,14 +105,16 @@ __global__ __launch_bounds__(256) void k_as_sl(AsPtrs A) {
 }
 
 // s = max(src, slo)
-__global__ __launch_bounds__(256) void k_as_smax(const double* __restrict__ src, const double* __restrict__ slo, double* __restrict__ dst, int64_t ns) {
+__global__ __launch_bounds__(256) void k_as_smax(AsmBt abt, const double* __restrict__ src, const double* __restrict__ slo, double* __restrict__ dst, int64_t ns) {
+    ASM_BARGS(abt, src, slo, dst, ns);
     int64_t k = blockIdx.x * 256 + threadIdx.x;
     if (k < ns) dst[k] = fmax(src[k], slo[k]);
 }
 
 // Everything an equality-constrained solve derives from its working set: soft rows and their known multiplier, the ordered
 // lists of hard rows and free variables with their inverse maps and masks, the bound-active part of p.  One workgroup.
-__global__ __launch_bounds__(1024) void k_as_setup(AsPtrs A, AsSets S, const double* __restrict__ p_ref, int64_t ldn, int64_t ldT) {
+__global__ __launch_bounds__(1024) void k_as_setup(AsmBt abt, AsPtrs A, AsSets S, const double* __restrict__ p_ref, int64_t ldn, int64_t ldT) {
+    ASM_BARGS(abt, A, S, p_ref, ldn, ldT);
     __shared__ int sh_cnt[16];
     int baseH = 0, baseF = 0, any_soft = 0;
     for (int64_t i0 = 0; i0 < A.M; i0 += 1024) {
@@ -171,7 +175,8 @@ __global__ __launch_bounds__(1024) void k_as_setup(AsPtrs A, AsSets S, const dou
 
 // right-hand sides of the two projections:  bH = r_H - (Ah pB)_H - sl_H ;  cF = q_F - (Ah' y_soft)_F ;  yH = y_ref_H
 // t = Ah pB and (when any_soft) tN = Ah' y_soft were produced by the matrix-vector kernels.
-__global__ __launch_bounds__(256) void k_as_rhs(AsPtrs A, const double* __restrict__ y_ref) {
+__global__ __launch_bounds__(256) void k_as_rhs(AsmBt abt, AsPtrs A, const double* __restrict__ y_ref) {
+    ASM_BARGS(abt, A, y_ref);
     int64_t t = blockIdx.x * 256 + threadIdx.x;
     const int nH = A.cnt[AC_NH];
     const bool soft = A.cnt[AC_ANYSOFT] != 0;
@@ -184,12 +189,14 @@ __global__ __launch_bounds__(256) void k_as_rhs(AsPtrs A, const double* __restri
     if (t < A.n) A.cF[t] = A.Fmask[t] != 0.0 ? A.q[t] - (soft ? A.tN[t] : 0.0) : 0.0;
 }
 // v[a] = bH[a] - t[H[a]]
-__global__ __launch_bounds__(256) void k_as_res_p(AsPtrs A) {
+__global__ __launch_bounds__(256) void k_as_res_p(AsmBt abt, AsPtrs A) {
+    ASM_BARGS(abt, A);
     int64_t a = blockIdx.x * 256 + threadIdx.x;
     if (a < A.cnt[AC_NH]) A.v[a] = A.bH[a] - A.t[A.Hidx[a]];
 }
 // yfull = scatter of a compact H-vector (zero elsewhere); optionally accumulate it into uacc
-__global__ __launch_bounds__(256) void k_as_scatter_h(AsPtrs A, const double* __restrict__ src, int accumulate) {
+__global__ __launch_bounds__(256) void k_as_scatter_h(AsmBt abt, AsPtrs A, const double* __restrict__ src, int accumulate) {
+    ASM_BARGS(abt, A, src, accumulate);
     int64_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= A.M) return;
     int pos = A.hpos[i];
@@ -197,27 +204,32 @@ __global__ __launch_bounds__(256) void k_as_scatter_h(AsPtrs A, const double* __
     if (accumulate && pos >= 0) A.uacc[pos] += src[pos];
 }
 // pF += Fmask .* tN
-__global__ __launch_bounds__(256) void k_as_add_f(AsPtrs A) {
+__global__ __launch_bounds__(256) void k_as_add_f(AsmBt abt, AsPtrs A) {
+    ASM_BARGS(abt, A);
     int64_t j = blockIdx.x * 256 + threadIdx.x;
     if (j < A.n) A.pF[j] += A.Fmask[j] * A.tN[j];
 }
 // rd = Fmask .* (cF - tN)
-__global__ __launch_bounds__(256) void k_as_rd(AsPtrs A) {
+__global__ __launch_bounds__(256) void k_as_rd(AsmBt abt, AsPtrs A) {
+    ASM_BARGS(abt, A);
     int64_t j = blockIdx.x * 256 + threadIdx.x;
     if (j < A.n) A.rd[j] = A.Fmask[j] * (A.cF[j] - A.tN[j]);
 }
 // v[a] = t[H[a]]
-__global__ __launch_bounds__(256) void k_as_gather_h(AsPtrs A) {
+__global__ __launch_bounds__(256) void k_as_gather_h(AsmBt abt, AsPtrs A) {
+    ASM_BARGS(abt, A);
     int64_t a = blockIdx.x * 256 + threadIdx.x;
     if (a < A.cnt[AC_NH]) A.v[a] = A.t[A.Hidx[a]];
 }
 // yH += u
-__global__ __launch_bounds__(256) void k_as_add_yh(AsPtrs A) {
+__global__ __launch_bounds__(256) void k_as_add_yh(AsmBt abt, AsPtrs A) {
+    ASM_BARGS(abt, A);
     int64_t a = blockIdx.x * 256 + threadIdx.x;
     if (a < A.cnt[AC_NH]) A.yH[a] += A.u[a];
 }
 // p_F <- pF ; y_H <- yH (soft rows keep their known multiplier, inactive rows 0)
-__global__ __launch_bounds__(256) void k_as_merge(AsPtrs A, int with_y) {
+__global__ __launch_bounds__(256) void k_as_merge(AsmBt abt, AsPtrs A, int with_y) {
+    ASM_BARGS(abt, A, with_y);
     int64_t t = blockIdx.x * 256 + threadIdx.x;
     if (t < A.n && A.Fmask[t] != 0.0) A.p[t] = A.pF[t];
     if (with_y && t < A.M) {
@@ -230,7 +242,8 @@ __global__ __launch_bounds__(256) void k_as_merge(AsPtrs A, int with_y) {
 // Computes the basic slack values, act = Ah p + E s, z = q - Ah' y, the LP optimality measures of (p, s, y) on the working
 // set `cur`, the corrected working set `nx` with the number of changes, and the number of positions where `nx` differs
 // from `prev` (cycle detection).  One workgroup.
-__global__ __launch_bounds__(1024) void k_as_finish(AsPtrs A, AsSets cur, AsSets nx, AsSets prev, int have_prev, double tol_p, double tol_d) {
+__global__ __launch_bounds__(1024) void k_as_finish(AsmBt abt, AsPtrs A, AsSets cur, AsSets nx, AsSets prev, int have_prev, double tol_p, double tol_d) {
+    ASM_BARGS(abt, A, cur, nx, prev, have_prev, tol_p, tol_d);
     __shared__ double sh[16];
     double pr = 0.0, du = 0.0, nchg = 0.0, ndiff = 0.0;
     const double td = tol_d * A.scale_q;
@@ -315,7 +328,8 @@ __global__ __launch_bounds__(1024) void k_as_finish(AsPtrs A, AsSets cur, AsSets
 // Primal round tail.  Inputs: t = Ah p, tN = Ah' u_full (u = multipliers of the least-norm problem on the hard rows).
 // Violated inequalities of the face join the working set W (in place); when none is violated, non-mandatory members of W
 // with a wrong-sign multiplier leave; when nothing changes the hard rows must hold (AS_HARDRES).
-__global__ __launch_bounds__(1024) void k_face_primal_finish(AsPtrs A, AsSets W, AsSets part, double tol_p, double tol_m, int check_only) {
+__global__ __launch_bounds__(1024) void k_face_primal_finish(AsmBt abt, AsPtrs A, AsSets W, AsSets part, double tol_p, double tol_m, int check_only) {
+    ASM_BARGS(abt, A, W, part, tol_p, tol_m, check_only);
     __shared__ double sh[16];
     __shared__ int s_viol;
     double nviol = 0.0, nrel = 0.0, hres = 0.0;
@@ -400,8 +414,8 @@ __global__ __launch_bounds__(1024) void k_face_primal_finish(AsPtrs A, AsSets W,
 
 // ---- anchored method in the null space of the mandatory set (oracle: _face_primal_anchored) -------------------------------
 // p = p0 + sum_c u_c z_c   (Zbuf row c = z_c, an n-vector supported on the partition's free columns)
-__global__ __launch_bounds__(256) void k_face_ns_combine(const double* __restrict__ p0, const double* __restrict__ Zbuf, int64_t ldz,
-                                                         const double* __restrict__ u, int k, double* __restrict__ p, int64_t n) {
+__global__ __launch_bounds__(256) void k_face_ns_combine(AsmBt abt, const double* __restrict__ p0, const double* __restrict__ Zbuf, int64_t ldz, const double* __restrict__ u, int k, double* __restrict__ p, int64_t n) {
+    ASM_BARGS(abt, p0, Zbuf, ldz, u, k, p, n);
     int64_t j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     double acc = p0[j];
@@ -416,8 +430,8 @@ __device__ __forceinline__ double as_ratio(double g0, double g1) {
     const double a = fmax(g0, 0.0);
     return a / (a - g1);
 }
-__global__ __launch_bounds__(1024) void k_face_ns_step(AsPtrs A, AsSets W, double* __restrict__ pa, double* __restrict__ sa,
-                                                       double* __restrict__ acta, double tol_p) {
+__global__ __launch_bounds__(1024) void k_face_ns_step(AsmBt abt, AsPtrs A, AsSets W, double* __restrict__ pa, double* __restrict__ sa, double* __restrict__ acta, double tol_p) {
+    ASM_BARGS(abt, A, W, pa, sa, acta, tol_p);
     __shared__ double sh[16];
     const int64_t M = A.M, n = A.n, ns = A.ns;
     double nviol = 0.0, alpha = 2.0, hres = 0.0;
@@ -508,8 +522,8 @@ __global__ __launch_bounds__(1024) void k_face_ns_step(AsPtrs A, AsSets W, doubl
 }
 // The blocking constraint as  c'p (>= | <=) b  on the free columns of the partition: rd = c, AS_EQRES = g = b - c'(p0 - pfix),
 // AS_PR = c'c.   t0 = Ah p0.
-__global__ __launch_bounds__(1024) void k_face_ns_col(AsPtrs A, const double* __restrict__ Ah, int64_t ld, int fam, int64_t e,
-                                                      const double* __restrict__ p0, const double* __restrict__ t0) {
+__global__ __launch_bounds__(1024) void k_face_ns_col(AsmBt abt, AsPtrs A, const double* __restrict__ Ah, int64_t ld, int fam, int64_t e, const double* __restrict__ p0, const double* __restrict__ t0) {
+    ASM_BARGS(abt, A, Ah, ld, fam, e, p0, t0);
     __shared__ double sh[16];
     double cc = 0.0;
     const int64_t row = fam == 0 ? e : (fam == 1 ? (int64_t)A.srow[e] : -1);
@@ -530,12 +544,14 @@ __global__ __launch_bounds__(1024) void k_face_ns_col(AsPtrs A, const double* __
     }
 }
 // z = rd - Fmask .* tN   (tN = N0' S0^-1 N0 c)
-__global__ __launch_bounds__(256) void k_face_ns_z(AsPtrs A, double* __restrict__ z) {
+__global__ __launch_bounds__(256) void k_face_ns_z(AsmBt abt, AsPtrs A, double* __restrict__ z) {
+    ASM_BARGS(abt, A, z);
     int64_t j = blockIdx.x * 256 + threadIdx.x;
     if (j < A.n) z[j] = A.rd[j] - A.Fmask[j] * A.tN[j];
 }
 // undo a mark of the working set (release of an added constraint)
-__global__ void k_face_ns_unmark(AsPtrs A, AsSets W, int fam, int64_t e) {
+__global__ void k_face_ns_unmark(AsmBt abt, AsPtrs A, AsSets W, int fam, int64_t e) {
+    ASM_BARGS(abt, A, W, fam, e);
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (fam == 0) W.rowst[e] = 0;
     else if (fam == 1) { W.sst[e] = 1; W.rowst[A.srow[e]] = 1; }
@@ -544,7 +560,8 @@ __global__ void k_face_ns_unmark(AsPtrs A, AsSets W, int fam, int64_t e) {
 
 // Dual round tail (oracle: face_dual).  Input: tN = Ah' y.  z = q - Ah'y; sign conditions of the LP dual that y violates
 // become active: the dual working set D shrinks in place (row leaves H / variable joins F / slack becomes basic).
-__global__ __launch_bounds__(1024) void k_face_dual_finish(AsPtrs A, AsSets D, double tol_m) {
+__global__ __launch_bounds__(1024) void k_face_dual_finish(AsmBt abt, AsPtrs A, AsSets D, double tol_m) {
+    ASM_BARGS(abt, A, D, tol_m);
     __shared__ double sh[16];
     const double td = tol_m * A.scale_q;
     double nviol = 0.0;
@@ -572,7 +589,8 @@ __global__ __launch_bounds__(1024) void k_face_dual_finish(AsPtrs A, AsSets D, d
 
 // LP optimality measures of a (p, s, y) triple with separate primal / dual working sets (oracle: face_polish tail).
 // Inputs: act (with slacks), z, y, s are current.  pr uses only feasibility; du is measured on the dual working set.
-__global__ __launch_bounds__(1024) void k_face_kkt(AsPtrs A, AsSets D) {
+__global__ __launch_bounds__(1024) void k_face_kkt(AsmBt abt, AsPtrs A, AsSets D) {
+    ASM_BARGS(abt, A, D);
     __shared__ double sh[16];
     double pr = 0.0, du = 0.0;
     for (int64_t i = threadIdx.x; i < A.M; i += 1024) {
@@ -606,7 +624,8 @@ __global__ __launch_bounds__(1024) void k_face_kkt(AsPtrs A, AsSets D) {
 }
 
 // copy of a working set
-__global__ __launch_bounds__(256) void k_as_copy_sets(AsSets dst, AsSets src, int64_t M, int64_t n, int64_t ns) {
+__global__ __launch_bounds__(256) void k_as_copy_sets(AsmBt abt, AsSets dst, AsSets src, int64_t M, int64_t n, int64_t ns) {
+    ASM_BARGS(abt, dst, src, M, n, ns);
     int64_t t = blockIdx.x * 256 + threadIdx.x;
     if (t < M) dst.rowst[t] = src.rowst[t];
     if (t < n) dst.bst[t] = src.bst[t];

@@ -36,9 +36,9 @@ __device__ __forceinline__ double fn_value(const FnStore& F, int64_t r, const do
 }
 // eval_constraint + eval_constraint_jacobian of the affine / quadratic rows (MOI_wrapper.jl:875-944): one thread per row
 // (blockIdx.y = trial point of a batched line search: x and E advance by ldx / ldE per trial; the Jacobian is only written for one point)
-__global__ __launch_bounds__(256) void k_fn_rows(FnStore F, const double* __restrict__ x, double* __restrict__ E, double* __restrict__ dE,
-                                                 int write_jac, int64_t ldx, int64_t ldE) {
+__global__ __launch_bounds__(256) void k_fn_rows(AsmBt abt, FnStore F, const double* __restrict__ x, double* __restrict__ E, double* __restrict__ dE, int write_jac, int64_t ldx, int64_t ldE) {
 #pragma clang fp contract(off)
+    ASM_BARGS(abt, F, x, E, dE, write_jac, ldx, ldE);
     int64_t r = blockIdx.x * 256 + threadIdx.x;
     if (r >= F.n_rows) return;
     x += blockIdx.y * ldx;
@@ -58,8 +58,9 @@ __global__ __launch_bounds__(256) void k_fn_rows(FnStore F, const double* __rest
 // (blockIdx.x = trial point.)  The terms are formed by all threads - each behind two or three dependent loads, which one thread walking the
 // list pays one after the other: 226 us for the 2 000 terms of the dense synthetic objective - and ADDED by one thread in list order, so the
 // sum is the reference's, bit for bit.
-__global__ __launch_bounds__(256) void k_fn_objective(FnStore F, const double* __restrict__ x, double* __restrict__ f_out, int64_t ldx) {
+__global__ __launch_bounds__(256) void k_fn_objective(AsmBt abt, FnStore F, const double* __restrict__ x, double* __restrict__ f_out, int64_t ldx) {
 #pragma clang fp contract(off)
+    ASM_BARGS(abt, F, x, f_out, ldx);
     __shared__ double term[1024];
     x += blockIdx.x * ldx;
     const int64_t r = F.n_rows;
@@ -87,8 +88,9 @@ __global__ __launch_bounds__(256) void k_fn_objective(FnStore F, const double* _
     if (threadIdx.x == 0) f_out[blockIdx.x] = F.objective_scale * v;
 }
 // fill_gradient! (MOI_wrapper.jl:827-850): one thread per variable sums its contributions in term order
-__global__ __launch_bounds__(256) void k_fn_gradient(FnStore F, const double* __restrict__ x, double* __restrict__ df) {
+__global__ __launch_bounds__(256) void k_fn_gradient(AsmBt abt, FnStore F, const double* __restrict__ x, double* __restrict__ df) {
 #pragma clang fp contract(off)
+    ASM_BARGS(abt, F, x, df);
     int64_t j = blockIdx.x * 256 + threadIdx.x;
     if (j >= F.n) return;
     double g = 0.0;
@@ -101,9 +103,8 @@ __global__ __launch_bounds__(256) void k_fn_gradient(FnStore F, const double* __
 // ipar: [nl, va0, vm0, pf0, pt0, qf0, qt0, then f_bus[nl], t_bus[nl]] ; dpar: 10 coefficient arrays of length nl
 // (k_ff_p, k_ff_q, k_tt_p, k_tt_q, a_f, b_f, a_t, b_t).  Rows: pfr, qfr, pto, qto (nl each) from row r0; Jacobian values from
 // j0 in 4 groups x 5 sub-blocks of nl (d/d flow variable, vm_f, vm_t, va_f, va_t).
-__global__ __launch_bounds__(256) void k_nlp_acopf_ohm(const int64_t* __restrict__ ipar, const double* __restrict__ dpar,
-                                                       const double* __restrict__ x, double* __restrict__ E, double* __restrict__ dE,
-                                                       int64_t r0, int64_t j0, int write_jac, int64_t ldx, int64_t ldE) {
+__global__ __launch_bounds__(256) void k_nlp_acopf_ohm(AsmBt abt, const int64_t* __restrict__ ipar, const double* __restrict__ dpar, const double* __restrict__ x, double* __restrict__ E, double* __restrict__ dE, int64_t r0, int64_t j0, int write_jac, int64_t ldx, int64_t ldE) {
+    ASM_BARGS(abt, ipar, dpar, x, E, dE, r0, j0, write_jac, ldx, ldE);
     const int64_t nl = ipar[0];
     int64_t l = blockIdx.x * 256 + threadIdx.x;
     if (l >= nl) return;
@@ -143,9 +144,8 @@ __global__ __launch_bounds__(256) void k_nlp_acopf_ohm(const int64_t* __restrict
 }
 // ---- NLP block 2: dense quadratic rows  g_i = sum_j A_ij x_j + 1/2 Q_ij x_j^2 ,  J_ij = A_ij + Q_ij x_j  (row-major pattern).
 // dpar: A (m x n) then Q (m x n); one wavefront per row.
-__global__ __launch_bounds__(256) void k_nlp_dense_quadratic(const double* __restrict__ dpar, int64_t mrows, int64_t n, const double* __restrict__ x,
-                                                             double* __restrict__ E, double* __restrict__ dE, int64_t r0, int64_t j0, int write_jac,
-                                                             int64_t ldx, int64_t ldE) {
+__global__ __launch_bounds__(256) void k_nlp_dense_quadratic(AsmBt abt, const double* __restrict__ dpar, int64_t mrows, int64_t n, const double* __restrict__ x, double* __restrict__ E, double* __restrict__ dE, int64_t r0, int64_t j0, int write_jac, int64_t ldx, int64_t ldE) {
+    ASM_BARGS(abt, dpar, mrows, n, x, E, dE, r0, j0, write_jac, ldx, ldE);
     int64_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= mrows) return;
     x += blockIdx.y * ldx;
@@ -163,14 +163,15 @@ __global__ __launch_bounds__(256) void k_nlp_dense_quadratic(const double* __res
     if (lane == 0) E[r0 + i] = acc;
 }
 
-__global__ __launch_bounds__(256) void k_axpy_out(const double* __restrict__ x, double alpha, const double* __restrict__ p, double* __restrict__ out, int64_t n) {
+__global__ __launch_bounds__(256) void k_axpy_out(AsmBt abt, const double* __restrict__ x, double alpha, const double* __restrict__ p, double* __restrict__ out, int64_t n) {
+    ASM_BARGS(abt, x, alpha, p, out, n);
     int64_t j = blockIdx.x * 256 + threadIdx.x;
     if (j < n) out[j] = x[j] + alpha * p[j];
 }
 // the trial points of a batched line search: out[t] = x + alpha[t] p, t = blockIdx.y
 struct TrialAlphas { double a[8]; };
-__global__ __launch_bounds__(256) void k_axpy_trials(const double* __restrict__ x, TrialAlphas al, const double* __restrict__ p, double* __restrict__ out, int64_t n,
-                                                     int64_t ldx) {
+__global__ __launch_bounds__(256) void k_axpy_trials(AsmBt abt, const double* __restrict__ x, TrialAlphas al, const double* __restrict__ p, double* __restrict__ out, int64_t n, int64_t ldx) {
+    ASM_BARGS(abt, x, al, p, out, n, ldx);
     int64_t j = blockIdx.x * 256 + threadIdx.x;
     if (j < n) out[blockIdx.y * ldx + j] = x[j] + al.a[blockIdx.y] * p[j];
 }
@@ -182,7 +183,8 @@ struct SlpVecs {
     int64_t n, m;
 };
 // norm_violations (inf and 1 norm), norm_complementarity (inf norm), KT_residuals  - common.jl:35-98
-__global__ __launch_bounds__(1024) void k_slp_norms(SlpVecs V, double* __restrict__ out) {
+__global__ __launch_bounds__(1024) void k_slp_norms(AsmBt abt, SlpVecs V, double* __restrict__ out) {
+    ASM_BARGS(abt, V, out);
     __shared__ double sh[16];
     double vinf = 0.0, v1 = 0.0, cinf = 0.0, den = 0.0, res = 0.0, ndf = 0.0, sc = 0.0;
     for (int64_t i = threadIdx.x; i < V.m; i += 1024) {
@@ -224,9 +226,8 @@ __global__ __launch_bounds__(1024) void k_slp_norms(SlpVecs V, double* __restric
 // alpha = 0), ps = p_slack as 2 entries per row (second NaN when the row has one slack).
 //   mode 0 (phi):        normal  f_trial + nu . viol(Et)                restoration  prim_infeas + alpha * sum(slacks) + nu . viol(lhs)
 //   mode 1 (derivative): normal  df . p - nu . viol(E)                  restoration  sum(slacks) - nu . viol(E - viol(E))
-__global__ __launch_bounds__(1024) void k_slp_merit(SlpVecs V, const double* __restrict__ Et, const double* __restrict__ nu, const double* __restrict__ ps,
-                                                    const double* __restrict__ p, double alpha, int feasibility, double prim_infeas, const double* __restrict__ f_trial,
-                                                    int mode, double* __restrict__ out, TrialAlphas al, int64_t ldE) {
+__global__ __launch_bounds__(1024) void k_slp_merit(AsmBt abt, SlpVecs V, const double* __restrict__ Et, const double* __restrict__ nu, const double* __restrict__ ps, const double* __restrict__ p, double alpha, int feasibility, double prim_infeas, const double* __restrict__ f_trial, int mode, double* __restrict__ out, TrialAlphas al, int64_t ldE) {
+    ASM_BARGS(abt, V, Et, nu, ps, p, alpha, feasibility, prim_infeas, f_trial, mode, out, al, ldE);
     __shared__ double sh[16];
     double pen = 0.0, ssum = 0.0, dfp = 0.0;
     if (gridDim.x > 1) {              // batched line search: one workgroup per trial point

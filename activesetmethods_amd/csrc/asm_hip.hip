@@ -11,6 +11,7 @@
 #include "asm_as_kernels.hip.h"
 #include "asm_ns_kernels.hip.h"
 #include "asm_eval_kernels.hip.h"
+#include "asm_batch.hip.h"
 #include "../../include/asm_hip.h"
 
 #include <sched.h>
@@ -471,7 +472,7 @@ struct Dev {
             }
             if (!h->ahTg_valid) {
                 hipLaunchKernelGGL(k_transpose_dense, dim3((unsigned)((h->n + 63) / 64), (unsigned)((h->M + 63) / 64)), dim3(256), 0, h->stream, h->d_Ah,
-                                   h->ldn, h->M, h->n, h->d_AhTg, h->Mp);
+                                   h->ldn, h->M, h->n, h->d_AhTg, h->Mp, (int64_t)-1);
                 h->ahTg_valid = true;
             }
             int id = begin(ASM_K_GEMV, 2.0 * h->M * h->n, 8.0 * h->M * h->ldn);
@@ -608,7 +609,7 @@ struct Dev {
     void ensure_AhT() {
         if (h->ahT_valid) return;
         hipLaunchKernelGGL(k_transpose_dense, dim3((unsigned)((h->n + 63) / 64), (unsigned)((h->M + 63) / 64)), dim3(256), 0, h->stream, h->d_Ah,
-                           h->ldn, h->M, h->n, h->d_AhT, h->ldT);
+                           h->ldn, h->M, h->n, h->d_AhT, h->ldT, (int64_t)-1);
         h->nzT_valid = false;
         const int nch = (int)(h->ldT / ASM_KC);
         if (!h->dense_fast && nch <= ASM_MAXCHUNKS && h->nnz * 8 <= h->M * h->n) {
@@ -809,10 +810,10 @@ struct Dev {
                 if (h->panel_epoch == 0) h->panel_epoch = 1;
                 // beside the trailing update the register-capped build must be used (its wavefronts have to fit into freed update slots)
                 if (beside_updates)
-                    hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)G), dim3(256), 0, cur, fS, fld, I0, std::min(I1, Ms), Mi, (const double*)h->d_diag0, thr,
+                    asmb::launch_resident(k_chol_panel, dim3((unsigned)G), dim3(256), 0, cur, fS, fld, I0, std::min(I1, Ms), Mi, (const double*)h->d_diag0, thr,
                                        fLinv, h->d_pflags, h->d_ptmo, h->panel_epoch);
                 else
-                    hipLaunchKernelGGL(k_chol_panel_solo, dim3((unsigned)G), dim3(256), 0, cur, fS, fld, I0, std::min(I1, Ms), Mi, (const double*)h->d_diag0, thr,
+                    asmb::launch_resident(k_chol_panel_solo, dim3((unsigned)G), dim3(256), 0, cur, fS, fld, I0, std::min(I1, Ms), Mi, (const double*)h->d_diag0, thr,
                                        fLinv, h->d_pflags, h->d_ptmo, h->panel_epoch);
             } else
             for (int k0 = I0; k0 < I1; k0 += ASM_NB) {
@@ -1246,7 +1247,7 @@ struct Solver {
         if (k <= h->ns_fN.wb) {
             const int kp = (int)round_up(k, 32);
             hipLaunchKernelGGL(k_transpose_dense, dim3((unsigned)((h->ldn + 63) / 64), (unsigned)((k + 63) / 64)), dim3(256), 0, h->stream, (const double*)h->d_nsG, h->ns_ldg,
-                               (int64_t)k, h->ldn, h->d_nsZT, h->ns_fN.ld);
+                               (int64_t)k, h->ldn, h->d_nsZT, h->ns_fN.ld, (int64_t)-1);
             dev.gemm_nt(h->ns_fN.Binv, h->ns_fN.wb, h->d_nsZT, h->ns_fN.ld, nullptr, 0, h->d_nsG, h->ns_ldg, k, (int)h->ldn, kp, 0);
         } else {
             hipLaunchKernelGGL(k_ns_ortho, dim3((unsigned)((h->ldn + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->ns_fN.S, h->ns_fN.ld, k, h->d_nsG, h->ns_ldg, h->ldn);
@@ -3625,7 +3626,7 @@ int asm_test_trsm_rows(asm_handle* h, const double* S, int64_t N, const double* 
         HIPCHK(hipMemset(dX, 0, nrhs * ldr * sizeof(double)));
         HIPCHK(hipMemset(dLt, 0, h->Mp * h->Mp * sizeof(double)));
         for (int64_t r = 0; r < nrhs; ++r) HIPCHK(hipMemcpy(dR + r * ldr, R + r * N, N * sizeof(double), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_transpose_dense, dim3((unsigned)((N + 63) / 64), (unsigned)((N + 63) / 64)), dim3(256), 0, h->stream, (const double*)h->d_S, h->Mp, N, N, dLt, h->Mp);
+        hipLaunchKernelGGL(k_transpose_dense, dim3((unsigned)((N + 63) / 64), (unsigned)((N + 63) / 64)), dim3(256), 0, h->stream, (const double*)h->d_S, h->Mp, N, N, dLt, h->Mp, (int64_t)-1);
         d.trsm_rows(dR, dX, ldr, (int)nrhs, (int)N, backward ? dLt : nullptr);
         HIPCHK(hipStreamSynchronize(h->stream));
         const double* out = backward ? dR : dX;

@@ -119,7 +119,8 @@ __device__ __forceinline__ double slack_sum(const IpmPtrs& P, int64_t i, const d
 }
 
 // residuals + convergence measures; act = Ah p and aty = Ah' y were produced by the gemv kernels
-__global__ __launch_bounds__(1024) void k_ipm_measures(IpmPtrs P, unsigned pub) {
+__global__ __launch_bounds__(1024) void k_ipm_measures(AsmBt abt, IpmPtrs P, unsigned pub) {
+    ASM_BARGS(abt, P, pub);
     __shared__ double sh[16];
     __shared__ bool last;
     double pinf = 0.0, dinf = 0.0, mu = 0.0, ymax = 0.0, rpmax = 0.0;
@@ -174,7 +175,8 @@ __global__ __launch_bounds__(1024) void k_ipm_measures(IpmPtrs P, unsigned pub) 
     scal_publish(P, pub);
 }
 
-__global__ __launch_bounds__(256) void k_ipm_theta(IpmPtrs P, double rho_p) {
+__global__ __launch_bounds__(256) void k_ipm_theta(AsmBt abt, IpmPtrs P, double rho_p) {
+    ASM_BARGS(abt, P, rho_p);
     int64_t t = blockIdx.x * 256 + threadIdx.x;
     if (t < P.n) {
         bool fr = P.ub[t] > P.lb[t];
@@ -200,7 +202,8 @@ __device__ __forceinline__ double mcc_term(double x, double dx, double z, double
     double v = (x + dx) * (z + dz);
     return fmax(fmin(fmax(v, lo), hi) - v, -hi);
 }
-__global__ __launch_bounds__(256) void k_ipm_rhs1(IpmPtrs P, IpmDir A, int mode, double tp, double td, double bmin, double bmax) {
+__global__ __launch_bounds__(256) void k_ipm_rhs1(AsmBt abt, IpmPtrs P, IpmDir A, int mode, double tp, double td, double bmin, double bmax) {
+    ASM_BARGS(abt, P, A, mode, tp, td, bmin, bmax);
     int64_t t = blockIdx.x * 256 + threadIdx.x;
     const double sm = mode ? P.scal[SC_SM] : 0.0;
     const double lo = bmin * sm, hi = bmax * sm;
@@ -247,7 +250,8 @@ __global__ __launch_bounds__(256) void k_ipm_rhs1(IpmPtrs P, IpmDir A, int mode,
 }
 
 // rhs = -rp - Ah(theta hp) + sg rcg/pi - E(ths hs)
-__global__ __launch_bounds__(256) void k_ipm_rhs2(IpmPtrs P, double res) {
+__global__ __launch_bounds__(256) void k_ipm_rhs2(AsmBt abt, IpmPtrs P, double res) {
+    ASM_BARGS(abt, P, res);
     int64_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P.M) return;
     bool ineq = P.rtype[i] != 0;
@@ -260,13 +264,15 @@ __global__ __launch_bounds__(256) void k_ipm_rhs2(IpmPtrs P, double res) {
     P.rhs[i] = v;
 }
 
-__global__ __launch_bounds__(256) void k_vec_mul(double* __restrict__ x, const double* __restrict__ a, int64_t len) {
+__global__ __launch_bounds__(256) void k_vec_mul(AsmBt abt, double* __restrict__ x, const double* __restrict__ a, int64_t len) {
+    ASM_BARGS(abt, x, a, len);
     int64_t t = blockIdx.x * 256 + threadIdx.x;
     if (t < len) x[t] *= a[t];
 }
 
 // res = rhs - (sres + dS dy) ; scal[EMAX] = max|res| ; scal[RMAX] = max(1, max|rhs|)
-__global__ __launch_bounds__(1024) void k_ipm_res(IpmPtrs P, const double* __restrict__ sres, const double* __restrict__ dy, unsigned pub) {
+__global__ __launch_bounds__(1024) void k_ipm_res(AsmBt abt, IpmPtrs P, const double* __restrict__ sres, const double* __restrict__ dy, unsigned pub) {
+    ASM_BARGS(abt, P, sres, dy, pub);
     __shared__ double sh[16];
     double emax = 0.0, rmax = 1.0;
     for (int64_t i = threadIdx.x; i < P.M; i += 1024) {
@@ -286,7 +292,8 @@ __global__ __launch_bounds__(1024) void k_ipm_res(IpmPtrs P, const double* __res
 
 // ---- preconditioned conjugate gradients on  S dy = rhs,  S = Ah Th^-1 Ah' + dS,  preconditioner = the Cholesky factor.
 // p = z ; rz = r'z
-__global__ __launch_bounds__(1024) void k_pcg_start(IpmPtrs P, const double* __restrict__ z, double* __restrict__ p) {
+__global__ __launch_bounds__(1024) void k_pcg_start(AsmBt abt, IpmPtrs P, const double* __restrict__ z, double* __restrict__ p) {
+    ASM_BARGS(abt, P, z, p);
     __shared__ double sh[16];
     double acc = 0.0;
     for (int64_t i = threadIdx.x; i < P.M; i += 1024) {
@@ -302,8 +309,8 @@ __global__ __launch_bounds__(1024) void k_pcg_start(IpmPtrs P, const double* __r
     }
 }
 // Sp = sres + dS p ; alpha = rz / p'Sp ; x += alpha p ; r -= alpha Sp ; scal[EMAX] = max|r|
-__global__ __launch_bounds__(1024) void k_pcg_step1(IpmPtrs P, const double* __restrict__ sres, const double* __restrict__ p,
-                                                    double* __restrict__ x, unsigned pub) {
+__global__ __launch_bounds__(1024) void k_pcg_step1(AsmBt abt, IpmPtrs P, const double* __restrict__ sres, const double* __restrict__ p, double* __restrict__ x, unsigned pub) {
+    ASM_BARGS(abt, P, sres, p, x, pub);
     __shared__ double sh[16];
     double acc = 0.0;
     for (int64_t i = threadIdx.x; i < P.M; i += 1024) acc += p[i] * (sres[i] + P.dS[i] * p[i]);
@@ -328,7 +335,8 @@ __global__ __launch_bounds__(1024) void k_pcg_step1(IpmPtrs P, const double* __r
     scal_publish(P, pub);
 }
 // beta = r'z / rz_old ; p = z + beta p ; rz = r'z
-__global__ __launch_bounds__(1024) void k_pcg_step2(IpmPtrs P, const double* __restrict__ z, double* __restrict__ p) {
+__global__ __launch_bounds__(1024) void k_pcg_step2(AsmBt abt, IpmPtrs P, const double* __restrict__ z, double* __restrict__ p) {
+    ASM_BARGS(abt, P, z, p);
     __shared__ double sh[16];
     double acc = 0.0;
     for (int64_t i = threadIdx.x; i < P.M; i += 1024) acc += P.res[i] * z[i];
@@ -340,7 +348,8 @@ __global__ __launch_bounds__(1024) void k_pcg_step2(IpmPtrs P, const double* __r
 }
 
 // Newton direction from dy and aty2 = Ah' dy (in P.aty is NOT touched; tN holds Ah' dy)
-__global__ __launch_bounds__(256) void k_ipm_dir(IpmPtrs P, IpmDir D, const double* __restrict__ tN) {
+__global__ __launch_bounds__(256) void k_ipm_dir(AsmBt abt, IpmPtrs P, IpmDir D, const double* __restrict__ tN) {
+    ASM_BARGS(abt, P, D, tN);
     int64_t t = blockIdx.x * 256 + threadIdx.x;
     if (t < P.n) {
         bool fr = P.ub[t] > P.lb[t];
@@ -365,7 +374,8 @@ __global__ __launch_bounds__(256) void k_ipm_dir(IpmPtrs P, IpmDir D, const doub
 __device__ __forceinline__ double ratio(double x, double dx) { return dx < 0.0 ? -x / dx : 1e300; }
 
 // step lengths to the boundary (ap primal, ad dual), each capped at 1
-__global__ __launch_bounds__(1024) void k_ipm_steps(IpmPtrs P, IpmDir D, unsigned pub) {
+__global__ __launch_bounds__(1024) void k_ipm_steps(AsmBt abt, IpmPtrs P, IpmDir D, unsigned pub) {
+    ASM_BARGS(abt, P, D, pub);
     __shared__ double sh[16];
     __shared__ bool last;
     double ap = 1e300, ad = 1e300;
@@ -400,7 +410,8 @@ __global__ __launch_bounds__(1024) void k_ipm_steps(IpmPtrs P, IpmDir D, unsigne
 }
 
 // mu_aff -> sigma = (mu_aff/mu)^3 -> sm = sigma mu
-__global__ __launch_bounds__(1024) void k_ipm_muaff(IpmPtrs P, IpmDir A) {
+__global__ __launch_bounds__(1024) void k_ipm_muaff(AsmBt abt, IpmPtrs P, IpmDir A) {
+    ASM_BARGS(abt, P, A);
     __shared__ double sh[16];
     __shared__ bool last;
     const double ap = P.scal[SC_AP], ad = P.scal[SC_AD];
@@ -431,7 +442,8 @@ __global__ __launch_bounds__(1024) void k_ipm_muaff(IpmPtrs P, IpmDir A) {
 }
 
 // D += E (candidate direction of a centrality corrector)
-__global__ __launch_bounds__(256) void k_ipm_diradd(IpmPtrs P, IpmDir D, IpmDir E) {
+__global__ __launch_bounds__(256) void k_ipm_diradd(AsmBt abt, IpmPtrs P, IpmDir D, IpmDir E) {
+    ASM_BARGS(abt, P, D, E);
     int64_t t = blockIdx.x * 256 + threadIdx.x;
     if (t < P.n) {
         D.dp[t] += E.dp[t];
@@ -450,7 +462,8 @@ __global__ __launch_bounds__(256) void k_ipm_diradd(IpmPtrs P, IpmDir D, IpmDir 
 }
 
 // iterate += (al primal, be dual) * direction
-__global__ __launch_bounds__(256) void k_ipm_update(IpmPtrs P, IpmDir C, double al, double be) {
+__global__ __launch_bounds__(256) void k_ipm_update(AsmBt abt, IpmPtrs P, IpmDir C, double al, double be) {
+    ASM_BARGS(abt, P, C, al, be);
     int64_t t = blockIdx.x * 256 + threadIdx.x;
     if (t < P.n) {
         bool fr = P.ub[t] > P.lb[t];
@@ -475,12 +488,14 @@ __global__ __launch_bounds__(256) void k_ipm_update(IpmPtrs P, IpmDir C, double 
 }
 
 // starting point (oracle: IPM.__init__); act = Ah p0 must already be in P.act
-__global__ __launch_bounds__(256) void k_ipm_init_p(IpmPtrs P) {
+__global__ __launch_bounds__(256) void k_ipm_init_p(AsmBt abt, IpmPtrs P) {
+    ASM_BARGS(abt, P);
     int64_t t = blockIdx.x * 256 + threadIdx.x;
     if (t < P.n) P.p[t] = 0.5 * (P.lb[t] + P.ub[t]);
     if (t < P.ns) P.s[t] = P.slo[t] + 1.0;
 }
-__global__ __launch_bounds__(256) void k_ipm_init_rest(IpmPtrs P) {
+__global__ __launch_bounds__(256) void k_ipm_init_rest(AsmBt abt, IpmPtrs P) {
+    ASM_BARGS(abt, P);
     int64_t t = blockIdx.x * 256 + threadIdx.x;
     const double mu0 = P.scale_q;
     if (t < P.n) {
@@ -510,7 +525,8 @@ __global__ __launch_bounds__(256) void k_ipm_init_rest(IpmPtrs P) {
 
 // ---- column form of the Newton system (restoration LPs): K = Th + Ah' D^-1 Ah, preconditioner by Sherman-Morrison-Woodbury
 // dinv = 1/dS (rows; the padding up to the k-chunk multiple stays 0), th = Theta + rho_p for free columns, `fixed` else
-__global__ __launch_bounds__(256) void k_ipm_col_prep(IpmPtrs P, double rho_p, double fixed, double* __restrict__ dinv, double* __restrict__ th) {
+__global__ __launch_bounds__(256) void k_ipm_col_prep(AsmBt abt, IpmPtrs P, double rho_p, double fixed, double* __restrict__ dinv, double* __restrict__ th) {
+    ASM_BARGS(abt, P, rho_p, fixed, dinv, th);
     int64_t t = blockIdx.x * 256 + threadIdx.x;
     if (t < P.M) dinv[t] = 1.0 / P.dS[t];
     if (t < P.n) {
@@ -519,21 +535,22 @@ __global__ __launch_bounds__(256) void k_ipm_col_prep(IpmPtrs P, double rho_p, d
     }
 }
 // u = dinv .* r
-__global__ __launch_bounds__(256) void k_col_scale(const double* __restrict__ dinv, const double* __restrict__ r, double* __restrict__ u, int64_t M) {
+__global__ __launch_bounds__(256) void k_col_scale(AsmBt abt, const double* __restrict__ dinv, const double* __restrict__ r, double* __restrict__ u, int64_t M) {
+    ASM_BARGS(abt, dinv, r, u, M);
     int64_t t = blockIdx.x * 256 + threadIdx.x;
     if (t < M) u[t] = dinv[t] * r[t];
 }
 // out = u - dinv .* w
-__global__ __launch_bounds__(256) void k_col_finish(const double* __restrict__ dinv, const double* __restrict__ u, const double* __restrict__ w,
-                                                    double* __restrict__ out, int64_t M) {
+__global__ __launch_bounds__(256) void k_col_finish(AsmBt abt, const double* __restrict__ dinv, const double* __restrict__ u, const double* __restrict__ w, double* __restrict__ out, int64_t M) {
+    ASM_BARGS(abt, dinv, u, w, out, M);
     int64_t t = blockIdx.x * 256 + threadIdx.x;
     if (t < M) out[t] = u[t] - dinv[t] * w[t];
 }
 
 // ---- reduced row form (normal phase of large sparse problems): s_ii = sum_j Ah_ij^2 / Th_j over the CSR copy of the pattern,
 // gather / scatter between the full row space and the factored subset E, diagonal preconditioner on the dropped rows I
-__global__ __launch_bounds__(256) void k_ipm_sdiag_csr(const int* __restrict__ ptr, const int* __restrict__ col, const double* __restrict__ vals,
-                                                       const double* __restrict__ thinv, double* __restrict__ out, int64_t M) {
+__global__ __launch_bounds__(256) void k_ipm_sdiag_csr(AsmBt abt, const int* __restrict__ ptr, const int* __restrict__ col, const double* __restrict__ vals, const double* __restrict__ thinv, double* __restrict__ out, int64_t M) {
+    ASM_BARGS(abt, ptr, col, vals, thinv, out, M);
     int64_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= M) return;
     double acc = 0.0;
@@ -544,13 +561,14 @@ __global__ __launch_bounds__(256) void k_ipm_sdiag_csr(const int* __restrict__ p
     out[i] = acc;
 }
 // ce[a] = r[E[a]]
-__global__ __launch_bounds__(256) void k_red_gather(const int* __restrict__ E, int nE, const double* __restrict__ r, double* __restrict__ ce) {
+__global__ __launch_bounds__(256) void k_red_gather(AsmBt abt, const int* __restrict__ E, int nE, const double* __restrict__ r, double* __restrict__ ce) {
+    ASM_BARGS(abt, E, nE, r, ce);
     int a = blockIdx.x * 256 + threadIdx.x;
     if (a < nE) ce[a] = r[E[a]];
 }
 // z[E[a]] = ze[a] ; z[I[b]] = r[I[b]] / dI[b]
-__global__ __launch_bounds__(256) void k_red_scatter(const int* __restrict__ E, int nE, const double* __restrict__ ze, const int* __restrict__ I,
-                                                     int nI, const double* __restrict__ dI, const double* __restrict__ r, double* __restrict__ z) {
+__global__ __launch_bounds__(256) void k_red_scatter(AsmBt abt, const int* __restrict__ E, int nE, const double* __restrict__ ze, const int* __restrict__ I, int nI, const double* __restrict__ dI, const double* __restrict__ r, double* __restrict__ z) {
+    ASM_BARGS(abt, E, nE, ze, I, nI, dI, r, z);
     int a = blockIdx.x * 256 + threadIdx.x;
     if (a < nE) z[E[a]] = ze[a];
     if (a < nI) z[I[a]] = r[I[a]] / dI[a];

@@ -18,6 +18,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "asm_bt.hip.h"
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
@@ -31,9 +32,8 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 // original j_str order (perm is a stable sort), starting from 0.0 exactly like `J[r,c] += dE[k]`.
 // `adj_off` (>=0) is the image of that entry in the extra `<=` row of a range constraint; it is
 // refreshed only when one of the terms is non-zero (stored-entry semantics of subproblem.jl:448-457).
-__global__ void k_assemble(const double* __restrict__ dE, const int64_t* __restrict__ perm,
-                           const int64_t* __restrict__ ustart, const int64_t* __restrict__ uoff,
-                           const int64_t* __restrict__ adj_off, double* __restrict__ J, int64_t nu) {
+__global__ void k_assemble(AsmBt abt, const double* __restrict__ dE, const int64_t* __restrict__ perm, const int64_t* __restrict__ ustart, const int64_t* __restrict__ uoff, const int64_t* __restrict__ adj_off, double* __restrict__ J, int64_t nu) {
+    ASM_BARGS(abt, dE, perm, ustart, uoff, adj_off, J, nu);
     for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u < nu; u += (int64_t)gridDim.x * blockDim.x) {
         double acc = 0.0;
         bool any = false;
@@ -49,7 +49,8 @@ __global__ void k_assemble(const double* __restrict__ dE, const int64_t* __restr
 }
 
 // Fast path when the pattern is duplicate-free and already row-major dense (config C2): a strided copy.
-__global__ void k_assemble_dense(const double* __restrict__ dE, double* __restrict__ J, int64_t m, int64_t n, int64_t ldn) {
+__global__ void k_assemble_dense(AsmBt abt, const double* __restrict__ dE, double* __restrict__ J, int64_t m, int64_t n, int64_t ldn) {
+    ASM_BARGS(abt, dE, J, m, n, ldn);
     int64_t total = m * n;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         int64_t i = t / n, j = t - i * n;
@@ -75,8 +76,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // One workgroup per row: rho_i = pow2(max_j |J_ij c_j|),  Ah_ij = J_ij c_j / rho_i  (all factors are powers of two).
-__global__ __launch_bounds__(256) void k_scale_rows(const double* __restrict__ J, const double* __restrict__ c,
-                                                    double* __restrict__ Ah, double* __restrict__ rho, int64_t n, int64_t ldn) {
+__global__ __launch_bounds__(256) void k_scale_rows(AsmBt abt, const double* __restrict__ J, const double* __restrict__ c, double* __restrict__ Ah, double* __restrict__ rho, int64_t n, int64_t ldn) {
+    ASM_BARGS(abt, J, c, Ah, rho, n, ldn);
     __shared__ double red[4];
     __shared__ double s_inv;
     int64_t i = blockIdx.x;
@@ -99,8 +100,8 @@ __global__ __launch_bounds__(256) void k_scale_rows(const double* __restrict__ J
 }
 
 // out[i] = sum_j A[i,j] x[j]   (one wavefront per row, 16-byte loads along the row)
-__global__ __launch_bounds__(256) void k_gemv_n(const double* __restrict__ A, int64_t ld, const double* __restrict__ x,
-                                                double* __restrict__ out, int64_t M, int64_t ncols) {
+__global__ __launch_bounds__(256) void k_gemv_n(AsmBt abt, const double* __restrict__ A, int64_t ld, const double* __restrict__ x, double* __restrict__ out, int64_t M, int64_t ncols) {
+    ASM_BARGS(abt, A, ld, x, out, M, ncols);
     int64_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= M) return;
     int lane = threadIdx.x & 63;
@@ -120,8 +121,8 @@ __global__ __launch_bounds__(256) void k_gemv_n(const double* __restrict__ A, in
 
 // the same product for FEW LONG rows (the k x n basis of the null-space form: 519 rows of 11 192): one workgroup per row, so that four times
 // as many wavefronts keep loads in flight (one wavefront per row: 28 us = 1.6 TB/s for 46 MB)
-__global__ __launch_bounds__(256) void k_gemv_n_wide(const double* __restrict__ A, int64_t ld, const double* __restrict__ x,
-                                                     double* __restrict__ out, int64_t M, int64_t ncols) {
+__global__ __launch_bounds__(256) void k_gemv_n_wide(AsmBt abt, const double* __restrict__ A, int64_t ld, const double* __restrict__ x, double* __restrict__ out, int64_t M, int64_t ncols) {
+    ASM_BARGS(abt, A, ld, x, out, M, ncols);
     __shared__ double red[4];
     const int64_t i = blockIdx.x;
     const double2* row = reinterpret_cast<const double2*>(A + i * ld);
@@ -142,8 +143,8 @@ __global__ __launch_bounds__(256) void k_gemv_n_wide(const double* __restrict__ 
 
 // out[i] = sum_{j < ncols} A[i,j] x[j] with ncols exact (entries of x beyond ncols are not touched): one wavefront per row.  The transposed
 // product A'y of a DENSE matrix through its transposed copy - one launch of 5 us instead of the two-stage column reduction (13 us at 500 x 1000).
-__global__ __launch_bounds__(256) void k_gemv_n_exact(const double* __restrict__ A, int64_t ld, const double* __restrict__ x,
-                                                      double* __restrict__ out, int64_t rows, int64_t ncols) {
+__global__ __launch_bounds__(256) void k_gemv_n_exact(AsmBt abt, const double* __restrict__ A, int64_t ld, const double* __restrict__ x, double* __restrict__ out, int64_t rows, int64_t ncols) {
+    ASM_BARGS(abt, A, ld, x, out, rows, ncols);
     int64_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -156,8 +157,8 @@ __global__ __launch_bounds__(256) void k_gemv_n_exact(const double* __restrict__
 
 // partial[r][j] = sum_{i in row chunk r} A[i,j] y[i]   ; second stage sums the chunks in order (deterministic).
 #define ASM_TMAXCHUNKS 128
-__global__ __launch_bounds__(256) void k_gemv_t_stage1(const double* __restrict__ A, int64_t ld, const double* __restrict__ y,
-                                                       double* __restrict__ partial, int64_t M, int64_t ncols, int64_t chunk) {
+__global__ __launch_bounds__(256) void k_gemv_t_stage1(AsmBt abt, const double* __restrict__ A, int64_t ld, const double* __restrict__ y, double* __restrict__ partial, int64_t M, int64_t ncols, int64_t chunk) {
+    ASM_BARGS(abt, A, ld, y, partial, M, ncols, chunk);
     int64_t j = blockIdx.x * 256 + threadIdx.x;
     int64_t r = blockIdx.y;
     int64_t i0 = r * chunk, i1 = i0 + chunk;
@@ -167,8 +168,8 @@ __global__ __launch_bounds__(256) void k_gemv_t_stage1(const double* __restrict_
     for (int64_t i = i0; i < i1; ++i) acc = fma(A[i * ld + j], y[i], acc);
     partial[r * ncols + j] = acc;
 }
-__global__ __launch_bounds__(256) void k_gemv_t_stage2(const double* __restrict__ partial, double* __restrict__ out,
-                                                       int64_t R, int64_t ncols) {
+__global__ __launch_bounds__(256) void k_gemv_t_stage2(AsmBt abt, const double* __restrict__ partial, double* __restrict__ out, int64_t R, int64_t ncols) {
+    ASM_BARGS(abt, partial, out, R, ncols);
     int64_t j = blockIdx.x * 256 + threadIdx.x;
     if (j >= ncols) return;
     double acc = 0.0;
@@ -228,10 +229,8 @@ __device__ __forceinline__ bool tri_tile_xcd(int ntr, int& bi, int& bj, bool dea
 // KC = k-chunk staged through LDS (32: 139 KB of LDS, one workgroup per CU; 16: 74 KB and <= 128 VGPRs, two per CU -
 // used for the Cholesky updates so that the latency-bound panel kernels of the look-ahead stream can share the CUs).
 template <int T, int NW, int KC, int WPE>
-__global__ __launch_bounds__(64 * NW, WPE) void k_syrk(const double* __restrict__ A, int64_t ld, const int* __restrict__ idx, int64_t row0,
-                                              int Ms, int K, const double* __restrict__ theta, const double* __restrict__ diag,
-                                              double* __restrict__ S, int64_t ldS, int64_t srow0, int mode, int MsB, int ntj,
-                                              const unsigned char* __restrict__ nzflags, int nzpitch, int64_t ksplit) {
+__global__ __launch_bounds__(64 * NW, WPE) void k_syrk(AsmBt abt, const double* __restrict__ A, int64_t ld, const int* __restrict__ idx, int64_t row0, int Ms, int K, const double* __restrict__ theta, const double* __restrict__ diag, double* __restrict__ S, int64_t ldS, int64_t srow0, int mode, int MsB, int ntj, const unsigned char* __restrict__ nzflags, int nzpitch, int64_t ksplit) {
+    ASM_BARGS(abt, A, ld, idx, row0, Ms, K, theta, diag, S, ldS, srow0, mode, MsB, ntj, nzflags, nzpitch, ksplit);
     constexpr int TS = 32 * T;
     if (gridDim.y > 1) {
         // split-K (small matrices with a long k range: the k x k Newton matrix of the null-space form): slice blockIdx.y of the
@@ -420,8 +419,8 @@ __device__ __forceinline__ void glds16(const double* gsrc, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_syrk_upd(const double* __restrict__ A, int64_t ld, int64_t row0, int Ms, int K, double* __restrict__ S, int64_t ldS, int64_t srow0,
-                int MsB, int ntj) {
+void k_syrk_upd(AsmBt abt, const double* __restrict__ A, int64_t ld, int64_t row0, int Ms, int K, double* __restrict__ S, int64_t ldS, int64_t srow0, int MsB, int ntj) {
+    ASM_BARGS(abt, A, ld, row0, Ms, K, S, ldS, srow0, MsB, ntj);
     constexpr int TS = ASM_UPD_TS, KC = ASM_UPD_KC;
     constexpr int STG = 2 * TS * KC;                                           // doubles per stage: A image (8 KB), then B image (8 KB)
     __shared__ __attribute__((aligned(1024))) double lds[4 * STG];            // 64 KB
@@ -548,8 +547,8 @@ void k_syrk_upd(const double* __restrict__ A, int64_t ld, int64_t row0, int Ms, 
 }
 
 // diag0[i] = S_ii ; then S_ii += reg.   mode 0: reg_i = rel*S_ii + absv ;  mode 1: reg = rel*max(max_i S_ii, 1e-300)
-__global__ __launch_bounds__(1024) void k_diag_prepare(double* __restrict__ S, int64_t ldS, int Ms, double* __restrict__ diag0,
-                                                       int mode, double rel, double absv) {
+__global__ __launch_bounds__(1024) void k_diag_prepare(AsmBt abt, double* __restrict__ S, int64_t ldS, int Ms, double* __restrict__ diag0, int mode, double rel, double absv) {
+    ASM_BARGS(abt, S, ldS, Ms, diag0, mode, rel, absv);
     __shared__ double red[16];
     __shared__ double s_max;
     double mx = 0.0;
@@ -757,8 +756,8 @@ __device__ __forceinline__ void potrf64_body(double* __restrict__ D, double* __r
         else out[e] = v;
     }
 }
-__global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int64_t ldS, int k0, int nb,
-                                                    const double* __restrict__ diag0, double thr, double* __restrict__ Linv) {
+__global__ __launch_bounds__(256) void k_potrf_diag(AsmBt abt, double* __restrict__ S, int64_t ldS, int k0, int nb, const double* __restrict__ diag0, double thr, double* __restrict__ Linv) {
+    ASM_BARGS(abt, S, ldS, k0, nb, diag0, thr, Linv);
     __shared__ double D[ASM_NB * ASM_DP];
     __shared__ double W[ASM_NB * ASM_DP];
     __shared__ potrf_T_t T[4];
@@ -772,8 +771,8 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int6
 // row-major Linv itself; both operands sit in LDS with pitch = 2 mod 32 doubles (conflict-free fragment reads).  Linv is
 // lower triangular with explicit zeros above the diagonal, so the full product is the triangular one.
 #define ASM_XP 66
-__global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ S, int64_t ldS, int k0, int nb, int Ms,
-                                                    const double* __restrict__ Linv) {
+__global__ __launch_bounds__(256) void k_trsm_panel(AsmBt abt, double* __restrict__ S, int64_t ldS, int k0, int nb, int Ms, const double* __restrict__ Linv) {
+    ASM_BARGS(abt, S, ldS, k0, nb, Ms, Linv);
     __shared__ double Xa[ASM_NB * ASM_XP];      // the tile  X[r][q]
     __shared__ double Li[ASM_NB * ASM_XP];      // Linv[c][q]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -814,7 +813,8 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ S, int6
 // (c <= r), P = S[:, k0:k0+64] the panel just solved.  One workgroup per 64 x 64 tile: both operand tiles are staged whole
 // (pitch = 2 mod 32 doubles), 16 k-steps of v_mfma_f64_16x16x4_f64 per wavefront, the accumulators start from the S tile
 // and the left operand is negated - the generic k_syrk pays its k-chunk pipeline and 128 x 128 tiles for K = 64.
-__global__ __launch_bounds__(256) void k_panel_update64(double* __restrict__ S, int64_t ldS, int k0, int k1, int c_end, int Ms) {
+__global__ __launch_bounds__(256) void k_panel_update64(AsmBt abt, double* __restrict__ S, int64_t ldS, int k0, int k1, int c_end, int Ms) {
+    ASM_BARGS(abt, S, ldS, k0, k1, c_end, Ms);
     __shared__ double Pa[ASM_NB * ASM_XP];
     __shared__ double Pb[ASM_NB * ASM_XP];
     const int ti = blockIdx.x, tj = blockIdx.y;
@@ -899,7 +899,8 @@ __device__ __forceinline__ void pnl_wait(unsigned* flag, unsigned epoch, unsigne
     __syncthreads();
 }
 // test hook: workgroups waiting for a flag that no producer of the launch sets (the bounded spin must end and report)
-__global__ __launch_bounds__(256) void k_pnl_wait_probe(unsigned* flag, unsigned epoch, unsigned* tmo) {
+__global__ __launch_bounds__(256) void k_pnl_wait_probe(AsmBt abt, unsigned* flag, unsigned epoch, unsigned* tmo) {
+    ASM_BARGS(abt, flag, epoch, tmo);
     pnl_wait(flag, epoch, tmo);
 }
 #define ASM_PNL_LDS (2 * ASM_NB * ASM_XP + 4 * 16 * 17 + 2 * ASM_NB)
@@ -1067,22 +1068,20 @@ __device__ __forceinline__ void chol_panel_body(double* __restrict__ sm, double*
 
 // k_chol_panel: the version that runs BESIDE the trailing update (look-ahead stream), capped at 256 registers;
 // k_chol_panel_solo: the same body without the cap (312 registers, no spills) for chains that have the chip to themselves.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chol_panel(double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms,
-                                                    const double* __restrict__ diag0, double thr, double* __restrict__ Linv,
-                                                    unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chol_panel(AsmBt abt, double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms, const double* __restrict__ diag0, double thr, double* __restrict__ Linv, unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch) {
+    ASM_BARGS(abt, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch);
     __shared__ __attribute__((aligned(16))) double sm[ASM_PNL_LDS];
     chol_panel_body(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch);
 }
-__global__ __launch_bounds__(256) void k_chol_panel_solo(double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms,
-                                                         const double* __restrict__ diag0, double thr, double* __restrict__ Linv,
-                                                         unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch) {
+__global__ __launch_bounds__(256) void k_chol_panel_solo(AsmBt abt, double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms, const double* __restrict__ diag0, double thr, double* __restrict__ Linv, unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch) {
+    ASM_BARGS(abt, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch);
     __shared__ __attribute__((aligned(16))) double sm[ASM_PNL_LDS];
     chol_panel_body(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch);
 }
 
 // out[i] = || A[i, :] ||_2   (one wavefront per row) - KT_residuals / compute_nu! (common.jl:41, slp.jl:58)
-__global__ __launch_bounds__(256) void k_row_norms(const double* __restrict__ A, int64_t ld, double* __restrict__ out, int64_t M,
-                                                   int64_t ncols) {
+__global__ __launch_bounds__(256) void k_row_norms(AsmBt abt, const double* __restrict__ A, int64_t ld, double* __restrict__ out, int64_t M, int64_t ncols) {
+    ASM_BARGS(abt, A, ld, out, M, ncols);
     int64_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= M) return;
     int lane = threadIdx.x & 63;
@@ -1095,8 +1094,8 @@ __global__ __launch_bounds__(256) void k_row_norms(const double* __restrict__ A,
 
 // Scaling helpers (oracle/lp_solver.py: scale_lp): rmax[i] = max_j |J_ij| (1 if the row is empty), then
 // rel[j] = max_i |J_ij| / rmax[i] with the same deterministic two-stage column reduction as k_gemv_t.
-__global__ __launch_bounds__(256) void k_row_absmax(const double* __restrict__ A, int64_t ld, double* __restrict__ out, int64_t M,
-                                                    int64_t ncols) {
+__global__ __launch_bounds__(256) void k_row_absmax(AsmBt abt, const double* __restrict__ A, int64_t ld, double* __restrict__ out, int64_t M, int64_t ncols) {
+    ASM_BARGS(abt, A, ld, out, M, ncols);
     int64_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= M) return;
     int lane = threadIdx.x & 63;
@@ -1106,8 +1105,8 @@ __global__ __launch_bounds__(256) void k_row_absmax(const double* __restrict__ A
     mx = wave_max(mx);
     if (lane == 0) out[i] = mx > 0.0 ? mx : 1.0;
 }
-__global__ __launch_bounds__(256) void k_col_relmax_stage1(const double* __restrict__ A, int64_t ld, const double* __restrict__ rmax,
-                                                           double* __restrict__ partial, int64_t M, int64_t ncols, int64_t chunk) {
+__global__ __launch_bounds__(256) void k_col_relmax_stage1(AsmBt abt, const double* __restrict__ A, int64_t ld, const double* __restrict__ rmax, double* __restrict__ partial, int64_t M, int64_t ncols, int64_t chunk) {
+    ASM_BARGS(abt, A, ld, rmax, partial, M, ncols, chunk);
     int64_t j = blockIdx.x * 256 + threadIdx.x;
     int64_t r = blockIdx.y;
     int64_t i0 = r * chunk, i1 = i0 + chunk;
@@ -1117,8 +1116,8 @@ __global__ __launch_bounds__(256) void k_col_relmax_stage1(const double* __restr
     for (int64_t i = i0; i < i1; ++i) mx = fmax(mx, fabs(A[i * ld + j]) / rmax[i]);
     partial[r * ncols + j] = mx;
 }
-__global__ __launch_bounds__(256) void k_col_relmax_stage2(const double* __restrict__ partial, double* __restrict__ out, int64_t R,
-                                                           int64_t ncols) {
+__global__ __launch_bounds__(256) void k_col_relmax_stage2(AsmBt abt, const double* __restrict__ partial, double* __restrict__ out, int64_t R, int64_t ncols) {
+    ASM_BARGS(abt, partial, out, R, ncols);
     int64_t j = blockIdx.x * 256 + threadIdx.x;
     if (j >= ncols) return;
     double mx = 0.0;
@@ -1128,16 +1127,16 @@ __global__ __launch_bounds__(256) void k_col_relmax_stage2(const double* __restr
 
 // The same three scaling passes on the CSR / CSC pattern of a sparse Jacobian (values gathered in pattern order: v[k] = J[off[k]]): the
 // maxima are order-independent, so the results are those of the dense kernels - which spend 0.9 ms per pass on the zeros at 18 637 x 11 192.
-__global__ __launch_bounds__(256) void k_sp_row_absmax(const int* __restrict__ ptr, const double* __restrict__ v, double* __restrict__ out, int64_t M) {
+__global__ __launch_bounds__(256) void k_sp_row_absmax(AsmBt abt, const int* __restrict__ ptr, const double* __restrict__ v, double* __restrict__ out, int64_t M) {
+    ASM_BARGS(abt, ptr, v, out, M);
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= M) return;
     double mx = 0.0;
     for (int k = ptr[i]; k < ptr[i + 1]; ++k) mx = fmax(mx, fabs(v[k]));
     out[i] = mx > 0.0 ? mx : 1.0;
 }
-__global__ __launch_bounds__(256) void k_sp_col_relmax(const int* __restrict__ cptr, const int* __restrict__ crow, const int* __restrict__ cpos,
-                                                       const double* __restrict__ v, const double* __restrict__ rmax, double* __restrict__ out,
-                                                       int64_t n, int64_t ncols) {
+__global__ __launch_bounds__(256) void k_sp_col_relmax(AsmBt abt, const int* __restrict__ cptr, const int* __restrict__ crow, const int* __restrict__ cpos, const double* __restrict__ v, const double* __restrict__ rmax, double* __restrict__ out, int64_t n, int64_t ncols) {
+    ASM_BARGS(abt, cptr, crow, cpos, v, rmax, out, n, ncols);
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= ncols) return;
     double mx = 0.0;
@@ -1147,9 +1146,8 @@ __global__ __launch_bounds__(256) void k_sp_col_relmax(const int* __restrict__ c
 }
 // rho_i = pow2(max |J_ij c_j|), Ah_ij = J_ij c_j / rho_i at the pattern's entries (the rest of the dense copy is zero and stays zero), and the
 // same values in pattern order (vAh)
-__global__ __launch_bounds__(256) void k_sp_scale_rows(const int* __restrict__ ptr, const int* __restrict__ col, const int64_t* __restrict__ off,
-                                                       const double* __restrict__ vJ, const double* __restrict__ c, double* __restrict__ Ah,
-                                                       double* __restrict__ vAh, double* __restrict__ rho, int64_t M) {
+__global__ __launch_bounds__(256) void k_sp_scale_rows(AsmBt abt, const int* __restrict__ ptr, const int* __restrict__ col, const int64_t* __restrict__ off, const double* __restrict__ vJ, const double* __restrict__ c, double* __restrict__ Ah, double* __restrict__ vAh, double* __restrict__ rho, int64_t M) {
+    ASM_BARGS(abt, ptr, col, off, vJ, c, Ah, vAh, rho, M);
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= M) return;
     double mx = 0.0;
@@ -1167,7 +1165,8 @@ __global__ __launch_bounds__(256) void k_sp_scale_rows(const int* __restrict__ p
 // FP64 matrix-core peak probe: back-to-back v_mfma_f64_16x16x4_f64 on 8 independent accumulators per wavefront,
 // operands in registers, no memory traffic.  Used only to measure the roofline denominator on the box at hand.
 template <int NACC>
-__global__ __launch_bounds__(256) void k_mfma_f64_peak(double* __restrict__ out, int iters) {
+__global__ __launch_bounds__(256) void k_mfma_f64_peak(AsmBt abt, double* __restrict__ out, int iters) {
+    ASM_BARGS(abt, out, iters);
     v4f64 acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = (v4f64){0.0, 0.0, 0.0, 0.0};
@@ -1186,8 +1185,8 @@ __global__ __launch_bounds__(256) void k_mfma_f64_peak(double* __restrict__ out,
 
 // nz[t][c] = 1 iff the 32T-row tile t of A has a non-zero in k-chunk c (32 columns).  One workgroup per (tile, group of
 // 8 chunks); feeds the chunk skipping of the Schur build for sparse Jacobians (ACOPF: ~3 non-zeros per row).
-__global__ __launch_bounds__(256) void k_tile_nzflags(const double* __restrict__ A, int64_t ld, int64_t M, int tile_rows, int nchunks,
-                                                      unsigned char* __restrict__ nz, int nzpitch, const int* __restrict__ idx) {
+__global__ __launch_bounds__(256) void k_tile_nzflags(AsmBt abt, const double* __restrict__ A, int64_t ld, int64_t M, int tile_rows, int nchunks, unsigned char* __restrict__ nz, int nzpitch, const int* __restrict__ idx) {
+    ASM_BARGS(abt, A, ld, M, tile_rows, nchunks, nz, nzpitch, idx);
     const int t = blockIdx.x, c0 = blockIdx.y * 8;
     __shared__ int any[8];
     if (threadIdx.x < 8) any[threadIdx.x] = 0;
@@ -1224,7 +1223,8 @@ __global__ __launch_bounds__(256) void k_tile_nzflags(const double* __restrict__
 // (pitch = 2 mod 32 doubles).
 #define ASM_TP 66
 template <int WB>
-__global__ __launch_bounds__(256) void k_trtri_init(const double* __restrict__ Linv, int Ms, double* __restrict__ Binv) {
+__global__ __launch_bounds__(256) void k_trtri_init(AsmBt abt, const double* __restrict__ Linv, int Ms, double* __restrict__ Binv) {
+    ASM_BARGS(abt, Linv, Ms, Binv);
     const int B = blockIdx.x, i = blockIdx.y / (WB / ASM_NB), j = blockIdx.y % (WB / ASM_NB);
     const int b0 = B * WB;
     const int nsub = min((WB / ASM_NB), (Ms - b0 + ASM_NB - 1) / ASM_NB);
@@ -1238,11 +1238,11 @@ __global__ __launch_bounds__(256) void k_trtri_init(const double* __restrict__ L
     }
 }
 template <int WB>
-__global__ __launch_bounds__(256) void k_trtri_level(const double* __restrict__ L, int64_t ld, int Ms, double* __restrict__ Binv,
-                                                     double* __restrict__ Tbuf, int h, int stage) {
+__global__ __launch_bounds__(256) void k_trtri_level(AsmBt abt, const double* __restrict__ L, int64_t ld, int Ms, double* __restrict__ Binv, double* __restrict__ Tbuf, int h, int stage) {
+    ASM_BARGS(abt, L, ld, Ms, Binv, Tbuf, h, stage);
     __shared__ double Pa[ASM_NB * ASM_TP];      // left operand  P[r][k]
     __shared__ double Qt[ASM_NB * ASM_TP];      // right operand transposed  Qt[c][k] = Q[k][c]
-    const int B = blockIdx.x, pr = blockIdx.y, ti = blockIdx.z / h, tj = blockIdx.z % h;
+    const int B = blockIdx.x, pr = blockIdx.y, ti = asm_bz(abt) / h, tj = asm_bz(abt) % h;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int b0 = B * WB;
     const int c0 = pr * 2 * h * ASM_NB, r0 = c0 + h * ASM_NB;          // inside the wide block: cols of "1", rows of "2"
@@ -1306,8 +1306,8 @@ __global__ __launch_bounds__(256) void k_trtri_level(const double* __restrict__ 
 
 // forward, wide block B:  z_B = X_B w_B   (one wavefront per row: 128 workgroups of 4 rows; all loads of a row in flight)
 template <int WB>
-__global__ __launch_bounds__(256) void k_wtrsv_fwd_diag(const double* __restrict__ Binv, int B, int Ms, const double* __restrict__ w,
-                                                        double* __restrict__ z) {
+__global__ __launch_bounds__(256) void k_wtrsv_fwd_diag(AsmBt abt, const double* __restrict__ Binv, int B, int Ms, const double* __restrict__ w, double* __restrict__ z) {
+    ASM_BARGS(abt, Binv, B, Ms, w, z);
     const int b0 = B * WB;
     const double* X = Binv + (int64_t)B * WB * WB;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1331,8 +1331,8 @@ __global__ __launch_bounds__(256) void k_wtrsv_fwd_diag(const double* __restrict
 // forward panel update:  w[i] -= L[i, b0:b1] . z[b0:b1]   for i >= b1.  A wavefront owns 8 rows: their 64 loads are issued
 // together, the 8 sums are reduced, and lanes 0..7 apply the 8 read-modify-writes in parallel.
 template <int WB>
-__global__ __launch_bounds__(256) void k_wtrsv_fwd_panel(const double* __restrict__ L, int64_t ld, int B, int Ms, const double* __restrict__ z,
-                                                         double* __restrict__ w) {
+__global__ __launch_bounds__(256) void k_wtrsv_fwd_panel(AsmBt abt, const double* __restrict__ L, int64_t ld, int B, int Ms, const double* __restrict__ z, double* __restrict__ w) {
+    ASM_BARGS(abt, L, ld, B, Ms, z, w);
     __shared__ double zs[WB];
     const int b0 = B * WB, b1 = min(b0 + WB, Ms), wdt = b1 - b0;
     for (int c = threadIdx.x; c < WB; c += 256) zs[c] = c < wdt ? z[b0 + c] : 0.0;
@@ -1367,8 +1367,8 @@ __global__ __launch_bounds__(256) void k_wtrsv_fwd_panel(const double* __restric
 // backward partial sums for wide block B over chunks of 64 rows i >= b1:  part[g][c] = sum_i L[i, b0+c] x[i]
 #define ASM_WBROWS 64
 template <int WB>
-__global__ __launch_bounds__(256) void k_wtrsv_bwd_panel(const double* __restrict__ L, int64_t ld, int B, int Ms, const double* __restrict__ x,
-                                                         double* __restrict__ part) {
+__global__ __launch_bounds__(256) void k_wtrsv_bwd_panel(AsmBt abt, const double* __restrict__ L, int64_t ld, int B, int Ms, const double* __restrict__ x, double* __restrict__ part) {
+    ASM_BARGS(abt, L, ld, B, Ms, x, part);
     __shared__ double red[4][WB];
     const int b0 = B * WB, b1 = min(b0 + WB, Ms), wdt = b1 - b0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1407,8 +1407,8 @@ __global__ __launch_bounds__(256) void k_wtrsv_bwd_panel(const double* __restric
 }
 // t = z_B - sum_g part[g]   (8 workgroups of 64 columns; partials split over the 4 wavefronts in a fixed order)
 template <int WB>
-__global__ __launch_bounds__(256) void k_wtrsv_bwd_reduce(int B, int Ms, const double* __restrict__ z, const double* __restrict__ part,
-                                                          int n_part, double* __restrict__ t) {
+__global__ __launch_bounds__(256) void k_wtrsv_bwd_reduce(AsmBt abt, int B, int Ms, const double* __restrict__ z, const double* __restrict__ part, int n_part, double* __restrict__ t) {
+    ASM_BARGS(abt, B, Ms, z, part, n_part, t);
     __shared__ double red[4][64];
     const int b0 = B * WB, b1 = min(b0 + WB, Ms), wdt = b1 - b0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1430,8 +1430,8 @@ __global__ __launch_bounds__(256) void k_wtrsv_bwd_reduce(int B, int Ms, const d
 }
 // x_B = X_B' t  through the transposed block inverse (row c of XT = column c of X): one wavefront per unknown
 template <int WB>
-__global__ __launch_bounds__(256) void k_wtrsv_bwd_diag(const double* __restrict__ BinvT, int B, int Ms, const double* __restrict__ t,
-                                                        double* __restrict__ x, int tlen) {
+__global__ __launch_bounds__(256) void k_wtrsv_bwd_diag(AsmBt abt, const double* __restrict__ BinvT, int B, int Ms, const double* __restrict__ t, double* __restrict__ x, int tlen) {
+    ASM_BARGS(abt, BinvT, B, Ms, t, x, tlen);
     const int b0 = B * WB;
     const double* XT = BinvT + (int64_t)B * WB * WB;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1452,7 +1452,8 @@ __global__ __launch_bounds__(256) void k_wtrsv_bwd_diag(const double* __restrict
 }
 // XT_B = X_B'  (LDS-tiled transpose of every 512 x 512 block inverse)
 template <int WB>
-__global__ __launch_bounds__(256) void k_transpose_wb(const double* __restrict__ Binv, double* __restrict__ BinvT) {
+__global__ __launch_bounds__(256) void k_transpose_wb(AsmBt abt, const double* __restrict__ Binv, double* __restrict__ BinvT) {
+    ASM_BARGS(abt, Binv, BinvT);
     __shared__ double tile[64 * 65];
     const int B = blockIdx.x, ti = blockIdx.y / (WB / ASM_NB), tj = blockIdx.y % (WB / ASM_NB);
     const double* X = Binv + (int64_t)B * WB * WB;
@@ -1474,22 +1475,21 @@ __global__ __launch_bounds__(256) void k_transpose_wb(const double* __restrict__
 // Sparse matrix-vector products on the fixed Jacobian pattern (ACOPF: 0.03 % fill).  The dense row-major matrix stays
 // the operand of the MFMA kernels; these read a gathered copy of its pattern entries (CSR values, CSC via positions).
 // One thread per row / column, fixed summation order -> deterministic.
-__global__ __launch_bounds__(256) void k_sp_gather(const double* __restrict__ A, const int64_t* __restrict__ off,
-                                                   double* __restrict__ vals, int64_t nnz) {
+__global__ __launch_bounds__(256) void k_sp_gather(AsmBt abt, const double* __restrict__ A, const int64_t* __restrict__ off, double* __restrict__ vals, int64_t nnz) {
+    ASM_BARGS(abt, A, off, vals, nnz);
     int64_t k = blockIdx.x * 256 + threadIdx.x;
     if (k < nnz) vals[k] = A[off[k]];
 }
-__global__ __launch_bounds__(256) void k_spmv_n(const int* __restrict__ ptr, const int* __restrict__ col, const double* __restrict__ vals,
-                                                const double* __restrict__ x, double* __restrict__ out, int64_t M) {
+__global__ __launch_bounds__(256) void k_spmv_n(AsmBt abt, const int* __restrict__ ptr, const int* __restrict__ col, const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ out, int64_t M) {
+    ASM_BARGS(abt, ptr, col, vals, x, out, M);
     int64_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= M) return;
     double acc = 0.0;
     for (int k = ptr[i]; k < ptr[i + 1]; ++k) acc += vals[k] * x[col[k]];
     out[i] = acc;
 }
-__global__ __launch_bounds__(256) void k_spmv_t(const int* __restrict__ cptr, const int* __restrict__ row, const int* __restrict__ pos,
-                                                const double* __restrict__ vals, const double* __restrict__ y, double* __restrict__ out,
-                                                int64_t n, int64_t ldn) {
+__global__ __launch_bounds__(256) void k_spmv_t(AsmBt abt, const int* __restrict__ cptr, const int* __restrict__ row, const int* __restrict__ pos, const double* __restrict__ vals, const double* __restrict__ y, double* __restrict__ out, int64_t n, int64_t ldn) {
+    ASM_BARGS(abt, cptr, row, pos, vals, y, out, n, ldn);
     // eight lanes per column (a bus-voltage column of the ACOPF Jacobian has 10-30 entries, each behind two dependent loads: one thread
     // per column walked them one after the other, 10-16 us per product at 2 400-11 000 columns); partial sums combined by lane shuffles
     const int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
@@ -1507,8 +1507,8 @@ __global__ __launch_bounds__(256) void k_spmv_t(const int* __restrict__ cptr, co
 // matrix for the column form of the Newton system
 // band >= 0: square lower-triangular input (a Cholesky factor) whose entries beyond `band` sub-diagonals are zero (band = rows: dense): only
 // the tiles that hold factor entries are moved - the transposed factor is read in its upper band only (Dev::trsm_rows, backward pass)
-__global__ __launch_bounds__(256) void k_transpose_dense(const double* __restrict__ A, int64_t ld_in, int64_t rows, int64_t cols,
-                                                         double* __restrict__ out, int64_t ld_out, int64_t band = -1) {
+__global__ __launch_bounds__(256) void k_transpose_dense(AsmBt abt, const double* __restrict__ A, int64_t ld_in, int64_t rows, int64_t cols, double* __restrict__ out, int64_t ld_out, int64_t band) {
+    ASM_BARGS(abt, A, ld_in, rows, cols, out, ld_out, band);
     __shared__ double tile[64 * 65];
     const int64_t i0 = (int64_t)blockIdx.y * 64, j0 = (int64_t)blockIdx.x * 64;
     if (band >= 0 && (j0 > i0 + 63 || i0 > j0 + 63 + band)) return;

@@ -18,8 +18,8 @@
 // double-buffered in LDS through registers - the generic k_syrk<2, 4, 32, 1> with two operand matrices and a full rectangle.
 // Used by the multi-right-hand-side triangular solves (rows of A = right-hand sides, rows of B = rows of the factor / of the
 // explicit inverse of a wide diagonal block).
-__global__ __launch_bounds__(256) void k_gemm_nt(const double* __restrict__ A, int64_t lda, const double* __restrict__ B, int64_t ldb,
-                                                 const double* C0, int64_t ldc0, double* C, int64_t ldc, int Ma, int Mb, int K, int mode) {
+__global__ __launch_bounds__(256) void k_gemm_nt(AsmBt abt, const double* __restrict__ A, int64_t lda, const double* __restrict__ B, int64_t ldb, const double* C0, int64_t ldc0, double* C, int64_t ldc, int Ma, int Mb, int K, int mode) {
+    ASM_BARGS(abt, A, lda, B, ldb, C0, ldc0, C, ldc, Ma, Mb, K, mode);
     constexpr int TS = 64, KC = 32, PITCH = KC + 2;
     __shared__ __attribute__((aligned(16))) double As[2][TS * PITCH];
     __shared__ __attribute__((aligned(16))) double Bs[2][TS * PITCH];
@@ -115,9 +115,8 @@ struct NsIdx {
 };
 
 // R[c, :] = column J[c] of A_EF on the rows E (dense row of length ldr, zero elsewhere).  One workgroup per right-hand side.
-__global__ __launch_bounds__(256) void k_ns_rhs_cols(const int* __restrict__ cptr, const int* __restrict__ crow, const int* __restrict__ cpos,
-                                                     const double* __restrict__ vals, NsIdx X, const int* __restrict__ J, const double* __restrict__ Fm,
-                                                     double* __restrict__ R, int64_t ldr) {
+__global__ __launch_bounds__(256) void k_ns_rhs_cols(AsmBt abt, const int* __restrict__ cptr, const int* __restrict__ crow, const int* __restrict__ cpos, const double* __restrict__ vals, NsIdx X, const int* __restrict__ J, const double* __restrict__ Fm, double* __restrict__ R, int64_t ldr) {
+    ASM_BARGS(abt, cptr, crow, cpos, vals, X, J, Fm, R, ldr);
     const int c = blockIdx.x;
     double* row = R + (int64_t)c * ldr;
     for (int64_t e = threadIdx.x; e < ldr; e += 256) row[e] = 0.0;
@@ -131,9 +130,8 @@ __global__ __launch_bounds__(256) void k_ns_rhs_cols(const int* __restrict__ cpt
 }
 
 // PJ[c, j] = Fm_j (delta(j, J[c]) - sum_{i in E, A_ij != 0} W[c, epos(i)] A_ij)      (rows of the projector P)
-__global__ __launch_bounds__(256) void k_ns_pj(const int* __restrict__ cptr, const int* __restrict__ crow, const int* __restrict__ cpos,
-                                               const double* __restrict__ vals, NsIdx X, const int* __restrict__ J, const double* __restrict__ Fm,
-                                               const double* __restrict__ W, int64_t ldw, double* PJ, int64_t ldp, int64_t n, int64_t ldn, int second_pass) {
+__global__ __launch_bounds__(256) void k_ns_pj(AsmBt abt, const int* __restrict__ cptr, const int* __restrict__ crow, const int* __restrict__ cpos, const double* __restrict__ vals, NsIdx X, const int* __restrict__ J, const double* __restrict__ Fm, const double* __restrict__ W, int64_t ldw, double* PJ, int64_t ldp, int64_t n, int64_t ldn, int second_pass) {
+    ASM_BARGS(abt, cptr, crow, cpos, vals, X, J, Fm, W, ldw, PJ, ldp, n, ldn, second_pass);
     const int c = blockIdx.y;
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= ldn) return;
@@ -152,8 +150,8 @@ __global__ __launch_bounds__(256) void k_ns_pj(const int* __restrict__ cptr, con
 }
 
 // R[c, e] = sum_j A[Eidx[e], j] Zt[c, j]   (the equality rows applied to the basis rows: right-hand sides of the second projection pass)
-__global__ __launch_bounds__(256) void k_ns_rows_e(const int* __restrict__ rptr, const int* __restrict__ rcol, const double* __restrict__ vals, NsIdx X,
-                                                   const double* __restrict__ Fm, const double* __restrict__ Zt, int64_t ldz, double* __restrict__ R, int64_t ldr) {
+__global__ __launch_bounds__(256) void k_ns_rows_e(AsmBt abt, const int* __restrict__ rptr, const int* __restrict__ rcol, const double* __restrict__ vals, NsIdx X, const double* __restrict__ Fm, const double* __restrict__ Zt, int64_t ldz, double* __restrict__ R, int64_t ldr) {
+    ASM_BARGS(abt, rptr, rcol, vals, X, Fm, Zt, ldz, R, ldr);
     const int c = blockIdx.y;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= ldr) return;
@@ -167,34 +165,38 @@ __global__ __launch_bounds__(256) void k_ns_rows_e(const int* __restrict__ rptr,
 }
 
 // T[c, d] = PJ[c, J[d]]  (d <= c; the lower triangle of P[J, J]) into the factor buffer of the small system
-__global__ __launch_bounds__(256) void k_ns_gather_t(const double* __restrict__ PJ, int64_t ldp, const int* __restrict__ J, int k,
-                                                     double* __restrict__ T, int64_t ldt) {
+__global__ __launch_bounds__(256) void k_ns_gather_t(AsmBt abt, const double* __restrict__ PJ, int64_t ldp, const int* __restrict__ J, int k, double* __restrict__ T, int64_t ldt) {
+    ASM_BARGS(abt, PJ, ldp, J, k, T, ldt);
     const int c = blockIdx.y;
     const int d = blockIdx.x * 256 + threadIdx.x;
     if (d <= c && d < k) T[(int64_t)c * ldt + d] = PJ[(int64_t)c * ldp + J[d]];
 }
 
 // v[i] = val for i < len
-__global__ __launch_bounds__(256) void k_ns_fill(double* __restrict__ v, double val, int64_t len) {
+__global__ __launch_bounds__(256) void k_ns_fill(AsmBt abt, double* __restrict__ v, double val, int64_t len) {
+    ASM_BARGS(abt, v, val, len);
     int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t < len) v[t] = val;
 }
 
 // d[i] = S[i, i]
-__global__ __launch_bounds__(256) void k_ns_diag(const double* __restrict__ S, int64_t ld, int N, double* __restrict__ d) {
+__global__ __launch_bounds__(256) void k_ns_diag(AsmBt abt, const double* __restrict__ S, int64_t ld, int N, double* __restrict__ d) {
+    ASM_BARGS(abt, S, ld, N, d);
     int t = blockIdx.x * 256 + threadIdx.x;
     if (t < N) d[t] = S[(int64_t)t * ld + t];
 }
 
 // lower triangle of S[0:N, 0:N] := diag(dvec) (strictly lower part zero); dvec == nullptr: zero diagonal as well
-__global__ __launch_bounds__(256) void k_ns_set_diag(double* __restrict__ S, int64_t ld, int N, const double* __restrict__ dvec) {
+__global__ __launch_bounds__(256) void k_ns_set_diag(AsmBt abt, double* __restrict__ S, int64_t ld, int N, const double* __restrict__ dvec) {
+    ASM_BARGS(abt, S, ld, N, dvec);
     const int i = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j <= i && j < N) S[(int64_t)i * ld + j] = (j == i && dvec) ? dvec[i] : 0.0;
 }
 
 // cnt[0] = number of guarded pivots (diagonal entries of the factor >= big): one workgroup
-__global__ __launch_bounds__(1024) void k_ns_count_big(const double* __restrict__ S, int64_t ld, int N, double big, int* __restrict__ cnt) {
+__global__ __launch_bounds__(1024) void k_ns_count_big(AsmBt abt, const double* __restrict__ S, int64_t ld, int N, double big, int* __restrict__ cnt) {
+    ASM_BARGS(abt, S, ld, N, big, cnt);
     __shared__ int sh[16];
     int c = 0;
     for (int i = threadIdx.x; i < N; i += 1024) c += S[(int64_t)i * ld + i] >= big ? 1 : 0;
@@ -211,7 +213,8 @@ __global__ __launch_bounds__(1024) void k_ns_count_big(const double* __restrict_
 // In place  Zt = L^-1 PJ  (forward substitution down the k rows, one thread per column; L = k x k lower factor, pitch ldl).
 // The rows already finished are read back from Zt itself (coalesced across the workgroup, L2 resident); the row of L is
 // staged in LDS 64 entries at a time.
-__global__ __launch_bounds__(256) void k_ns_ortho(const double* __restrict__ L, int64_t ldl, int k, double* __restrict__ Zt, int64_t ldz, int64_t ncols) {
+__global__ __launch_bounds__(256) void k_ns_ortho(AsmBt abt, const double* __restrict__ L, int64_t ldl, int k, double* __restrict__ Zt, int64_t ldz, int64_t ncols) {
+    ASM_BARGS(abt, L, ldl, k, Zt, ldz, ncols);
     __shared__ double lrow[64];
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool live = j < ncols;
@@ -231,8 +234,8 @@ __global__ __launch_bounds__(256) void k_ns_ortho(const double* __restrict__ L, 
 }
 
 // GIt[c, ipos] = sum_{j in row i} A_ij Zt[c, j]   for the inequality rows i = Iidx[ipos]   (Zt is zero in the fixed columns)
-__global__ __launch_bounds__(256) void k_ns_gi(const int* __restrict__ rptr, const int* __restrict__ rcol, const double* __restrict__ vals, NsIdx X,
-                                               const double* __restrict__ Zt, int64_t ldz, double* __restrict__ GIt, int nIp) {
+__global__ __launch_bounds__(256) void k_ns_gi(AsmBt abt, const int* __restrict__ rptr, const int* __restrict__ rcol, const double* __restrict__ vals, NsIdx X, const double* __restrict__ Zt, int64_t ldz, double* __restrict__ GIt, int nIp) {
+    ASM_BARGS(abt, rptr, rcol, vals, X, Zt, ldz, GIt, nIp);
     const int c = blockIdx.y;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= nIp) return;
@@ -246,7 +249,8 @@ __global__ __launch_bounds__(256) void k_ns_gi(const int* __restrict__ rptr, con
 }
 
 // theta~ = [ (muL/tL + muU/tU + rho) Fm  (n, zero padded to ldn) | 1/dS on the inequality rows (nI, zero padded to nIp) ]
-__global__ __launch_bounds__(256) void k_ns_theta(IpmPtrs P, NsIdx X, double rho_p, double* __restrict__ th, int64_t ldn, int nIp) {
+__global__ __launch_bounds__(256) void k_ns_theta(AsmBt abt, IpmPtrs P, NsIdx X, double rho_p, double* __restrict__ th, int64_t ldn, int nIp) {
+    ASM_BARGS(abt, P, X, rho_p, th, ldn, nIp);
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t < ldn) {
         double v = 0.0;
@@ -258,19 +262,22 @@ __global__ __launch_bounds__(256) void k_ns_theta(IpmPtrs P, NsIdx X, double rho
 
 // ---- vector kernels of the null-space Newton solve (oracle: IPM.run, solve_ns).  thI = theta~ + ldn = D_I^-1 by position in I.
 // out[e] = scale * r[Eidx[e]]
-__global__ __launch_bounds__(256) void k_ns_gather_e(NsIdx X, const double* __restrict__ r, double scale, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_ns_gather_e(AsmBt abt, NsIdx X, const double* __restrict__ r, double scale, double* __restrict__ out) {
+    ASM_BARGS(abt, X, r, scale, out);
     int t = blockIdx.x * 256 + threadIdx.x;
     if (t < X.nE) out[t] = scale * r[X.Eidx[t]];
 }
 // yM[i] = tE[epos] on the equality rows, zero on the inequality rows
-__global__ __launch_bounds__(256) void k_ns_rowvec_e(NsIdx X, const double* __restrict__ tE, double* __restrict__ yM, int64_t M) {
+__global__ __launch_bounds__(256) void k_ns_rowvec_e(AsmBt abt, NsIdx X, const double* __restrict__ tE, double* __restrict__ yM, int64_t M) {
+    ASM_BARGS(abt, X, tE, yM, M);
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= M) return;
     const int ep = X.Epos[i];
     yM[i] = ep >= 0 ? tE[ep] : 0.0;
 }
 // inequality rows: bI = -res rp + sg rcg / pi,  yM = D_I^-1 bI ; equality rows: both zero
-__global__ __launch_bounds__(256) void k_ns_bi(IpmPtrs P, NsIdx X, const double* __restrict__ thI, double res, double* __restrict__ bI, double* __restrict__ yM) {
+__global__ __launch_bounds__(256) void k_ns_bi(AsmBt abt, IpmPtrs P, NsIdx X, const double* __restrict__ thI, double res, double* __restrict__ bI, double* __restrict__ yM) {
+    ASM_BARGS(abt, P, X, thI, res, bI, yM);
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= P.M) return;
     const int ip = X.Ipos[i];
@@ -283,28 +290,30 @@ __global__ __launch_bounds__(256) void k_ns_bi(IpmPtrs P, NsIdx X, const double*
     yM[i] = y;
 }
 // wM[i] = D_I^-1 aM[i] on the inequality rows, zero on the equality rows
-__global__ __launch_bounds__(256) void k_ns_wm(NsIdx X, const double* __restrict__ thI, const double* __restrict__ aM, double* __restrict__ wM, int64_t M) {
+__global__ __launch_bounds__(256) void k_ns_wm(AsmBt abt, NsIdx X, const double* __restrict__ thI, const double* __restrict__ aM, double* __restrict__ wM, int64_t M) {
+    ASM_BARGS(abt, X, thI, aM, wM, M);
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= M) return;
     const int ip = X.Ipos[i];
     wM[i] = ip >= 0 ? thI[ip] * aM[i] : 0.0;
 }
 // free columns (th != 0):  out = th x + atw - (h ? h : 0) ; fixed / padded columns: 0       (K x - h,  K = Th + A_I' D_I^-1 A_I)
-__global__ __launch_bounds__(256) void k_ns_kx(const double* __restrict__ th, const double* __restrict__ x, const double* __restrict__ atw,
-                                               const double* __restrict__ h, double* __restrict__ out, int64_t ldn) {
+__global__ __launch_bounds__(256) void k_ns_kx(AsmBt abt, const double* __restrict__ th, const double* __restrict__ x, const double* __restrict__ atw, const double* __restrict__ h, double* __restrict__ out, int64_t ldn) {
+    ASM_BARGS(abt, th, x, atw, h, out, ldn);
     int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= ldn) return;
     const double t = th[j];
     out[j] = t != 0.0 ? t * x[j] + atw[j] - (h ? h[j] : 0.0) : 0.0;
 }
 // x[j] = 0 on the fixed / padded columns (th == 0)
-__global__ __launch_bounds__(256) void k_ns_mask(double* __restrict__ x, const double* __restrict__ th, int64_t ldn) {
+__global__ __launch_bounds__(256) void k_ns_mask(AsmBt abt, double* __restrict__ x, const double* __restrict__ th, int64_t ldn) {
+    ASM_BARGS(abt, x, th, ldn);
     int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j < ldn && th[j] == 0.0) x[j] = 0.0;
 }
 // h~ = hp + A_I' D_I^-1 bI on the free columns (zero elsewhere) ;  v = h~ - res K dpbar
-__global__ __launch_bounds__(256) void k_ns_ht(const double* __restrict__ th, const double* __restrict__ hp, const double* __restrict__ atw,
-                                               const double* __restrict__ kdpb, double res, double* __restrict__ ht, double* __restrict__ v, int64_t n, int64_t ldn) {
+__global__ __launch_bounds__(256) void k_ns_ht(AsmBt abt, const double* __restrict__ th, const double* __restrict__ hp, const double* __restrict__ atw, const double* __restrict__ kdpb, double res, double* __restrict__ ht, double* __restrict__ v, int64_t n, int64_t ldn) {
+    ASM_BARGS(abt, th, hp, atw, kdpb, res, ht, v, n, ldn);
     int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= ldn) return;
     double h = 0.0, o = 0.0;
@@ -316,8 +325,8 @@ __global__ __launch_bounds__(256) void k_ns_ht(const double* __restrict__ th, co
     v[j] = o;
 }
 // out = rhs - N0 x  with N0 symmetric, lower triangle stored (pitch ld): one wavefront per row
-__global__ __launch_bounds__(256) void k_ns_symv_res(const double* __restrict__ N0, int64_t ld, int k, const double* __restrict__ x, const double* __restrict__ rhs,
-                                                     double* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_ns_symv_res(AsmBt abt, const double* __restrict__ N0, int64_t ld, int k, const double* __restrict__ x, const double* __restrict__ rhs, double* __restrict__ out) {
+    ASM_BARGS(abt, N0, ld, k, x, rhs, out);
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= k) return;
     double acc = 0.0;
@@ -327,14 +336,15 @@ __global__ __launch_bounds__(256) void k_ns_symv_res(const double* __restrict__ 
     if (lane == 0) out[i] = rhs[i] - acc;
 }
 // lower triangle copy  dst[i, j] = src[i, j], j <= i < k
-__global__ __launch_bounds__(256) void k_ns_copy_lower(const double* __restrict__ src, int64_t lds_, double* __restrict__ dst, int64_t ldd, int k) {
+__global__ __launch_bounds__(256) void k_ns_copy_lower(AsmBt abt, const double* __restrict__ src, int64_t lds_, double* __restrict__ dst, int64_t ldd, int k) {
+    ASM_BARGS(abt, src, lds_, dst, ldd, k);
     const int i = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j <= i && j < k) dst[(int64_t)i * ldd + j] = src[(int64_t)i * lds_ + j];
 }
 // lower triangle of the sum of the split-K slices (fixed order), written to the factor buffer and to the unregularised copy
-__global__ __launch_bounds__(256) void k_ns_reduce_lower(const double* __restrict__ parts, int nsplit, int64_t pstride, int64_t ld, double* __restrict__ S,
-                                                         double* __restrict__ N0, int k) {
+__global__ __launch_bounds__(256) void k_ns_reduce_lower(AsmBt abt, const double* __restrict__ parts, int nsplit, int64_t pstride, int64_t ld, double* __restrict__ S, double* __restrict__ N0, int k) {
+    ASM_BARGS(abt, parts, nsplit, pstride, ld, S, N0, k);
     const int i = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j <= i && j < k) {
@@ -346,13 +356,14 @@ __global__ __launch_bounds__(256) void k_ns_reduce_lower(const double* __restric
     }
 }
 // x = a + b
-__global__ __launch_bounds__(256) void k_ns_add(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ x, int64_t len) {
+__global__ __launch_bounds__(256) void k_ns_add(AsmBt abt, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ x, int64_t len) {
+    ASM_BARGS(abt, a, b, x, len);
     int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j < len) x[j] = a[j] + b[j];
 }
 // dp = res dpbar + Z du on the free columns, with the bound multipliers' directions (k_ipm_dir's column part)
-__global__ __launch_bounds__(256) void k_ns_dp(IpmPtrs P, IpmDir D, const double* __restrict__ th, const double* __restrict__ dpb, double res,
-                                               const double* __restrict__ zu, int64_t ldn) {
+__global__ __launch_bounds__(256) void k_ns_dp(AsmBt abt, IpmPtrs P, IpmDir D, const double* __restrict__ th, const double* __restrict__ dpb, double res, const double* __restrict__ zu, int64_t ldn) {
+    ASM_BARGS(abt, P, D, th, dpb, res, zu, ldn);
     int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= ldn) return;
     double dp = 0.0, dL = 0.0, dU = 0.0;
@@ -365,8 +376,8 @@ __global__ __launch_bounds__(256) void k_ns_dp(IpmPtrs P, IpmDir D, const double
     if (t < P.n) { D.dmuL[t] = dL; D.dmuU[t] = dU; }
 }
 // inequality rows: dy = D_I^-1 (bI - aM), dpi = sg dy, dg = (rcg - g dpi)/pi, wM = D_I^-1 aM ; equality rows: dy = dpi = dg = wM = 0
-__global__ __launch_bounds__(256) void k_ns_rows(IpmPtrs P, IpmDir D, NsIdx X, const double* __restrict__ thI, const double* __restrict__ bI,
-                                                 const double* __restrict__ aM, double* __restrict__ wM) {
+__global__ __launch_bounds__(256) void k_ns_rows(AsmBt abt, IpmPtrs P, IpmDir D, NsIdx X, const double* __restrict__ thI, const double* __restrict__ bI, const double* __restrict__ aM, double* __restrict__ wM) {
+    ASM_BARGS(abt, P, D, X, thI, bI, aM, wM);
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= P.M) return;
     const int ip = X.Ipos[i];
@@ -383,13 +394,14 @@ __global__ __launch_bounds__(256) void k_ns_rows(IpmPtrs P, IpmDir D, NsIdx X, c
     wM[i] = w;
 }
 // out[Eidx[e]] = tE[e]   (add != 0: += )
-__global__ __launch_bounds__(256) void k_ns_scatter_e(NsIdx X, const double* __restrict__ tE, double* __restrict__ out, int add) {
+__global__ __launch_bounds__(256) void k_ns_scatter_e(AsmBt abt, NsIdx X, const double* __restrict__ tE, double* __restrict__ out, int add) {
+    ASM_BARGS(abt, X, tE, out, add);
     int t = blockIdx.x * 256 + threadIdx.x;
     if (t < X.nE) out[X.Eidx[t]] = (add ? out[X.Eidx[t]] : 0.0) + tE[t];
 }
 // slot[0] = max_j |th_j dp_j - aty_j - hp_j| over the free columns: the dual-equation error of the step (one workgroup)
-__global__ __launch_bounds__(1024) void k_ns_err(const double* __restrict__ th, const double* __restrict__ dp, const double* __restrict__ aty,
-                                                 const double* __restrict__ hp, int64_t n, double* __restrict__ slot) {
+__global__ __launch_bounds__(1024) void k_ns_err(AsmBt abt, const double* __restrict__ th, const double* __restrict__ dp, const double* __restrict__ aty, const double* __restrict__ hp, int64_t n, double* __restrict__ slot) {
+    ASM_BARGS(abt, th, dp, aty, hp, n, slot);
     __shared__ double sh[16];
     double m = 0.0;
     for (int64_t j = threadIdx.x; j < n; j += 1024)
@@ -408,7 +420,8 @@ struct NsEq {
     int64_t ldc;                      // pitch of Csel (>= k, multiple of 32)
 };
 // ordered compaction of the working set (one workgroup): bounds by variable index, then inequality rows by index; ksoft := -1
-__global__ __launch_bounds__(1024) void k_nseq_setup(AsPtrs A, AsSets S, NsIdx X, NsEq Q, int64_t ldn) {
+__global__ __launch_bounds__(1024) void k_nseq_setup(AsmBt abt, AsPtrs A, AsSets S, NsIdx X, NsEq Q, int64_t ldn) {
+    ASM_BARGS(abt, A, S, X, Q, ldn);
     __shared__ int sh_cnt[16];
     int base = 0;
     for (int64_t j0 = 0; j0 < A.n; j0 += 1024) {
@@ -430,7 +443,8 @@ __global__ __launch_bounds__(1024) void k_nseq_setup(AsPtrs A, AsSets S, NsIdx X
     if (threadIdx.x == 0) { Q.cnt[0] = nB; Q.cnt[1] = base; }
 }
 // Csel[a, c] = Gt[c, sel[a]]  (c < k; zero in the padding columns) and the right-hand side d[a]
-__global__ __launch_bounds__(256) void k_nseq_gather(AsPtrs A, AsSets S, NsIdx X, NsEq Q, const double* __restrict__ Gt, int64_t ldg, int k, int64_t ldn) {
+__global__ __launch_bounds__(256) void k_nseq_gather(AsmBt abt, AsPtrs A, AsSets S, NsIdx X, NsEq Q, const double* __restrict__ Gt, int64_t ldg, int k, int64_t ldn) {
+    ASM_BARGS(abt, A, S, X, Q, Gt, ldg, k, ldn);
     const int a = blockIdx.y;
     const int c = blockIdx.x * 256 + threadIdx.x;
     const int col = Q.sel[a];
@@ -443,18 +457,20 @@ __global__ __launch_bounds__(256) void k_nseq_gather(AsPtrs A, AsSets S, NsIdx X
     }
 }
 // pfix: fixed columns at their value, zero elsewhere
-__global__ __launch_bounds__(256) void k_nseq_pfix(AsPtrs A, double* __restrict__ pfix, int64_t ldn) {
+__global__ __launch_bounds__(256) void k_nseq_pfix(AsmBt abt, AsPtrs A, double* __restrict__ pfix, int64_t ldn) {
+    ASM_BARGS(abt, A, pfix, ldn);
     int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j < ldn) pfix[j] = (j < A.n && !(A.ub[j] > A.lb[j])) ? A.lb[j] : 0.0;
 }
 // out[e] = r[Eidx[e]] - aM[Eidx[e]]
-__global__ __launch_bounds__(256) void k_nseq_be(AsPtrs A, NsIdx X, const double* __restrict__ aM, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_nseq_be(AsmBt abt, AsPtrs A, NsIdx X, const double* __restrict__ aM, double* __restrict__ out) {
+    ASM_BARGS(abt, A, X, aM, out);
     int t = blockIdx.x * 256 + threadIdx.x;
     if (t < X.nE) out[t] = A.r[X.Eidx[t]] - aM[X.Eidx[t]];
 }
 // pbar = pfix + (masked) x ;  vz = Fm (clip0 - pbar)   (input of u0 = Zt vz)
-__global__ __launch_bounds__(256) void k_nseq_pbar(AsPtrs A, const double* __restrict__ pfix, const double* __restrict__ x, const double* __restrict__ zero,
-                                                   double* __restrict__ pbar, double* __restrict__ vz, int64_t ldn) {
+__global__ __launch_bounds__(256) void k_nseq_pbar(AsmBt abt, AsPtrs A, const double* __restrict__ pfix, const double* __restrict__ x, const double* __restrict__ zero, double* __restrict__ pbar, double* __restrict__ vz, int64_t ldn) {
+    ASM_BARGS(abt, A, pfix, x, zero, pbar, vz, ldn);
     int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= ldn) return;
     const bool fr = j < A.n && A.ub[j] > A.lb[j];
@@ -463,12 +479,14 @@ __global__ __launch_bounds__(256) void k_nseq_pbar(AsPtrs A, const double* __res
     vz[j] = fr ? zero[j] - pb : 0.0;
 }
 // out = a - b  (len)
-__global__ __launch_bounds__(256) void k_nseq_sub(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out, int64_t len) {
+__global__ __launch_bounds__(256) void k_nseq_sub(AsmBt abt, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out, int64_t len) {
+    ASM_BARGS(abt, a, b, out, len);
     int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t < len) out[t] = a[t] - b[t];
 }
 // p = pbar + Z u on the free columns, bound-active variables exactly on their bound, fixed columns at their value
-__global__ __launch_bounds__(256) void k_nseq_p(AsPtrs A, AsSets S, NsEq Q, const double* __restrict__ zu, int64_t ldn) {
+__global__ __launch_bounds__(256) void k_nseq_p(AsmBt abt, AsPtrs A, AsSets S, NsEq Q, const double* __restrict__ zu, int64_t ldn) {
+    ASM_BARGS(abt, A, S, Q, zu, ldn);
     int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= A.n) return;
     double v;
@@ -478,7 +496,8 @@ __global__ __launch_bounds__(256) void k_nseq_p(AsPtrs A, AsSets S, NsEq Q, cons
     A.p[j] = v;
 }
 // y on the inequality rows: the multiplier of the row's constraint (0 when inactive); zero on the equality rows
-__global__ __launch_bounds__(256) void k_nseq_yi(AsPtrs A, NsIdx X, NsEq Q, double* __restrict__ yM) {
+__global__ __launch_bounds__(256) void k_nseq_yi(AsmBt abt, AsPtrs A, NsIdx X, NsEq Q, double* __restrict__ yM) {
+    ASM_BARGS(abt, A, X, Q, yM);
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= A.M) return;
     const int ip = X.Ipos[i];
@@ -487,7 +506,8 @@ __global__ __launch_bounds__(256) void k_nseq_yi(AsPtrs A, NsIdx X, NsEq Q, doub
     yM[i] = v;
 }
 // w = Fm (q - A_Ia' y_Ia) - z_B
-__global__ __launch_bounds__(256) void k_nseq_w(AsPtrs A, NsEq Q, const double* __restrict__ atw, double* __restrict__ w, int64_t ldn) {
+__global__ __launch_bounds__(256) void k_nseq_w(AsmBt abt, AsPtrs A, NsEq Q, const double* __restrict__ atw, double* __restrict__ w, int64_t ldn) {
+    ASM_BARGS(abt, A, Q, atw, w, ldn);
     int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= ldn) return;
     double v = 0.0;
@@ -498,7 +518,8 @@ __global__ __launch_bounds__(256) void k_nseq_w(AsPtrs A, NsEq Q, const double* 
     w[j] = v;
 }
 // y = yM with the equality rows from tE
-__global__ __launch_bounds__(256) void k_nseq_y(AsPtrs A, NsIdx X, const double* __restrict__ yM, const double* __restrict__ tE) {
+__global__ __launch_bounds__(256) void k_nseq_y(AsmBt abt, AsPtrs A, NsIdx X, const double* __restrict__ yM, const double* __restrict__ tE) {
+    ASM_BARGS(abt, A, X, yM, tE);
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= A.M) return;
     const int ep = X.Epos[i];
@@ -507,28 +528,33 @@ __global__ __launch_bounds__(256) void k_nseq_y(AsPtrs A, NsIdx X, const double*
 
 // ---- null-space iteration without solves against S0 (oracle: IPM.run use_ns / IPM.measures / IPM.ns_finish_y)
 // d0 = Fm (p - pbar)
-__global__ __launch_bounds__(256) void k_ns_e0(IpmPtrs P, const double* __restrict__ pbar, double* __restrict__ d0, int64_t ldn) {
+__global__ __launch_bounds__(256) void k_ns_e0(AsmBt abt, IpmPtrs P, const double* __restrict__ pbar, double* __restrict__ d0, int64_t ldn) {
+    ASM_BARGS(abt, P, pbar, d0, ldn);
     int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= ldn) return;
     d0[j] = (j < P.n && P.ub[j] > P.lb[j]) ? P.p[j] - pbar[j] : 0.0;
 }
 // e = d0 - zz on the free columns ; dpb = -e
-__global__ __launch_bounds__(256) void k_ns_e1(IpmPtrs P, const double* __restrict__ d0, const double* __restrict__ zz, double* __restrict__ e, int64_t ldn) {
+__global__ __launch_bounds__(256) void k_ns_e1(AsmBt abt, IpmPtrs P, const double* __restrict__ d0, const double* __restrict__ zz, double* __restrict__ e, int64_t ldn) {
+    ASM_BARGS(abt, P, d0, zz, e, ldn);
     int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= ldn) return;
     e[j] = (j < P.n && P.ub[j] > P.lb[j]) ? d0[j] - zz[j] : 0.0;
 }
 // x *= a
-__global__ __launch_bounds__(256) void k_ns_scale(double* __restrict__ x, double a, int64_t len) {
+__global__ __launch_bounds__(256) void k_ns_scale(AsmBt abt, double* __restrict__ x, double a, int64_t len) {
+    ASM_BARGS(abt, x, a, len);
     int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j < len) x[j] *= a;
 }
-__global__ __launch_bounds__(256) void k_ns_neg(const double* __restrict__ x, double* __restrict__ out, int64_t len) {
+__global__ __launch_bounds__(256) void k_ns_neg(AsmBt abt, const double* __restrict__ x, double* __restrict__ out, int64_t len) {
+    ASM_BARGS(abt, x, out, len);
     int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j < len) out[j] = -x[j];
 }
 // scal[SC_DINF] = max_c |zr_c| / scale_q  (the dual residual inside the null space of the equality rows), then the scalar block goes to the host
-__global__ __launch_bounds__(1024) void k_ns_dinf(IpmPtrs P, const double* __restrict__ zr, int k, unsigned pub) {
+__global__ __launch_bounds__(1024) void k_ns_dinf(AsmBt abt, IpmPtrs P, const double* __restrict__ zr, int k, unsigned pub) {
+    ASM_BARGS(abt, P, zr, k, pub);
     __shared__ double sh[16];
     double m = 0.0;
     for (int c = threadIdx.x; c < k; c += 1024) m = fmax(m, fabs(zr[c]));
@@ -537,7 +563,8 @@ __global__ __launch_bounds__(1024) void k_ns_dinf(IpmPtrs P, const double* __res
     scal_publish(P, pub);
 }
 // slot[0] = max(slot[0], max|r| / max(1, max|rhs|))   (relative residual of a reduced solve; one workgroup)
-__global__ __launch_bounds__(1024) void k_ns_relres(const double* __restrict__ r, const double* __restrict__ rhs, int k, double* __restrict__ slot) {
+__global__ __launch_bounds__(1024) void k_ns_relres(AsmBt abt, const double* __restrict__ r, const double* __restrict__ rhs, int k, double* __restrict__ slot) {
+    ASM_BARGS(abt, r, rhs, k, slot);
     __shared__ double sh[16];
     double a = 0.0, b = 1.0;
     for (int c = threadIdx.x; c < k; c += 1024) { a = fmax(a, fabs(r[c])); b = fmax(b, fabs(rhs[c])); }
@@ -623,8 +650,8 @@ __device__ __forceinline__ void small_chol_solve(const double* __restrict__ L, i
     }
 }
 // out = (L L')^-1 rhs
-__global__ __launch_bounds__(1024) void k_small_solve(const double* __restrict__ L, int64_t ld, const double* __restrict__ Linv, int k,
-                                                      const double* __restrict__ rhs, double* __restrict__ out) {
+__global__ __launch_bounds__(1024) void k_small_solve(AsmBt abt, const double* __restrict__ L, int64_t ld, const double* __restrict__ Linv, int k, const double* __restrict__ rhs, double* __restrict__ out) {
+    ASM_BARGS(abt, L, ld, Linv, k, rhs, out);
     __shared__ double x[ASM_SMALL_MAX], t[64], part[16 * 64];
     for (int i = threadIdx.x; i < k; i += 1024) x[i] = rhs[i];
     __syncthreads();
@@ -645,8 +672,8 @@ __device__ __forceinline__ void small_symv_res(const double* __restrict__ N0, in
 }
 // The reduced solve of a null-space Newton step in one launch (oracle: solve_ns): du = N^-1 ru, one refinement sweep on the unregularised
 // N0, and slot[0] = max(slot[0], max|ru - N0 du| / max(1, max|ru|)).
-__global__ __launch_bounds__(1024) void k_ns_reduced_solve(const double* __restrict__ L, int64_t ld, const double* __restrict__ Linv, const double* __restrict__ N0,
-                                                           int k, const double* __restrict__ ru, double* __restrict__ du, double* __restrict__ slot) {
+__global__ __launch_bounds__(1024) void k_ns_reduced_solve(AsmBt abt, const double* __restrict__ L, int64_t ld, const double* __restrict__ Linv, const double* __restrict__ N0, int k, const double* __restrict__ ru, double* __restrict__ du, double* __restrict__ slot) {
+    ASM_BARGS(abt, L, ld, Linv, N0, k, ru, du, slot);
     __shared__ double x[ASM_SMALL_MAX], y[ASM_SMALL_MAX], b[ASM_SMALL_MAX], t[64], part[16 * 64], sh[16];
     for (int i = threadIdx.x; i < k; i += 1024) { b[i] = ru[i]; x[i] = ru[i]; }
     __syncthreads();
@@ -663,7 +690,8 @@ __global__ __launch_bounds__(1024) void k_ns_reduced_solve(const double* __restr
     if (threadIdx.x == 0) slot[0] = fmax(slot[0], a / m);
 }
 // out[j] = sum_c Zt[c, j] u[c]   (k rows of pitch ld, one thread per column; u staged in LDS) - the basis applied in one launch
-__global__ __launch_bounds__(256) void k_gemv_t_small(const double* __restrict__ Zt, int64_t ld, int k, const double* __restrict__ u, double* __restrict__ out, int64_t ncols) {
+__global__ __launch_bounds__(256) void k_gemv_t_small(AsmBt abt, const double* __restrict__ Zt, int64_t ld, int k, const double* __restrict__ u, double* __restrict__ out, int64_t ncols) {
+    ASM_BARGS(abt, Zt, ld, k, u, out, ncols);
     __shared__ double us[ASM_SMALL_MAX];
     for (int i = threadIdx.x; i < k; i += 256) us[i] = u[i];
     __syncthreads();
@@ -676,16 +704,16 @@ __global__ __launch_bounds__(256) void k_gemv_t_small(const double* __restrict__
 
 // ---- banded S0 = A_EF A_EF' built from its structural pattern (equality rows in reverse Cuthill-McKee order)
 // clears row i, columns [i - w + 1, i] (w covers the band rounded up to the factorisation's tiles; the factor of the previous LP lives there)
-__global__ __launch_bounds__(256) void k_ns_zero_band(double* __restrict__ S, int64_t ld, int nE, int w) {
+__global__ __launch_bounds__(256) void k_ns_zero_band(AsmBt abt, double* __restrict__ S, int64_t ld, int nE, int w) {
+    ASM_BARGS(abt, S, ld, nE, w);
     const int i = blockIdx.y;
     const int c = i - (int)(blockIdx.x * 256 + threadIdx.x);
     if (i < nE && c >= 0 && (int)(blockIdx.x * 256 + threadIdx.x) < w) S[(int64_t)i * ld + c] = 0.0;
 }
 // one thread per structural entry (pi, pj), pj <= pi: the dot product of rows Eidx[pi] and Eidx[pj] over the free columns (both rows' column
 // lists are sorted: a merge)
-__global__ __launch_bounds__(256) void k_ns_s0_sparse(const int* __restrict__ pairs, int64_t npairs, const int* __restrict__ ptr, const int* __restrict__ col,
-                                                      const double* __restrict__ val, const int* __restrict__ Eidx, const double* __restrict__ Fm,
-                                                      double* __restrict__ S, int64_t ld) {
+__global__ __launch_bounds__(256) void k_ns_s0_sparse(AsmBt abt, const int* __restrict__ pairs, int64_t npairs, const int* __restrict__ ptr, const int* __restrict__ col, const double* __restrict__ val, const int* __restrict__ Eidx, const double* __restrict__ Fm, double* __restrict__ S, int64_t ld) {
+    ASM_BARGS(abt, pairs, npairs, ptr, col, val, Eidx, Fm, S, ld);
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= npairs) return;
     const int pi = pairs[2 * t], pj = pairs[2 * t + 1];
@@ -704,9 +732,8 @@ __global__ __launch_bounds__(256) void k_ns_s0_sparse(const int* __restrict__ pa
 
 // Gram matrix of a row list in the handle's banded row order, entry by entry: pair (ri, rj) of rows that share a column -> place (cpos[ri], cpos[rj])
 // of the list (skipped when either row is not in it); weights theta over the columns, `diag` (indexed by place) added on the diagonal
-__global__ __launch_bounds__(256) void k_schur_sparse(const int* __restrict__ pairs, int64_t npairs, const int* __restrict__ cpos, const int* __restrict__ ptr,
-                                                      const int* __restrict__ col, const double* __restrict__ val, const double* __restrict__ theta,
-                                                      const double* __restrict__ diag, double* __restrict__ S, int64_t ld, const int* __restrict__ vpos) {
+__global__ __launch_bounds__(256) void k_schur_sparse(AsmBt abt, const int* __restrict__ pairs, int64_t npairs, const int* __restrict__ cpos, const int* __restrict__ ptr, const int* __restrict__ col, const double* __restrict__ val, const double* __restrict__ theta, const double* __restrict__ diag, double* __restrict__ S, int64_t ld, const int* __restrict__ vpos) {
+    ASM_BARGS(abt, pairs, npairs, cpos, ptr, col, val, theta, diag, S, ld, vpos);
     // vpos: the lists (ptr, col) are the CSC side of the pattern (Gram matrix of COLUMNS: the column form's K = Th + A' D^-1 A) and entry a of
     // a list has its value at val[vpos[a]]; null: CSR, values in list order
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
