@@ -22,6 +22,23 @@ class KernelStats(C.Structure):
     _fields_ = [("ms", C.c_double * 7), ("calls", C.c_int64 * 7), ("flops", C.c_double * 7), ("bytes", C.c_double * 7)]
 
 
+class SlpParams(C.Structure):
+    """asm_slp_params (src/parameters.jl:17-28)."""
+    _fields_ = [("max_iter", C.c_int32), ("max_lp_solves", C.c_int32), ("tol_direction", C.c_double), ("tol_residual", C.c_double),
+                ("tol_infeas", C.c_double), ("eta", C.c_double), ("tau", C.c_double), ("min_alpha", C.c_double)]
+
+
+class SlpResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("iter", C.c_int32), ("lp_solves", C.c_int32), ("restoration_solves", C.c_int32),
+                ("ls_trials", C.c_int32), ("slot", C.c_int32), ("paths", C.c_int32 * 12), ("ipm_iters", C.c_int32), ("ns_cold", C.c_int32),
+                ("obj_val", C.c_double), ("prim_infeas", C.c_double), ("dual_infeas", C.c_double), ("compl_", C.c_double)]
+
+
+class BatchStats(C.Structure):
+    _fields_ = [("rounds", C.c_int64), ("ops", C.c_int64), ("launches", C.c_int64), ("releases", C.c_int64), ("blob_bytes", C.c_int64),
+                ("emit_ms", C.c_double), ("wait_ms", C.c_double), ("host_ms", C.c_double), ("wall_ms", C.c_double)]
+
+
 _P = C.c_void_p
 _D = C.POINTER(C.c_double)
 _I64 = C.POINTER(C.c_int64)
@@ -55,6 +72,21 @@ PROTOTYPES = {
     "asm_slp_merit": (C.c_int, [_P, C.c_int, C.c_double, _D, _D, _D, C.c_int, C.c_double, _D]),
     "asm_slp_line_search": (C.c_int, [_P, _D, _D, _D, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _D, _D,
                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "asm_sublp_set_ns_basis": (C.c_int, [_P, _I32, C.c_int64]),
+    "asm_slp_run": (C.c_int, [_P, C.POINTER(SlpParams), _D, _D, _D, _D, _D, _D, C.POINTER(SlpResult)]),
+    "asm_batch_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(_P)]),
+    "asm_batch_destroy": (C.c_int, [_P]),
+    "asm_batch_last_error": (C.c_char_p, [_P]),
+    "asm_batch_slots": (C.c_int, [_P]),
+    "asm_batch_handle": (_P, [_P, C.c_int]),
+    "asm_batch_setup": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, _I64, _I64, _D, _D, _D, _D]),
+    "asm_batch_eval_setup": (C.c_int, [_P, C.c_int64, _I64, _I64, _D, _I64, _I64, _I64, _D, _D, _I64, _I64, _I64, _D, _I64, C.c_double, C.c_int,
+                                       C.c_int64, C.c_int64, _I64, C.c_int64, _D, C.c_int64]),
+    "asm_batch_set_ns_basis": (C.c_int, [_P, _I32, C.c_int64]),
+    "asm_batch_ns_basis": (C.c_int, [_P, _I32, _I64]),
+    "asm_batch_sublp_solve": (C.c_int, [_P, C.c_int, _D, _D, _D, _D, _D, _D, _D, _D, _D, _D, _I32, _D, _D, _D, _D, _D, _I32]),
+    "asm_batch_slp_run": (C.c_int, [_P, C.c_int64, _D, _D, _D, _D, _D, C.POINTER(SlpParams), _D, _D, _D, _D, _D, C.POINTER(SlpResult)]),
+    "asm_batch_get_stats": (C.c_int, [_P, C.POINTER(BatchStats)]),
     "asm_test_syrk": (C.c_int, [_P, _D, C.c_int64, C.c_int64, _I32, C.c_int64, _D, _D, _D, C.c_int]),
     "asm_test_syrk_update": (C.c_int, [_P, _D, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _D, C.c_int]),
     "asm_test_cholesky": (C.c_int, [_P, _D, C.c_int64, _D]),

@@ -313,6 +313,7 @@ struct asm_handle {
     asm_kernel_stats kstats;
     std::vector<TimedRegion> regions;
     std::vector<hipEvent_t> event_pool;
+    bool batch_slot = false;        // slot of an asm_batch: the stream belongs to the batch, no look-ahead stream, no event timing
     bool fused_panel = true;        // Cholesky inner panels as one dataflow launch (k_chol_panel) instead of three launches per 64-wide step
     int panel_wgs = 240;            // its grid bound: every workgroup must be able to become resident
     int num_cus = 256;              // compute units of the device (hipDeviceProp_t::multiProcessorCount)
@@ -841,7 +842,7 @@ struct Dev {
         // stream beside (b), so the latency-bound chain hides under the MFMA-bound update.
         const int NBO = CHOL_NBO;
         const int nP = (Ms + NBO - 1) / NBO;
-        const bool la = nP > 2;
+        const bool la = nP > 2 && !h->batch_slot;      // (a batch slot records its launches for ONE stream)
         while ((int)h->la_events.size() < 2 * nP + 2) {
             hipEvent_t e;
             HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1106,6 +1107,11 @@ struct Solver {
         if (pub == 0) {
             HIPCHK(hipMemcpyAsync(h->h_scal, P.scal, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
+            return;
+        }
+        if (asmb::in_fiber()) {      // scenario batch: the publishing kernel is recorded; the round that launches it ends before this fiber resumes
+            asmb::flush_wait();
+            if (__atomic_load_n(h->h_seq, __ATOMIC_ACQUIRE) != pub) throw HipError("read_scal: the batch round ended without the publishing kernel's sequence word");
             return;
         }
         // hot spin for the common case (the kernel is next on an otherwise idle stream: 6.7 us), then yield, then sleep: with several
@@ -1717,10 +1723,12 @@ struct Solver {
         hipLaunchKernelGGL(k_ipm_dir, dim3(g), dim3(256), 0, h->stream, P, D, d_tN);
     }
 
+    int btag = 100;      // alignment tags of a scenario batch grow in program order inside one LP (asm_batch.hip.h)
     int ipm_run(double tol, int max_more) {
         const int M = (int)lp.M;
         int done = 0;
         while (true) {
+            asmb::barrier(btag);                 // scenario batch: iterations of different scenarios run in lockstep (min-PC-first)
             ipm_measures();
             if (h->verbose) std::fprintf(stderr, "[asm] ipm %3d pinf %.3e dinf %.3e gap %.3e\n", ip.iters, ip.pinf, ip.dinf, ip.gap);
             if (ip.pinf <= tol && ip.gap <= tol && (ip.dinf <= tol || (ip.gap <= IPM_GAP_DONE * tol && ip.dinf <= IPM_DINF_FLOOR))) {
@@ -2020,6 +2028,7 @@ struct Solver {
         bool have_prev = false;
         double t_round = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
         for (int k = 0; k <= rounds; ++k) {
+            asmb::barrier(btag + 60 + k);
             if (ns_lp && p_ref == d_zero && y_ref == nullptr) {
                 if (!as_solve_ns(S_[cur])) return false;
             } else {
@@ -2278,6 +2287,8 @@ struct Solver {
         h->stats.path = -1;
         h->stats.polished = 1;
         cur_hint = &hint;
+        btag = 30;
+        asmb::barrier(btag);
         ipm_upload_lp();
         as_begin_lp();
         // null-space basis of the equality rows (oracle: solve_scaled): made first, the active-set solves of the warm attempt and of the
@@ -2303,6 +2314,7 @@ struct Solver {
                 hint.warm_skip -= 1;
             } else {
                 double t0 = now_ms();
+                btag = 40 - 60;
                 as_upload_sets(*warm, 0);
                 bool okw = eqp_loop(d_zero, nullptr, 1);
                 t_warm += now_ms() - t0;
@@ -2313,13 +2325,17 @@ struct Solver {
             }
         }
         const bool prefer_ref = hint.prefer_ref;
+        btag = 90;
+        asmb::barrier(btag);
         ipm_init();
         const double tols[3] = {1e-9, 1e-10, 1e-12};      // oracle: IPM_STAGES
         const int more[3] = {IPM_MAXIT, 6, 6};
         bool have_sets = false;
         for (int stage = 0; stage < 3; ++stage) {
             double t0 = now_ms();
+            btag = 100 + 100 * stage;
             int st = ipm_run(tols[stage], more[stage]);
+            asmb::barrier(btag + 50);
             t_ipm += now_ms() - t0;
             h->stats.ipm_iters = ip.iters;
             h->stats.col_iters = ip.col_iters;
@@ -2366,6 +2382,8 @@ struct Solver {
             t_polish += now_ms() - t1;
             if (okp) { h->stats.path = 1 + stage; return ASM_OPTIMAL; }
         }
+        btag = 400;
+        asmb::barrier(btag);
         if (have_sets) {
             double t1 = now_ms();
             // non-unique optimum: canonical (least-norm) pair of the optimal faces the partition describes (oracle: face_polish)
@@ -2841,6 +2859,7 @@ void solve_raw(asm_handle* h, const LpRaw& L, int slot, LpSol& out) {
         std::fprintf(stderr, "[asm] solve_raw %-10s +%.2f ms\n", what, t - (last > tr0 ? last : tr0));
         last = t;
     };
+    asmb::barrier(20);
     sv.dev.assemble();
     lap("assemble");
     sv.dev.col_relmax(rel.data());
@@ -2870,6 +2889,7 @@ void solve_raw(asm_handle* h, const LpRaw& L, int slot, LpSol& out) {
     lap("host-lp");
     out.status = sv.solve_scaled(&h->warm[slot], h->hint[slot]);
     lap("solve");
+    asmb::barrier(900);
     if (out.status == ASM_OPTIMAL) {
         sv.as_download(o, out.as);
         const ActiveSet& prev = h->warm[slot];
@@ -3109,8 +3129,10 @@ int asm_destroy(asm_handle* h) {
     for (auto e : h->event_pool) (void)hipEventDestroy(e);
     free_device(h);
     for (auto e : h->la_events) (void)hipEventDestroy(e);
-    if (h->stream2) (void)hipStreamDestroy(h->stream2);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (!h->batch_slot) {
+        if (h->stream2) (void)hipStreamDestroy(h->stream2);
+        if (h->stream) (void)hipStreamDestroy(h->stream);
+    }
     delete h;
     return ASM_OK;
 }
@@ -3142,8 +3164,12 @@ int asm_sublp_set_bounds(asm_handle* h, const double* c_lb, const double* c_ub, 
             HIPCHK(hipMemcpy(h->d_ev_vecs + 2 * h->m, h->v_lb.data(), h->n * sizeof(double), hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(h->d_ev_vecs + 2 * h->m + h->n, h->v_ub.data(), h->n * sizeof(double), hipMemcpyHostToDevice));
         }
+        // the retained working sets and the basis Z belong to the old instance; the basis COLUMNS of the null-space form are kept - the
+        // pattern is the same, and a set that no longer spans null(A_EF) is detected and re-selected by the next LP (Solver::ns_setup)
+        std::vector<int> keepJ = h->hint[0].ns_J;
         h->warm[0] = ActiveSet(); h->warm[1] = ActiveSet(); h->last = ActiveSet();
         h->hint[0] = SolveHint(); h->hint[1] = SolveHint();
+        h->hint[0].ns_J.swap(keepJ);
         h->ns_Zk = 0;
         h->hint[1].prefer_ref = true;
         h->inputs_ready = false;
@@ -3469,6 +3495,7 @@ int asm_slp_line_search(asm_handle* h, const double* p, const double* nu, const 
         int trials = 0;
         *ok_out = -1;
         while (*ok_out < 0) {
+            asmb::barrier(920);
             // eight trial points per set of launches (trial index in the grid): x + alpha_t p, the function values there, the merit values
             TrialAlphas al;
             for (int t = 0; t < CH; ++t) { a[t] = al.a[t] = alpha; alpha *= tau; }
@@ -3687,6 +3714,352 @@ int asm_test_assemble(asm_handle* h, const double* dE, double* J_out) {
             HIPCHK(hipMemcpy(J_out + i * h->n, h->d_J + i * h->ldn, h->n * sizeof(double), hipMemcpyDeviceToHost));
         d.resolve_timing();
     });
+}
+
+
+int asm_sublp_set_ns_basis(asm_handle* h, const int32_t* J, int64_t k) {
+    return guarded(h, [&] {
+        if (!h->setup_done || k < 0 || (k > 0 && !J)) throw std::invalid_argument("asm_sublp_set_ns_basis: setup first / bad argument");
+        for (int64_t a = 0; a < k; ++a)
+            if (J[a] < 0 || J[a] >= h->n) throw std::invalid_argument("asm_sublp_set_ns_basis: column out of range");
+        h->hint[0].ns_J.assign(J, J + k);
+        h->ns_Zk = 0;
+    });
+}
+
+}  // extern "C"
+
+// =========================================================================================================
+// Native SLP driver (rows f2 of SURVEY.md section 8): run!(::SlpLS), slp_line_search.jl:78-215, on the device evaluator - the same
+// sequence of library calls as activesetmethods_amd/slp.py (SlpLS.run with Parameters(device_eval=True)), statement by statement, so
+// that a whole scenario solve is one C call and B of them can run as fibers of one host thread (asm_batch_slp_run).
+// =========================================================================================================
+namespace {
+
+struct SlpRunLS {
+    asm_handle* h;
+    const asm_slp_params& o;
+    int64_t n, m;
+    vec x, p, lam, mU, mL, ps, df, E, nu;
+    double f = 0.0, phi = INF, alpha = 1.0, D = 0.0, prim_infeas = INF, dual_infeas = INF, compl_ = INF;
+    bool fr = false;
+    int iter = 1, ret = -5, lp_solves = 0, fr_solves = 0, ls_trials = 0;
+    asm_slp_result* res;
+
+    SlpRunLS(asm_handle* hh, const asm_slp_params& par, asm_slp_result* r) : h(hh), o(par), n(hh->n), m(hh->m), res(r) {
+        x.assign(n, 0.0); p.assign(n, 0.0); lam.assign(m, 0.0); mU.assign(n, 0.0); mL.assign(n, 0.0);
+        ps.assign(2 * std::max<int64_t>(m, 1), 0.0); df.assign(n, 0.0); E.assign(std::max<int64_t>(m, 1), 0.0); nu.assign(m, 0.0);
+    }
+    void chk(int rc, const char* what) {
+        if (rc != ASM_OK) throw HipError(std::string(what) + ": " + h->err);
+    }
+    bool feasible_enough() const { return prim_infeas <= o.tol_infeas; }
+    double finite_or_zero(double v) const { return std::isfinite(v) ? v : 0.0; }
+
+    void run(const double* x0) {
+        // slp_line_search.jl:96-104 (the clamp tests x_U > -Inf, sic)
+        for (int64_t j = 0; j < n; ++j) {
+            double v = x0[j];
+            if (h->v_lb[j] > -INF) v = std::max(v, h->v_lb[j]);
+            if (h->v_ub[j] > -INF) v = std::min(v, h->v_ub[j]);
+            x[j] = v;
+        }
+        iter = 1;
+        while (true) {
+            if (o.max_lp_solves > 0 && lp_solves >= o.max_lp_solves) break;
+            asmb::next_cycle();
+            asmb::barrier(10);
+            chk(asm_eval_functions(h, x.data(), &f, df.data(), E.data()), "asm_eval_functions");      // :109-110
+            alpha = 0.0;
+            double nrm[4];
+            chk(asm_slp_norms(h, lam.data(), mU.data(), mL.data(), nrm), "asm_slp_norms");             // :113-118, the previous LP's multipliers
+            prim_infeas = nrm[0]; dual_infeas = nrm[2]; compl_ = nrm[3];
+            int32_t status = 0;
+            chk(asm_sublp_solve_resident(h, 1000.0, fr ? 1 : 0, p.data(), lam.data(), mU.data(), mL.data(), ps.data(), &status), "asm_sublp_solve_resident");   // :122-123
+            lp_solves += 1;
+            if (fr) fr_solves += 1;
+            if (res) {
+                const int pth = h->stats.path;
+                if (pth >= 0 && pth < 12) res->paths[pth] += 1;
+                res->ipm_iters += h->stats.ipm_iters;
+                res->ns_cold += h->stats.ns_cold;
+            }
+            if (status != ASM_OPTIMAL && status != ASM_INFEASIBLE) {                                     // :127-133
+                if (feasible_enough()) ret = 6;
+                break;
+            }
+            if (status == ASM_INFEASIBLE) {                                                              // :135-147
+                if (fr) { ret = feasible_enough() ? 6 : 2; break; }
+                fr = true;
+                continue;
+            }
+            for (int64_t i = 0; i < m; ++i) nu[i] = iter == 1 ? std::fabs(lam[i]) : std::max(nu[i], std::fabs(lam[i]));       // :251-261
+            asmb::barrier(910);
+            chk(asm_slp_merit(h, 0, 0.0, p.data(), nu.data(), ps.data(), fr ? 1 : 0, finite_or_zero(prim_infeas), &phi), "asm_slp_merit");
+            chk(asm_slp_merit(h, 1, 0.0, p.data(), nu.data(), ps.data(), fr ? 1 : 0, finite_or_zero(prim_infeas), &D), "asm_slp_merit");
+            int trials = 0, ok = 0;
+            double phi_a = 0.0;
+            chk(asm_slp_line_search(h, p.data(), nu.data(), ps.data(), fr ? 1 : 0, finite_or_zero(prim_infeas), phi, D, o.eta, o.tau, o.min_alpha, &alpha, &phi_a,
+                                    &trials, &ok), "asm_slp_line_search");                                // :222-244
+            ls_trials += trials;
+            if (!ok && fr) ret = -3;
+            const bool valid = ok != 0;
+            if (iter >= o.max_iter) { ret = feasible_enough() ? 6 : -1; break; }                         // :160-166
+            double pmax = 0.0;
+            for (int64_t j = 0; j < n; ++j) pmax = std::max(pmax, std::fabs(p[j]));
+            if ((feasible_enough() && compl_ <= o.tol_residual) || pmax <= o.tol_direction) {            // :168-182
+                if (fr) { fr = false; iter += 1; continue; }
+                if (dual_infeas <= o.tol_residual) { ret = 0; break; }
+            }
+            if (!valid) {                                                                                 // :184-199
+                if (ret == -3) { ret = feasible_enough() ? 6 : 2; break; }
+                fr = true;
+                iter += 1;
+                continue;
+            }
+            for (int64_t j = 0; j < n; ++j) x[j] = x[j] + alpha * p[j];                                  // :201-203
+            iter += 1;
+        }
+        // :208-214: objective at the final point
+        double f_end = 0.0;
+        vec Et(std::max<int64_t>(m, 1));
+        asmb::barrier(990);
+        chk(asm_eval_constraints(h, x.data(), &f_end, Et.data()), "asm_eval_constraints");
+        if (res) {
+            res->status = ret; res->iter = iter; res->lp_solves = lp_solves; res->restoration_solves = fr_solves; res->ls_trials = ls_trials;
+            res->obj_val = f_end; res->prim_infeas = prim_infeas; res->dual_infeas = dual_infeas; res->compl_ = compl_;
+        }
+    }
+};
+
+void slp_run_ls(asm_handle* h, const asm_slp_params* par, const double* x0, double* x_out, double* lambda, double* mult_x_U, double* mult_x_L, double* g_out,
+                asm_slp_result* res) {
+    if (!h->ev_ready) throw std::logic_error("asm_slp_run: asm_eval_setup first (the native driver evaluates on the device)");
+    if (res) std::memset(res, 0, sizeof(*res));
+    SlpRunLS r(h, *par, res);
+    r.run(x0);
+    if (x_out) std::memcpy(x_out, r.x.data(), h->n * sizeof(double));
+    if (lambda && h->m) std::memcpy(lambda, r.lam.data(), h->m * sizeof(double));
+    if (mult_x_U) std::memcpy(mult_x_U, r.mU.data(), h->n * sizeof(double));
+    if (mult_x_L) std::memcpy(mult_x_L, r.mL.data(), h->n * sizeof(double));
+    if (g_out && h->m) std::memcpy(g_out, r.E.data(), h->m * sizeof(double));
+}
+
+}  // namespace
+
+struct asm_batch {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<asm_handle*> slots;
+    asmb::Sched sched;
+    std::string err;
+    std::vector<int> J_ref;         // basis columns of the null-space form every scenario starts from (first cold selection of the batch)
+    bool setup_done = false;
+    asm_batch_stats stats;
+};
+
+namespace {
+template <class F>
+int bguarded(asm_batch* b, F&& fn) {
+    if (!b) return ASM_ERR_ARG;
+    try {
+        fn();
+        return ASM_OK;
+    } catch (const HipError& e) { b->err = e.what(); return ASM_ERR_HIP; }
+    catch (const asmb::BatchError& e) { b->err = e.what(); return ASM_ERR_HIP; }
+    catch (const std::invalid_argument& e) { b->err = e.what(); return ASM_ERR_ARG; }
+    catch (const std::logic_error& e) { b->err = e.what(); return ASM_ERR_STATE; }
+    catch (const std::exception& e) { b->err = e.what(); return ASM_ERR_ARG; }
+}
+void bcheck(asm_batch* b, int slot, int rc, const char* what) {
+    if (rc != ASM_OK) throw HipError(std::string(what) + " (slot " + std::to_string(slot) + "): " + b->slots[slot]->err);
+}
+// run `work(slot)` for every slot in [0, count) as fibers of this thread, launches merged across slots
+template <class W>
+void run_fibers(asm_batch* b, int count, W&& work) {
+    asmb::Sched& S = b->sched;
+    for (asmb::Fiber* f : S.fibers) { if (f->stack) munmap(f->stack, f->stack_size); delete f; }
+    S.fibers.clear();
+    for (int s = 0; s < count; ++s) S.add_fiber([&work, s] { work(s); });
+    const double t0 = asmb::Sched::now_ms();
+    S.run();
+    b->stats.wall_ms += asmb::Sched::now_ms() - t0;
+    b->stats.rounds = (int64_t)S.n_rounds; b->stats.ops = (int64_t)S.n_ops; b->stats.launches = (int64_t)S.n_launches; b->stats.releases = (int64_t)S.n_releases;
+    b->stats.blob_bytes = (int64_t)S.blob_bytes; b->stats.emit_ms = S.t_emit_ms; b->stats.wait_ms = S.t_wait_ms; b->stats.host_ms = S.t_host_ms;
+}
+}  // namespace
+
+extern "C" {
+
+int asm_slp_run(asm_handle* h, const asm_slp_params* par, const double* x0, double* x, double* lambda, double* mult_x_U, double* mult_x_L, double* g,
+                asm_slp_result* res) {
+    return guarded(h, [&] {
+        if (!par || !x0) throw std::invalid_argument("asm_slp_run: null pointer");
+        slp_run_ls(h, par, x0, x, lambda, mult_x_U, mult_x_L, g, res);
+    });
+}
+
+int asm_batch_create(int device, int n_slots, asm_batch** out) {
+    if (!out || n_slots < 1 || n_slots > 4096) return ASM_ERR_ARG;
+    *out = nullptr;
+    asm_batch* b = new (std::nothrow) asm_batch();
+    if (!b) return ASM_ERR_ARG;
+    b->device = device;
+    std::memset(&b->stats, 0, sizeof(b->stats));
+    int rc = ASM_OK;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&b->stream) != hipSuccess) { delete b; return ASM_ERR_HIP; }
+    for (int s = 0; s < n_slots && rc == ASM_OK; ++s) {
+        asm_handle* h = nullptr;
+        rc = asm_create(device, &h);
+        if (rc != ASM_OK) break;
+        // the slot's launches are recorded and merged onto the batch's stream: no streams of its own, no look-ahead stream, no event timing
+        (void)hipStreamDestroy(h->stream2);
+        (void)hipStreamDestroy(h->stream);
+        h->stream = b->stream; h->stream2 = b->stream;
+        h->batch_slot = true;
+        h->timing = 0;
+        b->slots.push_back(h);
+    }
+    if (rc == ASM_OK) {
+        try {
+            b->sched.init(device, b->stream, b->slots[0]->panel_wgs);
+            if (const char* nb = std::getenv("ASM_BATCH_NO_BARRIERS")) b->sched.use_barriers = !(nb[0] == '1');
+        } catch (const std::exception&) { rc = ASM_ERR_HIP; }
+    }
+    if (rc != ASM_OK) {
+        for (asm_handle* h : b->slots) (void)asm_destroy(h);
+        (void)hipStreamDestroy(b->stream);
+        delete b;
+        return rc;
+    }
+    *out = b;
+    return ASM_OK;
+}
+
+int asm_batch_destroy(asm_batch* b) {
+    if (!b) return ASM_ERR_ARG;
+    (void)hipSetDevice(b->device);
+    (void)hipStreamSynchronize(b->stream);
+    for (asm_handle* h : b->slots) (void)asm_destroy(h);
+    b->sched.release();
+    (void)hipStreamDestroy(b->stream);
+    delete b;
+    return ASM_OK;
+}
+
+const char* asm_batch_last_error(const asm_batch* b) { return b ? b->err.c_str() : "null batch"; }
+int asm_batch_slots(const asm_batch* b) { return b ? (int)b->slots.size() : 0; }
+asm_handle* asm_batch_handle(asm_batch* b, int slot) { return (b && slot >= 0 && slot < (int)b->slots.size()) ? b->slots[slot] : nullptr; }
+
+int asm_batch_setup(asm_batch* b, int64_t n, int64_t m, int64_t nnz, const int64_t* j_row, const int64_t* j_col, const double* c_lb, const double* c_ub,
+                    const double* v_lb, const double* v_ub) {
+    return bguarded(b, [&] {
+        for (size_t s = 0; s < b->slots.size(); ++s) bcheck(b, (int)s, asm_sublp_setup(b->slots[s], n, m, nnz, j_row, j_col, c_lb, c_ub, v_lb, v_ub), "asm_sublp_setup");
+        b->J_ref.clear();
+        b->setup_done = true;
+    });
+}
+
+int asm_batch_eval_setup(asm_batch* b, int64_t n_rows, const int64_t* aff_ptr, const int64_t* aff_var, const double* aff_coef, const int64_t* quad_ptr,
+                         const int64_t* q_v1, const int64_t* q_v2, const double* q_coef, const double* constant, const int64_t* jac_off, const int64_t* g_ptr,
+                         const int64_t* g_kind, const double* g_coef, const int64_t* g_other, double objective_scale, int nlp_kind, int64_t nlp_rows,
+                         int64_t nlp_nnz, const int64_t* nlp_ipar, int64_t n_ipar, const double* nlp_dpar, int64_t n_dpar) {
+    return bguarded(b, [&] {
+        if (!b->setup_done) throw std::logic_error("asm_batch_eval_setup: asm_batch_setup first");
+        for (size_t s = 0; s < b->slots.size(); ++s)
+            bcheck(b, (int)s, asm_eval_setup(b->slots[s], n_rows, aff_ptr, aff_var, aff_coef, quad_ptr, q_v1, q_v2, q_coef, constant, jac_off, g_ptr, g_kind, g_coef,
+                                             g_other, objective_scale, nlp_kind, nlp_rows, nlp_nnz, nlp_ipar, n_ipar, nlp_dpar, n_dpar), "asm_eval_setup");
+    });
+}
+
+int asm_batch_set_ns_basis(asm_batch* b, const int32_t* J, int64_t k) {
+    return bguarded(b, [&] {
+        if (!b->setup_done || k < 0 || (k > 0 && !J)) throw std::invalid_argument("asm_batch_set_ns_basis: setup first / bad argument");
+        b->J_ref.assign(J, J + k);
+        for (size_t s = 0; s < b->slots.size(); ++s) bcheck(b, (int)s, asm_sublp_set_ns_basis(b->slots[s], J, k), "asm_sublp_set_ns_basis");
+    });
+}
+
+// `count` LPs in lockstep, one per slot: asm_sublp_solve with a leading scenario dimension on every array
+int asm_batch_sublp_solve(asm_batch* b, int count, const double* c_lb, const double* c_ub, const double* v_lb, const double* v_ub, const double* dE,
+                          const double* df, const double* f, const double* E, const double* x_k, const double* delta, const int32_t* feasibility, double* p,
+                          double* lambda, double* mult_x_U, double* mult_x_L, double* p_slack, int32_t* status) {
+    return bguarded(b, [&] {
+        if (!b->setup_done) throw std::logic_error("asm_batch_sublp_solve: asm_batch_setup first");
+        if (count < 1 || count > (int)b->slots.size() || !dE || !df || !f || !x_k || !delta || !feasibility || !p || !mult_x_U || !mult_x_L || !status)
+            throw std::invalid_argument("asm_batch_sublp_solve: bad count or null pointer");
+        const int64_t n = b->slots[0]->n, m = b->slots[0]->m, nnz = b->slots[0]->nnz;
+        if (m > 0 && (!E || !lambda || !p_slack)) throw std::invalid_argument("asm_batch_sublp_solve: null pointer");
+        HIPCHK(hipSetDevice(b->device));
+        run_fibers(b, count, [&](int s) {
+            asm_handle* h = b->slots[s];
+            if (c_lb && c_ub && v_lb && v_ub) bcheck(b, s, asm_sublp_set_bounds(h, c_lb + s * m, c_ub + s * m, v_lb + s * n, v_ub + s * n), "asm_sublp_set_bounds");
+            asmb::next_cycle();
+            bcheck(b, s, asm_sublp_solve(h, dE + s * nnz, df + s * n, f[s], E ? E + s * m : nullptr, x_k + s * n, delta[s], feasibility[s], p + s * n,
+                                         lambda ? lambda + s * m : nullptr, mult_x_U + s * n, mult_x_L + s * n, p_slack ? p_slack + s * 2 * m : nullptr, status + s),
+                   "asm_sublp_solve");
+        });
+    });
+}
+
+// n_scen complete SLP runs (Line Search): the slots' fibers take the scenarios in index order; every array has a leading scenario dimension
+int asm_batch_slp_run(asm_batch* b, int64_t n_scen, const double* c_lb, const double* c_ub, const double* v_lb, const double* v_ub, const double* x0,
+                      const asm_slp_params* par, double* x, double* lambda, double* mult_x_U, double* mult_x_L, double* g, asm_slp_result* res) {
+    return bguarded(b, [&] {
+        if (!b->setup_done) throw std::logic_error("asm_batch_slp_run: asm_batch_setup first");
+        if (n_scen < 1 || !c_lb || !c_ub || !v_lb || !v_ub || !x0 || !par || !res) throw std::invalid_argument("asm_batch_slp_run: bad argument");
+        const int64_t n = b->slots[0]->n, m = b->slots[0]->m;
+        HIPCHK(hipSetDevice(b->device));
+        if (b->J_ref.empty()) {
+            // reference selection of the null-space basis columns: one LP of scenario 0 at its start point on slot 0 (cold selection); EVERY
+            // scenario, 0 included, then starts from these columns - the results do not depend on the slot or on what it solved before
+            asm_handle* h0 = b->slots[0];
+            bcheck(b, 0, asm_sublp_set_bounds(h0, c_lb, c_ub, v_lb, v_ub), "asm_sublp_set_bounds");
+            h0->hint[0].ns_J.clear();
+            vec xs(n), dfs(n), Es(std::max<int64_t>(m, 1)), pp(n), ll(std::max<int64_t>(m, 1)), uu(n), lo(n), sl(2 * std::max<int64_t>(m, 1));
+            for (int64_t j = 0; j < n; ++j) {
+                double v = x0[j];
+                if (v_lb[j] > -INF) v = std::max(v, v_lb[j]);
+                if (v_ub[j] > -INF) v = std::min(v, v_ub[j]);
+                xs[j] = v;
+            }
+            double f0 = 0.0;
+            int32_t st0 = 0;
+            bcheck(b, 0, asm_eval_functions(h0, xs.data(), &f0, dfs.data(), Es.data()), "asm_eval_functions");
+            bcheck(b, 0, asm_sublp_solve_resident(h0, 1000.0, 0, pp.data(), ll.data(), uu.data(), lo.data(), sl.data(), &st0), "asm_sublp_solve_resident");
+            b->J_ref = h0->hint[0].ns_J;
+        }
+        const int count = (int)std::min<int64_t>(n_scen, (int64_t)b->slots.size());
+        int64_t next = 0;
+        run_fibers(b, count, [&](int s) {
+            asm_handle* h = b->slots[s];
+            for (;;) {
+                const int64_t sc = next;
+                if (sc >= n_scen) break;
+                next = sc + 1;
+                bcheck(b, s, asm_sublp_set_bounds(h, c_lb + sc * m, c_ub + sc * m, v_lb + sc * n, v_ub + sc * n), "asm_sublp_set_bounds");
+                // every scenario starts from the batch's reference basis columns (results do not depend on which slot solved what before)
+                if (!b->J_ref.empty()) h->hint[0].ns_J = b->J_ref;
+                else h->hint[0].ns_J.clear();
+                slp_run_ls(h, par, x0 + sc * n, x ? x + sc * n : nullptr, lambda ? lambda + sc * m : nullptr, mult_x_U ? mult_x_U + sc * n : nullptr,
+                           mult_x_L ? mult_x_L + sc * n : nullptr, g ? g + sc * m : nullptr, res + sc);
+                res[sc].slot = s;
+            }
+        });
+    });
+}
+
+int asm_batch_ns_basis(const asm_batch* b, int32_t* J, int64_t* k) {
+    if (!b || !k) return ASM_ERR_ARG;
+    *k = (int64_t)b->J_ref.size();
+    if (J) for (size_t a = 0; a < b->J_ref.size(); ++a) J[a] = b->J_ref[a];
+    return ASM_OK;
+}
+
+int asm_batch_get_stats(const asm_batch* b, asm_batch_stats* out) {
+    if (!b || !out) return ASM_ERR_ARG;
+    *out = b->stats;
+    return ASM_OK;
 }
 
 }  // extern "C"

@@ -194,6 +194,79 @@ int asm_slp_merit(asm_handle* h, int mode, double alpha, const double* p, const 
 int asm_slp_line_search(asm_handle* h, const double* p, const double* nu, const double* p_slack, int feasibility, double prim_infeas, double phi0,
                         double D, double eta, double tau, double min_alpha, double* alpha, double* phi_alpha, int* trials, int* ok);
 
+/* Seed the retained basis columns of the null-space form (0-based; what asm_sublp_ns_basis returns): the next normal-phase LP builds its
+ * basis from them instead of selecting columns from scratch.  asm_sublp_set_bounds keeps the columns (same pattern), drops the basis. */
+int asm_sublp_set_ns_basis(asm_handle* h, const int32_t* J, int64_t k);
+
+/* ---- native SLP caller: run!(::SlpLS) (slp_line_search.jl:78-215) with every evaluation and reduction on the device ------------------
+ * The same sequence of library calls as the host drivers make per outer iteration (asm_eval_functions, asm_slp_norms,
+ * asm_sublp_solve_resident, asm_slp_merit x 2, asm_slp_line_search), so that one scenario solve is ONE call.  Parameters: src/parameters.jl:17-28. */
+typedef struct {
+    int32_t max_iter;          /* parameters.jl: max_iter */
+    int32_t max_lp_solves;     /* 0 = no cap (bench: fixed number of steps) */
+    double  tol_direction, tol_residual, tol_infeas, eta, tau, min_alpha;
+} asm_slp_params;
+typedef struct {
+    int32_t status;            /* slp.ret: 0 optimal, 2 infeasible, 6 almost feasible, -1 iteration limit, -3 line-search failure, -5 not finished */
+    int32_t iter, lp_solves, restoration_solves, ls_trials, slot;
+    int32_t paths[12];         /* histogram of asm_solve_stats.path over the LPs of the run */
+    int32_t ipm_iters, ns_cold;
+    double  obj_val, prim_infeas, dual_infeas, compl_;
+} asm_slp_result;
+/* x0[n] -> x[n], lambda[m], mult_x_U[n], mult_x_L[n], g[m] (constraint values at the last evaluated iterate); any output may be NULL.
+ * Needs asm_sublp_setup + asm_eval_setup on the handle. */
+int asm_slp_run(asm_handle* h, const asm_slp_params* par, const double* x0, double* x, double* lambda, double* mult_x_U, double* mult_x_L,
+                double* g, asm_slp_result* res);
+
+/* ---- scenario batches: B sub-problems with the same pattern advance through ONE launch sequence on ONE stream --------------------------
+ * The reference has no batching (one Optimizer <-> one Model <-> one SLP object, src/MOI_wrapper.jl:1093-1152); these entries are
+ * SURVEY.md section 8(b)'s "batch variants with a leading scenario dimension".  An asm_batch owns n_slots handles on one device; a batch
+ * call runs one fiber per slot on the calling thread, records every slot's kernel launches and merges equal launches of different slots
+ * into one (scenario index in the grid, argument table in HBM).  Results are bit-identical to the per-handle calls.
+ * Arrays carry a leading scenario dimension (row-major, scenario s at offset s * length). */
+typedef struct asm_batch asm_batch;
+int asm_batch_create(int device, int n_slots, asm_batch** out);
+int asm_batch_destroy(asm_batch* b);
+const char* asm_batch_last_error(const asm_batch* b);
+int asm_batch_slots(const asm_batch* b);
+/* the handle of a slot: the per-handle entries (statistics, asm_sublp_active_set, ...) work on it between batch calls */
+asm_handle* asm_batch_handle(asm_batch* b, int slot);
+/* asm_sublp_setup / asm_eval_setup for every slot (same pattern, same functions) */
+int asm_batch_setup(asm_batch* b, int64_t n, int64_t m, int64_t nnz, const int64_t* j_row, const int64_t* j_col,
+                    const double* c_lb, const double* c_ub, const double* v_lb, const double* v_ub);
+int asm_batch_eval_setup(asm_batch* b, int64_t n_rows, const int64_t* aff_ptr, const int64_t* aff_var, const double* aff_coef,
+                         const int64_t* quad_ptr, const int64_t* q_v1, const int64_t* q_v2, const double* q_coef,
+                         const double* constant, const int64_t* jac_off,
+                         const int64_t* g_ptr, const int64_t* g_kind, const double* g_coef, const int64_t* g_other,
+                         double objective_scale, int nlp_kind, int64_t nlp_rows, int64_t nlp_nnz,
+                         const int64_t* nlp_ipar, int64_t n_ipar, const double* nlp_dpar, int64_t n_dpar);
+/* basis columns every scenario of asm_batch_slp_run starts from (default: selected by one LP of scenario 0 on slot 0) */
+int asm_batch_set_ns_basis(asm_batch* b, const int32_t* J, int64_t k);
+int asm_batch_ns_basis(const asm_batch* b, int32_t* J, int64_t* k);
+/* asm_sublp_set_bounds (when the four bound arrays are given) + asm_sublp_solve for `count` <= n_slots scenarios in lockstep:
+ * c_lb, c_ub [count x m]; v_lb, v_ub, df, x_k, p, mult_x_U, mult_x_L [count x n]; dE [count x nnz]; f, delta, feasibility, status [count];
+ * E, lambda [count x m]; p_slack [count x 2m]. */
+int asm_batch_sublp_solve(asm_batch* b, int count, const double* c_lb, const double* c_ub, const double* v_lb, const double* v_ub,
+                          const double* dE, const double* df, const double* f, const double* E, const double* x_k,
+                          const double* delta, const int32_t* feasibility,
+                          double* p, double* lambda, double* mult_x_U, double* mult_x_L, double* p_slack, int32_t* status);
+/* n_scen complete SLP runs (asm_slp_run per scenario; n_scen may exceed n_slots: a slot takes the next scenario in index order when
+ * it finishes one).  c_lb, c_ub, g [n_scen x m]; v_lb, v_ub, x0, x, mult_x_U, mult_x_L [n_scen x n]; lambda [n_scen x m]; res [n_scen].
+ * Needs asm_batch_setup + asm_batch_eval_setup. */
+int asm_batch_slp_run(asm_batch* b, int64_t n_scen, const double* c_lb, const double* c_ub, const double* v_lb, const double* v_ub,
+                      const double* x0, const asm_slp_params* par,
+                      double* x, double* lambda, double* mult_x_U, double* mult_x_L, double* g, asm_slp_result* res);
+/* what the launch merging did since the batch was created */
+typedef struct {
+    int64_t rounds;        /* scheduler rounds (one blob copy + one completion wait each) */
+    int64_t ops;           /* operations the slots recorded (= launches the per-handle path would have made) */
+    int64_t launches;      /* launches actually made */
+    int64_t releases;      /* barrier groups released */
+    int64_t blob_bytes;    /* argument tables + copy payloads sent to the device */
+    double  emit_ms, wait_ms, host_ms, wall_ms;   /* merging + launching, waiting for the device, solver host code, total */
+} asm_batch_stats;
+int asm_batch_get_stats(const asm_batch* b, asm_batch_stats* out);
+
 /* Test hook: the matrices loaded by asm_test_cholesky / asm_test_chol_solve / asm_test_trsm_rows are banded with this half-bandwidth
  * (0 = dense): factorisation and substitutions stop at the band, as they do for S0 = A_EF A_EF' of the null-space form (its equality
  * rows are put in reverse Cuthill-McKee order at set-up). */
