@@ -330,6 +330,12 @@ void dmalloc(T** p, int64_t count) {
     HIPCHK(hipMalloc((void**)p, std::max<int64_t>(count, 1) * sizeof(T)));
 }
 
+// after host -> device copies whose source must stay untouched until they have run: in a scenario batch the payload was copied when the
+// operation was recorded, nothing to wait for
+inline void h2d_done(asm_handle* h) {
+    if (!asmb::in_fiber()) HIPCHK(hipStreamSynchronize(h->stream));
+}
+
 double* ns_dalloc(asm_handle* h, int64_t count) {
     double* d = nullptr;
     dmalloc(&d, count);
@@ -338,9 +344,12 @@ double* ns_dalloc(asm_handle* h, int64_t count) {
     return d;
 }
 // buffers of one Cholesky factor of order <= N (pitch = N rounded up to 32) with the block inverses of the substitution kernels
-void ns_alloc_factor(asm_handle* h, FacBuf& f, int64_t N) {
+void ns_alloc_factor(asm_handle* h, FacBuf& f, int64_t N, int band_hint = 0) {
     f.ld = round_up(std::max<int64_t>(N, 1), 32);
     f.wb = (f.ld <= 1024 || f.ld > 1536) ? 1024 : 512;      // one wide block (= the whole inverse) when the factor fits into it
+    // a narrow band: the explicit inverse of a wide diagonal block is dense whatever the band, its cost grows with the square of the block
+    // width - half the width is a quarter of the inverse (case300-sized S0, band 268 of 2 100: 16 % of a scenario batch's kernel time at 1024)
+    if (band_hint > 0 && band_hint <= 512 && f.ld > 1024) f.wb = 512;
     f.S = ns_dalloc(h, f.ld * f.ld);
     f.Linv = ns_dalloc(h, (f.ld / ASM_NB + 1) * ASM_NB * ASM_NB);
     f.Binv = ns_dalloc(h, (f.ld / f.wb + 1) * (int64_t)f.wb * f.wb);
@@ -417,7 +426,7 @@ struct Dev {
         std::memcpy(st, src, cnt * sizeof(double));
         for (int64_t i = cnt; i < padded; ++i) st[i] = 0.0;
         HIPCHK(hipMemcpyAsync(dst, st, padded * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));   // staging buffer is reused by the next call
+        h2d_done(h);   // staging buffer is reused by the next call
     }
     void d2h(double* dst, const double* src, int64_t cnt) {
         double* st = h->h_pin + h->pin_len;
@@ -742,7 +751,7 @@ struct Dev {
         if (diag) h2d(h->d_diag, diag, Ms, Ms);
         if (idx_host) {
             HIPCHK(hipMemcpyAsync(h->d_idx, idx_host, Ms * sizeof(int), hipMemcpyHostToDevice, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
+            h2d_done(h);
         }
         // sparse Jacobians: chunk flags of the gathered row set (second half of the flag buffer), as in the full Schur build
         const int nch = (int)(h->ldn / ASM_KC);
@@ -1091,7 +1100,7 @@ struct Solver {
         up(P.w, lp.w); up(P.slo, lp.slo);
         vec sc(h->scoef.begin(), h->scoef.begin() + lp.ns);
         up(P.scoef, sc);
-        HIPCHK(hipStreamSynchronize(h->stream));
+        h2d_done(h);
     }
     unsigned grid_all() const { return (unsigned)((std::max(std::max(lp.n, lp.M), std::max<int64_t>(lp.ns, 1)) + 255) / 256); }
     // Sequence number for the next publishing kernel (0 = the kernel does not publish: copy path)
@@ -1295,7 +1304,7 @@ struct Solver {
         const NsIdx X = nsX();
         const double* vals = dev.sparse_vals(h->d_Ah);
         HIPCHK(hipMemcpyAsync(h->d_nsJ, J.data(), k * sizeof(int), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        h2d_done(h);
         hipLaunchKernelGGL(k_ns_rhs_cols, dim3((unsigned)k), dim3(256), 0, h->stream, h->d_sc_ptr, h->d_sc_row, h->d_sc_pos, vals, X, (const int*)h->d_nsJ,
                            (const double*)h->d_nsFm, h->d_nsR, (int64_t)h->ns_nEp);
         dev.use_factor(h->ns_f0);
@@ -1326,7 +1335,7 @@ struct Solver {
             vec fm(h->ldn, 0.0);
             for (int64_t j = 0; j < n; ++j) fm[j] = lp.ub[j] > lp.lb[j] ? 1.0 : 0.0;
             HIPCHK(hipMemcpyAsync(h->d_nsFm, fm.data(), h->ldn * sizeof(double), hipMemcpyHostToDevice, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
+            h2d_done(h);
         }
         double t_v = now_ms();
         auto vlap = [&](const char* what) {
@@ -1805,10 +1814,10 @@ struct Solver {
                         std::vector<int> cp(lp.M, -1);
                         for (int a = 0; a < nE; ++a) cp[redE[a]] = a;
                         HIPCHK(hipMemcpyAsync(h->d_cpos, cp.data(), lp.M * sizeof(int), hipMemcpyHostToDevice, h->stream));
-                        HIPCHK(hipStreamSynchronize(h->stream));
+                        h2d_done(h);
                         dev.schur_banded_dev(h->d_cpos, nE, P.thp_inv, h->d_diag);
                     } else {
-                        HIPCHK(hipStreamSynchronize(h->stream));      // the host vectors go out of scope
+                        h2d_done(h);      // the host vectors go out of scope
                         dev.syrk_gathered_dev(h->d_idx, nE, P.thp_inv, h->d_diag);
                     }
                     dev.diag_prepare(nE, 0, 1e-13, 1e-30);
@@ -1937,7 +1946,7 @@ struct Solver {
         if (lp.M) HIPCHK(hipMemcpyAsync(S_[dst].rowst, buf.data(), lp.M * sizeof(int), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(S_[dst].bst, buf.data() + lp.M, lp.n * sizeof(int), hipMemcpyHostToDevice, h->stream));
         if (lp.ns) HIPCHK(hipMemcpyAsync(S_[dst].sst, buf.data() + lp.M + lp.n, lp.ns * sizeof(int), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        h2d_done(h);
     }
     void dcopy(double* dst, const double* src, int64_t cnt) {
         if (cnt > 0) HIPCHK(hipMemcpyAsync(dst, src, cnt * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -2731,8 +2740,9 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
             h->ns_eidx_h = eidx;
             h->d_nsEidx = ialloc(eidx, nE); h->d_nsEpos = ialloc(epos, h->M); h->d_nsIidx = ialloc(iidx, h->ns_nI); h->d_nsIpos = ialloc(ipos, h->M);
             h->d_nscnt = ialloc({}, 16);
-            ns_alloc_factor(h, h->ns_f0, h->ns_nEp);
-            h->ns_f0.band = (std::getenv("ASM_HIP_NO_BAND") || 2 * (int64_t)s0_band >= nE) ? 0 : std::max(s0_band, 1);
+            const int f0_band = (std::getenv("ASM_HIP_NO_BAND") || 2 * (int64_t)s0_band >= nE) ? 0 : std::max(s0_band, 1);
+            ns_alloc_factor(h, h->ns_f0, h->ns_nEp, f0_band);
+            h->ns_f0.band = f0_band;
             if (h->ns_f0.band > 0) {            // S0 is then built entry by entry from its structural pattern (k_ns_s0_sparse)
                 h->ns_npairs = (int64_t)s0_pairs.size() / 2;
                 h->d_nsS0pairs = ialloc(s0_pairs, (int64_t)s0_pairs.size());
@@ -2820,7 +2830,7 @@ void do_upload(asm_handle* h, const double* dE, const double* df, double f, cons
     if (!h->setup_done) throw std::logic_error("asm_sublp_setup has not been called");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemcpyAsync(h->d_dE, dE, h->nnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    h2d_done(h);
     h->J_valid = false;
     h->df.assign(df, df + h->n); h->E.assign(E, E + h->m); h->x_k.assign(x_k, x_k + h->n);
     h->f = f;
@@ -3432,7 +3442,12 @@ int asm_slp_norms(asm_handle* h, const double* lambda, const double* mult_x_U, c
         HIPCHK(hipMemsetAsync(h->d_vecM, 0, h->Mp * sizeof(double), h->stream));
         if (m) HIPCHK(hipMemcpyAsync(h->d_vecM, lam, m * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         d.launch_gemv_t(h->d_J, h->d_vecM, jtl);
-        if (m) hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, h->stream, h->d_J, h->ldn, rown, m, h->ldn);
+        if (m) {
+            if (const double* vJ = d.sparse_vals(h->d_J))      // sparse pattern: from the CSR copy (13 k entries instead of a 75 MB dense sweep at case300 size)
+                hipLaunchKernelGGL(k_sp_row_norms, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, h->stream, (const int*)h->d_sp_ptr, (const int*)h->d_sp_col, vJ, rown, m);
+            else
+                hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, h->stream, h->d_J, h->ldn, rown, m, h->ldn);
+        }
         hipLaunchKernelGGL(k_slp_norms, dim3(1), dim3(1024), 0, h->stream, ev_vecs(h, lam, mU, mL, jtl, rown), outd);
         HIPCHK(hipMemcpyAsync(st, outd, RN_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));

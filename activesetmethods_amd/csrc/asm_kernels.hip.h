@@ -1092,6 +1092,20 @@ __global__ __launch_bounds__(256) void k_row_norms(AsmBt abt, const double* __re
     if (lane == 0) out[i] = sqrt(acc);
 }
 
+// the same norms from the CSR copy of a sparse pattern, bit-identical to k_row_norms: lane l adds the entries of the columns = l (mod 64) in
+// column order (the zeros the dense sweep adds change nothing), then the same wavefront reduction
+__global__ __launch_bounds__(256) void k_sp_row_norms(AsmBt abt, const int* __restrict__ ptr, const int* __restrict__ col, const double* __restrict__ v, double* __restrict__ out, int64_t M) {
+    ASM_BARGS(abt, ptr, col, v, out, M);
+    int64_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= M) return;
+    int lane = threadIdx.x & 63;
+    double acc = 0.0;
+    for (int k = ptr[i]; k < ptr[i + 1]; ++k)
+        if ((col[k] & 63) == lane) acc = fma(v[k], v[k], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) out[i] = sqrt(acc);
+}
+
 // Scaling helpers (oracle/lp_solver.py: scale_lp): rmax[i] = max_j |J_ij| (1 if the row is empty), then
 // rel[j] = max_i |J_ij| / rmax[i] with the same deterministic two-stage column reduction as k_gemv_t.
 __global__ __launch_bounds__(256) void k_row_absmax(AsmBt abt, const double* __restrict__ A, int64_t ld, double* __restrict__ out, int64_t M, int64_t ncols) {

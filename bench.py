@@ -84,14 +84,117 @@ WORKLOADS = {
 
 
 def run_batch(args, rank, world, local_rank, dist, torch):
-    """Workload c5: scenarios are block-partitioned over ranks (activesetmethods_amd.batch), every rank solves its share
-    on its own GPU - `--concurrency` scenarios at a time, each worker thread with one persistent handle that moves from scenario to
-    scenario through asm_sublp_set_bounds (nothing is re-allocated) -, no data-path collective; one all-reduce merges the statistics."""
+    """Workload c5: scenarios are block-partitioned over ranks (activesetmethods_amd.batch), every rank solves its share on its own GPU
+    as ONE lockstep batch (include/asm_hip.h: asm_batch_*): `--slots` scenarios advance through one launch sequence on one stream, driven
+    by one host thread inside the library (native SLP driver per scenario, launches of different scenarios merged into one launch with the
+    scenario index in the grid); a slot takes the next scenario when it finishes one.  No data-path collective; one all-reduce merges
+    the statistics.  `--batch-mode pool` keeps the round-3 path (host threads, one handle / HIP stream each, Python SLP driver)."""
+    import numpy as np
     import activesetmethods_amd as A
     from activesetmethods_amd import acopf, batch
-    base = acopf.synthetic_case("case300", 1, 0.5)     # half the nominal synthetic load: Line-Search SLP converges in ~30 iterations
+    base = acopf.synthetic_case("case300", 1, 0.5)     # half the nominal synthetic load: Line-Search SLP converges in ~60 iterations
     per_gpu = args.steps
     total = per_gpu * world
+    lo, hi = batch.partition(total, world, rank)
+    par = A.Parameters(algorithm=args.algorithm, max_iter=args.max_iter, device_eval=True)
+    # the scenario NLPs of this rank as host objects (function lists, bounds, start points) before the timed region: inputs are in place
+    # when the clock starts, as for the other workloads; bounds uploads (per scenario) and every solve are inside it
+    problems = {s: acopf.function_model(acopf.scenario_case(base, s)).to_problem("case300-sized scenario %d" % s) for s in range(lo, hi)}
+    if args.batch_mode == "pool":
+        return run_batch_pool(args, rank, world, local_rank, dist, torch, base, problems, total, per_gpu)
+    n_slots = max(1, min(args.slots, hi - lo))
+    hb = batch.HipBatch(problems[lo], n_slots, device=local_rank)
+    if args.warmup:
+        # every slot allocates its null-space buffers in its first LP and the batch selects its reference basis columns: outside the clock
+        wpr = [acopf.function_model(acopf.scenario_case(base, 10 ** 6 + rank * 4096 + k)).to_problem("warm-up") for k in range(n_slots)]
+        hb.slp_run(np.stack([p.g_L for p in wpr]), np.stack([p.g_U for p in wpr]), np.stack([p.x_L for p in wpr]), np.stack([p.x_U for p in wpr]),
+                   np.stack([p.x0 for p in wpr]), par, max_lp_solves=2 * args.warmup)
+    st0 = hb.stats()
+    plist = [problems[s] for s in range(lo, hi)]
+    _freeze_heap()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    thr0 = _cpu_throttled_s()
+    t0 = time.perf_counter()
+    runs, stats, st1 = batch.solve_batch_lockstep(plist, par, n_slots, rank=rank, world=world, reduce_device=args.reduce_device, batch=hb)
+    torch.cuda.synchronize()
+    mine = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    thr = _cpu_throttled_s() - thr0
+    rank_s, rank_thr = [mine], [thr]
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=args.reduce_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        g = [torch.zeros(2, dtype=torch.float64, device=args.reduce_device) for _ in range(world)]
+        dist.all_gather(g, torch.tensor([mine, thr], dtype=torch.float64, device=args.reduce_device))
+        rank_s, rank_thr = [float(v[0]) for v in g], [float(v[1]) for v in g]
+    if rank == 0:
+        names = {0: "warm", 1: "ipm0+ln", 2: "ipm1+ln", 3: "ipm2+ln", 4: "ipm+face", 5: "ipm-unpolished", 6: "ipm-infeasible",
+                 7: "phase1-infeasible", 8: "ipm~+ln", 9: "ipm+ref", 10: "ipm-conv"}
+        hist = {}
+        for r in runs:
+            for k, c in enumerate(r.paths):
+                if c:
+                    hist[names.get(k, str(k))] = hist.get(names.get(k, str(k)), 0) + c
+        d = {k: st1[k] - st0[k] for k in st1}
+        out = {"metric": "batch-NLP solves/sec", "value": total / elapsed, "unit": "solves/s", "n_gpus": world, "steps": per_gpu,
+               "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / per_gpu, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": WORKLOADS["c5"]["desc"], "algorithm": args.algorithm, "max_iter": args.max_iter,
+                          "scenarios_total": total,
+                          "parallelism": "scenarios block-partitioned, %d per GPU; per GPU ONE lockstep batch of %d slots on one stream and one host thread "
+                                         "(asm_batch_slp_run: launches of different scenarios merged, scenario index in the grid)" % (per_gpu, n_slots),
+                          "inputs": "scenario NLPs built on the host before the timed region; bounds uploads and solves inside it"},
+               "batch_stats": stats,
+               "lockstep": {"slots": n_slots, "rounds": d["rounds"], "recorded_launches": d["ops"], "launches": d["launches"],
+                            "merge_ratio": d["ops"] / max(d["launches"], 1), "argument_table_MB": d["blob_bytes"] / 1e6,
+                            "emit_ms": d["emit_ms"], "device_wait_ms": d["wait_ms"], "solver_host_ms": d["host_ms"], "wall_ms": d["wall_ms"]},
+               "lp_outcomes": {"paths": hist, "lps": int(sum(r.lp_solves for r in runs)), "non_canonical_answers": int(sum(r.paths[9] + r.paths[10] for r in runs)),
+                               "unpolished": int(sum(r.paths[5] for r in runs)), "cold_basis_selections": int(sum(r.ns_cold for r in runs)),
+                               "ipm_iterations_per_lp": sum(r.ipm_iters for r in runs) / max(1, sum(r.lp_solves for r in runs))},
+               "host": {"cpu_quota": _host_cpu_quota(), "blas_threads": HOST_THREADS, "cgroup_throttled_s": round(thr, 3),
+                        "rank_seconds": [round(v, 3) for v in rank_s], "rank_throttled_s": [round(v, 3) for v in rank_thr]}}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = c5_cpu_baseline(base, lo, args, runs)
+        print(json.dumps(out))
+    hb.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def c5_cpu_baseline(base, sidx, args, runs):
+    """CPU comparator of the scenario batch on rank 0's host cores: SciPy's HiGHS dual simplex (sparse, cold start, 1 thread) on the sequence of
+    sub-LPs of ONE scenario (its iterates are recorded by a per-handle run of the same solver outside the timed region), for at most
+    --cpu-seconds; solves/s = LPs/s divided by the batch's mean LP count per scenario solve."""
+    try:
+        import activesetmethods_amd as A
+        from activesetmethods_amd import acopf
+        case = acopf.scenario_case(base, sidx)
+        prd = acopf.function_model(case).to_problem("case300-sized scenario %d" % sidx)
+        slp = A.optimize(A.Model.from_problem(prd, A.Parameters(algorithm=args.algorithm, max_iter=args.max_iter, device_eval=True)))
+        slp.optimizer.close()
+        hs = highs_sequence(acopf.acopf_problem(case, "case300-sized scenario"), slp.trace, args.cpu_seconds)
+        if "error" in hs:
+            return hs
+        lps_per_solve = sum(r.lp_solves for r in runs) / max(len(runs), 1)
+        return dict(value=hs["value"] / lps_per_solve, unit="solves/s", cores=1, kind="port",
+                    sample="HiGHS dual simplex (scipy.optimize.linprog, sparse, cold start, 1 thread) on the first %d sub-LPs of scenario %d's SLP run "
+                           "(%.1f s, %.2f LPs/s), divided by the batch's mean of %.1f LPs per scenario solve; LP solve time only - evaluation, "
+                           "assembly and the line search are not charged to the CPU" % (hs["lp_solved"], sidx, hs["seconds"], hs["value"], lps_per_solve),
+                    highs_sequence=hs)
+    except Exception as e:
+        return dict(error=repr(e))
+
+
+def run_batch_pool(args, rank, world, local_rank, dist, torch, base, problems, total, per_gpu):
+    """Round-3 path of workload c5 (--batch-mode pool): `--concurrency` host threads, each with one persistent handle = one HIP stream and
+    the Python SLP driver."""
+    import activesetmethods_amd as A
+    from activesetmethods_amd import batch
     import threading
     tls = threading.local()                 # one handle per worker thread of the stream pool, kept for the whole batch
 
@@ -99,33 +202,22 @@ def run_batch(args, rank, world, local_rank, dist, torch):
         opt = getattr(tls, "opt", None)
         if opt is None:
             opt = tls.opt = A.HipSubOptimizer(d, r, c, device=local_rank)
-            tls.fresh = True
         else:
             opt.set_bounds(d)               # keeps J, Ah, S, the assembly plan and the evaluator's function store in HBM
-            tls.fresh = False
         return opt
 
     def make_model(sidx):
-        pr = acopf.function_model(acopf.scenario_case(base, sidx)).to_problem("case300-sized scenario %d" % sidx)
-        return A.Model.from_problem(pr, A.Parameters(algorithm=args.algorithm, max_iter=args.max_iter, external_optimizer=factory,
-                                                     device_eval=not args.host_eval))
+        return A.Model.from_problem(problems[sidx], A.Parameters(algorithm=args.algorithm, max_iter=args.max_iter, external_optimizer=factory,
+                                                                 device_eval=not args.host_eval))
 
-    def run(model, max_lp_solves=None):
-        return A.optimize(model, max_lp_solves)     # the handle stays with the worker thread (closed when the pool ends)
-
-    if args.warmup:
-        run(make_model(10 ** 6 + rank), 2)
-    # the scenario NLPs of this rank as host objects (function lists, bounds, start points) before the timed region: inputs are in place when
-    # the clock starts, as for the other workloads; their upload to HBM (one handle set-up per scenario) and every solve are inside it
-    lo, hi = batch.partition(total, world, rank)
-    models = {s: make_model(s) for s in range(lo, hi)}
+    models = {s: make_model(s) for s in problems}
     _freeze_heap()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     thr0 = _cpu_throttled_s()
     t0 = time.perf_counter()
-    slps, stats = batch.solve_batch(models.__getitem__, total, rank, world, run=run, reduce_device=args.reduce_device,
+    slps, stats = batch.solve_batch(models.__getitem__, total, rank, world, run=lambda m: A.optimize(m), reduce_device=args.reduce_device,
                                     concurrency=args.concurrency)
     torch.cuda.synchronize()
     if dist is not None:
@@ -141,8 +233,7 @@ def run_batch(args, rank, world, local_rank, dist, torch):
                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": WORKLOADS["c5"]["desc"], "algorithm": args.algorithm, "max_iter": args.max_iter,
                           "scenarios_total": total,
-                          "parallelism": "scenarios block-partitioned, %d per GPU, %d at a time per GPU (stream pool)" % (per_gpu, args.concurrency),
-                          "inputs": "scenario NLPs built on the host before the timed region; handle set-up, uploads and solves inside it"},
+                          "parallelism": "scenarios block-partitioned, %d per GPU, %d at a time per GPU (stream pool, round-3 path)" % (per_gpu, args.concurrency)},
                "batch_stats": stats,
                "host": {"cpu_quota": _host_cpu_quota(), "blas_threads": HOST_THREADS, "cgroup_throttled_s": round(_cpu_throttled_s() - thr0, 3)}}
         print(json.dumps(out))
@@ -384,7 +475,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--scenarios-per-gpu", type=int, default=None, help="workload c5: scenarios per GPU (alias of --steps)")
     ap.add_argument("--max-iter", type=int, default=100, help="workload c5: SLP iteration cap per scenario")
-    ap.add_argument("--concurrency", type=int, default=2, help="workload c5: scenarios in flight per GPU (one handle / HIP stream each)")
+    ap.add_argument("--slots", type=int, default=64, help="workload c5: scenarios advancing in lockstep per GPU (slots of the asm_batch)")
+    ap.add_argument("--batch-mode", default="lockstep", choices=["lockstep", "pool"], help="workload c5: lockstep batch (default) or the round-3 stream pool")
+    ap.add_argument("--concurrency", type=int, default=2, help="workload c5, --batch-mode pool: scenarios in flight per GPU (one handle / HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-eval", action="store_true", help="evaluate f, grad f, g, Jacobian values with the NumPy callbacks instead of the device kernels")
     ap.add_argument("--kernel-breakdown", action="store_true",
