@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libasmhip.so")
 
 OPTIMAL, INFEASIBLE, DUAL_INFEASIBLE, OTHER = 1, 2, 3, 4
-K_NAMES = ("assemble", "scale", "gemv", "syrk", "chol", "trsv", "syrk_kernel")
+K_NAMES = ("assemble", "scale", "gemv", "syrk", "chol", "trsv", "syrk_kernel", "panel_kernel")
 
 
 class SolveStats(C.Structure):
@@ -19,7 +19,7 @@ class SolveStats(C.Structure):
 
 
 class KernelStats(C.Structure):
-    _fields_ = [("ms", C.c_double * 7), ("calls", C.c_int64 * 7), ("flops", C.c_double * 7), ("bytes", C.c_double * 7)]
+    _fields_ = [("ms", C.c_double * 8), ("calls", C.c_int64 * 8), ("flops", C.c_double * 8), ("bytes", C.c_double * 8)]
 
 
 class SlpParams(C.Structure):
@@ -61,6 +61,7 @@ PROTOTYPES = {
     "asm_sublp_last_stats": (C.c_int, [_P, C.POINTER(SolveStats)]),
     "asm_kernel_stats_get": (C.c_int, [_P, C.POINTER(KernelStats)]),
     "asm_kernel_stats_reset": (C.c_int, [_P]),
+    "asm_kernel_timing": (C.c_int, [_P, C.c_int]),
     "asm_kt_residuals": (C.c_int, [_P, _D, _D, _D, _D, _D]),
     "asm_jac_row_norms": (C.c_int, [_P, _D]),
     "asm_eval_setup": (C.c_int, [_P, C.c_int64, _I64, _I64, _D, _I64, _I64, _I64, _D, _D, _I64, _I64, _I64, _D, _I64, C.c_double, C.c_int,
@@ -78,6 +79,8 @@ PROTOTYPES = {
     "asm_batch_destroy": (C.c_int, [_P]),
     "asm_batch_last_error": (C.c_char_p, [_P]),
     "asm_batch_slots": (C.c_int, [_P]),
+    "asm_batch_set_groups": (C.c_int, [_P, C.c_int]),
+    "asm_batch_groups": (C.c_int, [_P]),
     "asm_batch_handle": (_P, [_P, C.c_int]),
     "asm_batch_setup": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, _I64, _I64, _D, _D, _D, _D]),
     "asm_batch_eval_setup": (C.c_int, [_P, C.c_int64, _I64, _I64, _D, _I64, _I64, _I64, _D, _D, _I64, _I64, _I64, _D, _I64, C.c_double, C.c_int,

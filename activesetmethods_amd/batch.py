@@ -104,7 +104,7 @@ class HipBatch:
     `problem`: a Problem built from a FunctionModel (its pattern, functions and NLP block are shared by every scenario; scenarios differ in
     bounds and start points)."""
 
-    def __init__(self, problem, n_slots, device=0):
+    def __init__(self, problem, n_slots, device=0, groups=None):
         import ctypes as C
         from . import _lib
         from .subproblem import AsmHipError
@@ -117,6 +117,9 @@ class HipBatch:
         rc = self._lib.asm_batch_create(int(device), int(n_slots), C.byref(self._b))
         if rc != 0:
             raise AsmHipError("asm_batch_create(device=%d, n_slots=%d) failed with code %d" % (device, n_slots, rc))
+        if groups is not None:
+            self._check(self._lib.asm_batch_set_groups(self._b, int(groups)))
+        self.groups = int(self._lib.asm_batch_groups(self._b))
         f64 = lambda a: np.ascontiguousarray(a, np.float64)
         jr, jc = np.ascontiguousarray(problem.j_row, np.int64), np.ascontiguousarray(problem.j_col, np.int64)
         gl, gu, xl, xu = map(f64, (problem.g_L, problem.g_U, problem.x_L, problem.x_U))

@@ -16,6 +16,8 @@
 
 #include <sched.h>
 #include <time.h>
+#include <atomic>
+#include <thread>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -317,7 +319,7 @@ struct asm_handle {
     bool fused_panel = true;        // Cholesky inner panels as one dataflow launch (k_chol_panel) instead of three launches per 64-wide step
     int panel_wgs = 240;            // its grid bound: every workgroup must be able to become resident
     int num_cus = 256;              // compute units of the device (hipDeviceProp_t::multiProcessorCount)
-    unsigned *d_pflags = nullptr, *d_ptmo = nullptr;
+    unsigned *d_pflags = nullptr, *d_ptmo = nullptr, *d_gbar = nullptr;      // panel flags, timeout word, grid barrier of k_trtri_fused
     unsigned panel_epoch = 0;
     int timing = 1;                 // HIP-event timing: 0 off, 1 the dominant kernel only (every k_syrk launch), 2 every kernel family
     bool verbose = false;
@@ -393,7 +395,7 @@ struct Dev {
         h->kstats.flops[kind] += flops;
         h->kstats.bytes[kind] += bytes;
         h->kstats.calls[kind] += 1;
-        if (h->timing < 2 && !(h->timing == 1 && kind == ASM_K_SYRK_KERNEL)) return -1;
+        if (h->timing < 2 && !(h->timing == 1 && (kind == ASM_K_SYRK_KERNEL || kind == ASM_K_PANEL_KERNEL))) return -1;
         TimedRegion r;
         r.a = get_event();
         r.b = get_event();
@@ -786,7 +788,9 @@ struct Dev {
     // explicit inverses of the wide blocks are not built
     void chol(int Ms, double thr = 1e-14, bool want_inverse = true) {
         if (Ms <= 0) return;
-        int id = begin(ASM_K_CHOL, (double)Ms * Ms * Ms / 3.0, 8.0 * 1.5 * Ms * (double)Ms);
+        // a banded factor (band b) costs about Ms (b + 64)^2 flops and touches Ms (b + 64) entries, not Ms^3 / 3 and Ms^2 / 2
+        const double bw = fband > 0 ? (double)std::min<int64_t>(Ms, (int64_t)fband + 64) : (double)Ms;
+        int id = begin(ASM_K_CHOL, fband > 0 ? (double)Ms * bw * bw : (double)Ms * Ms * Ms / 3.0, 8.0 * 1.5 * Ms * bw);
         chol_launches(Ms, thr);
         if (!want_inverse && fsmall && Ms <= ASM_SMALL_USE) {
             end(id);
@@ -796,7 +800,15 @@ struct Dev {
         // explicit inverses of the wide diagonal blocks by divide and conquer over the 64-wide sub-blocks: diagonal
         // blocks from k_potrf_diag, then log2 levels of two launches each (the scratch T uses the buffer of the
         // transposed copy, which is written afterwards)
-        if (fwb == 1024) trtri_launches<1024>(Ms); else trtri_launches<512>(Ms);
+        static const bool fuse_trtri = [] { const char* v = std::getenv("ASM_TRTRI_FUSED"); return !(v && v[0] == '0'); }();
+        if (Ms <= fwb && fuse_trtri && !asmb::in_fiber()) {
+            // one wide block: the whole inverse in one launch (grid barriers instead of launch boundaries; a scenario batch keeps the separate
+            // launches - merged across scenarios they are not latency-bound, and the fused kernel's workgroups must all be resident)
+            if (fwb == 1024)
+                asmb::launch_resident((k_trtri_fused<1024>), dim3(ASM_TRTRI_WGS), dim3(256), 0, h->stream, (const double*)fS, fld, Ms, (const double*)fLinv, fBinv, fBinvT, h->d_gbar, h->d_ptmo);
+            else
+                asmb::launch_resident((k_trtri_fused<512>), dim3(ASM_TRTRI_WGS / 2), dim3(256), 0, h->stream, (const double*)fS, fld, Ms, (const double*)fLinv, fBinv, fBinvT, h->d_gbar, h->d_ptmo);
+        } else if (fwb == 1024) trtri_launches<1024>(Ms); else trtri_launches<512>(Ms);
         end(id);
         h->stats.nfact += 1;
     }
@@ -818,6 +830,15 @@ struct Dev {
                 const int G = std::max(1, std::min(nrt, h->panel_wgs));
                 h->panel_epoch += 1;              // flags are "set" when they hold this launch's epoch: no reset between launches
                 if (h->panel_epoch == 0) h->panel_epoch = 1;
+                // algorithmic flops of the launch: per 64-wide step the factor + inverse of the diagonal block, the panel solve of the rows below
+                // and the rank-64 update of the panel's remaining columns
+                double pfl = 0.0;
+                for (int k0 = I0; k0 < std::min(I1, Ms); k0 += ASM_NB) {
+                    const double r = std::max(0, Mi - (k0 + ASM_NB)), w = std::max(0, std::min(I1, Mi) - (k0 + ASM_NB));
+                    pfl += 2.0 / 3.0 * ASM_NB * ASM_NB * ASM_NB + 2.0 * r * ASM_NB * ASM_NB + 2.0 * ASM_NB * (r * w - 0.5 * w * w);
+                }
+                int pid = begin(ASM_K_PANEL_KERNEL, pfl, 8.0 * 2.0 * (double)(Mi - I0) * (double)(std::min(I1, Mi) - I0), cur);
+                struct PEnd { Dev* d; int id; ~PEnd() { d->end(id); } } pend_{this, pid};
                 // beside the trailing update the register-capped build must be used (its wavefronts have to fit into freed update slots)
                 if (beside_updates)
                     asmb::launch_resident(k_chol_panel, dim3((unsigned)G), dim3(256), 0, cur, fS, fld, I0, std::min(I1, Ms), Mi, (const double*)h->d_diag0, thr,
@@ -2476,8 +2497,8 @@ void free_device(asm_handle* h) {
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     if (h->h_seq) (void)hipHostFree(h->h_seq);
     h->d_ipm = nullptr; h->d_ipm_i = nullptr; h->h_scal = nullptr; h->h_seq = nullptr; h->d_hscal = nullptr; h->d_hseq = nullptr;
-    F(h->d_pflags); F(h->d_ptmo);
-    h->d_pflags = h->d_ptmo = nullptr;
+    F(h->d_pflags); F(h->d_ptmo); F(h->d_gbar);
+    h->d_pflags = h->d_ptmo = h->d_gbar = nullptr;
     for (void* q : h->ns_bufs) F(q);
     h->ns_bufs.clear();
     h->ns_cap = false; h->ns_kcap = 0; h->ns_ccap = 0; h->ns_Zk = 0; h->ns_fC = FacBuf(); h->d_nsqi = nullptr; h->d_nsq = nullptr;
@@ -2513,7 +2534,8 @@ void check_panel_timeout(asm_handle* h) {
     HIPCHK(hipMemcpy(&tmo, h->d_ptmo, sizeof(unsigned), hipMemcpyDeviceToHost));
     if (tmo != 0) {
         HIPCHK(hipMemset(h->d_ptmo, 0, sizeof(unsigned)));      // reported once: the handle stays usable
-        throw HipError("k_chol_panel: a workgroup timed out waiting for a producer (grid not resident?)");
+        HIPCHK(hipMemset(h->d_gbar, 0, 4 * sizeof(unsigned)));
+        throw HipError("k_chol_panel / k_trtri_fused: a workgroup timed out waiting for a producer (grid not resident?)");
     }
 }
 
@@ -2628,6 +2650,8 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     dmalloc(&h->d_Linv, (h->Mp / ASM_NB + 1) * ASM_NB * ASM_NB);
     dmalloc(&h->d_pflags, ASM_PNL_NS * (ASM_PNL_NS + 1));
     dmalloc(&h->d_ptmo, 4);
+    dmalloc(&h->d_gbar, 4);
+    HIPCHK(hipMemsetAsync(h->d_gbar, 0, 4 * sizeof(unsigned), h->stream));
     HIPCHK(hipMemsetAsync(h->d_ptmo, 0, 4 * sizeof(unsigned), h->stream));
     HIPCHK(hipMemsetAsync(h->d_pflags, 0, ASM_PNL_NS * (ASM_PNL_NS + 1) * sizeof(unsigned), h->stream));
     h->wb = h->M > 1536 ? 1024 : 512;      // wide-block width of the triangular solves (k_wtrsv_*<WB>)
@@ -3276,6 +3300,15 @@ int asm_kernel_stats_get(asm_handle* h, asm_kernel_stats* out) {
     });
 }
 
+int asm_kernel_timing(asm_handle* h, int level) {
+    return guarded(h, [&] {
+        if (level < 0 || level > 2) throw std::invalid_argument("asm_kernel_timing: level 0, 1 or 2");
+        Dev d(h);
+        d.resolve_timing();
+        h->timing = h->batch_slot ? 0 : level;
+    });
+}
+
 int asm_kernel_stats_reset(asm_handle* h) {
     return guarded(h, [&] {
         Dev d(h);
@@ -3862,11 +3895,19 @@ void slp_run_ls(asm_handle* h, const asm_slp_params* par, const double* x0, doub
 
 }  // namespace
 
+// A batch is split into groups: each group = a contiguous range of slots, one stream, one scheduler, one host thread (group 0 runs on the
+// calling thread).  While one group's round executes on the device the other groups' host threads merge and launch theirs: two groups
+// hide the host side of the rounds (64 case300-sized scenarios on one GPU: 23 -> 32 solves/s).
+struct BatchGroup {
+    hipStream_t stream = nullptr;
+    asmb::Sched sched;
+    int lo = 0, hi = 0;             // slots [lo, hi)
+    std::exception_ptr err;
+};
 struct asm_batch {
     int device = 0;
-    hipStream_t stream = nullptr;
     std::vector<asm_handle*> slots;
-    asmb::Sched sched;
+    std::vector<BatchGroup*> groups;
     std::string err;
     std::vector<int> J_ref;         // basis columns of the null-space form every scenario starts from (first cold selection of the batch)
     bool setup_done = false;
@@ -3889,18 +3930,64 @@ int bguarded(asm_batch* b, F&& fn) {
 void bcheck(asm_batch* b, int slot, int rc, const char* what) {
     if (rc != ASM_OK) throw HipError(std::string(what) + " (slot " + std::to_string(slot) + "): " + b->slots[slot]->err);
 }
-// run `work(slot)` for every slot in [0, count) as fibers of this thread, launches merged across slots
+// run `work(slot)` for every slot in [0, count): the slots of a group are fibers of the group's thread, launches merged across them
 template <class W>
 void run_fibers(asm_batch* b, int count, W&& work) {
-    asmb::Sched& S = b->sched;
-    for (asmb::Fiber* f : S.fibers) { if (f->stack) munmap(f->stack, f->stack_size); delete f; }
-    S.fibers.clear();
-    for (int s = 0; s < count; ++s) S.add_fiber([&work, s] { work(s); });
     const double t0 = asmb::Sched::now_ms();
-    S.run();
+    auto run_group = [&](BatchGroup* g) {
+        try {
+            HIPCHK(hipSetDevice(b->device));
+            asmb::Sched& S = g->sched;
+            for (asmb::Fiber* f : S.fibers) { if (f->stack) munmap(f->stack, f->stack_size); delete f; }
+            S.fibers.clear();
+            for (int s = g->lo; s < std::min(g->hi, count); ++s) S.add_fiber([&work, s] { work(s); });
+            if (!S.fibers.empty()) S.run();
+        } catch (...) {
+            g->err = std::current_exception();
+        }
+    };
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < b->groups.size(); ++k)
+        if (b->groups[k]->lo < count) th.emplace_back(run_group, b->groups[k]);
+    run_group(b->groups[0]);
+    for (auto& t : th) t.join();
     b->stats.wall_ms += asmb::Sched::now_ms() - t0;
-    b->stats.rounds = (int64_t)S.n_rounds; b->stats.ops = (int64_t)S.n_ops; b->stats.launches = (int64_t)S.n_launches; b->stats.releases = (int64_t)S.n_releases;
-    b->stats.blob_bytes = (int64_t)S.blob_bytes; b->stats.emit_ms = S.t_emit_ms; b->stats.wait_ms = S.t_wait_ms; b->stats.host_ms = S.t_host_ms;
+    asm_batch_stats& st = b->stats;
+    st.rounds = st.ops = st.launches = st.releases = st.blob_bytes = 0;
+    st.emit_ms = st.wait_ms = st.host_ms = 0.0;
+    for (BatchGroup* g : b->groups) {
+        const asmb::Sched& S = g->sched;
+        st.rounds += (int64_t)S.n_rounds; st.ops += (int64_t)S.n_ops; st.launches += (int64_t)S.n_launches; st.releases += (int64_t)S.n_releases;
+        st.blob_bytes += (int64_t)S.blob_bytes; st.emit_ms += S.t_emit_ms; st.wait_ms += S.t_wait_ms; st.host_ms += S.t_host_ms;
+    }
+    for (BatchGroup* g : b->groups)
+        if (g->err) { std::exception_ptr e = g->err; g->err = nullptr; std::rethrow_exception(e); }
+}
+void batch_free_groups(asm_batch* b) {
+    for (BatchGroup* g : b->groups) {
+        g->sched.release();
+        if (g->stream) (void)hipStreamDestroy(g->stream);
+        delete g;
+    }
+    b->groups.clear();
+}
+// `n_groups` groups of (almost) equal size over the slots; the slots' launches go to their group's stream
+void batch_make_groups(asm_batch* b, int n_groups) {
+    HIPCHK(hipSetDevice(b->device));
+    for (BatchGroup* g : b->groups) HIPCHK(hipStreamSynchronize(g->stream));
+    batch_free_groups(b);
+    const int n = (int)b->slots.size();
+    n_groups = std::max(1, std::min(n_groups, n));
+    for (int k = 0; k < n_groups; ++k) {
+        BatchGroup* g = new BatchGroup();
+        b->groups.push_back(g);
+        HIPCHK(hipStreamCreate(&g->stream));
+        g->lo = (int)((int64_t)n * k / n_groups);
+        g->hi = (int)((int64_t)n * (k + 1) / n_groups);
+        g->sched.init(b->device, g->stream, b->slots[0]->panel_wgs);
+        if (const char* nb = std::getenv("ASM_BATCH_NO_BARRIERS")) g->sched.use_barriers = !(nb[0] == '1');
+        for (int s = g->lo; s < g->hi; ++s) { b->slots[s]->stream = g->stream; b->slots[s]->stream2 = g->stream; }
+    }
 }
 }  // namespace
 
@@ -3922,28 +4009,29 @@ int asm_batch_create(int device, int n_slots, asm_batch** out) {
     b->device = device;
     std::memset(&b->stats, 0, sizeof(b->stats));
     int rc = ASM_OK;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&b->stream) != hipSuccess) { delete b; return ASM_ERR_HIP; }
+    if (hipSetDevice(device) != hipSuccess) { delete b; return ASM_ERR_HIP; }
     for (int s = 0; s < n_slots && rc == ASM_OK; ++s) {
         asm_handle* h = nullptr;
         rc = asm_create(device, &h);
         if (rc != ASM_OK) break;
-        // the slot's launches are recorded and merged onto the batch's stream: no streams of its own, no look-ahead stream, no event timing
+        // the slot's launches are recorded and merged onto its group's stream: no streams of its own, no look-ahead stream, no event timing
         (void)hipStreamDestroy(h->stream2);
         (void)hipStreamDestroy(h->stream);
-        h->stream = b->stream; h->stream2 = b->stream;
+        h->stream = nullptr; h->stream2 = nullptr;
         h->batch_slot = true;
         h->timing = 0;
         b->slots.push_back(h);
     }
     if (rc == ASM_OK) {
         try {
-            b->sched.init(device, b->stream, b->slots[0]->panel_wgs);
-            if (const char* nb = std::getenv("ASM_BATCH_NO_BARRIERS")) b->sched.use_barriers = !(nb[0] == '1');
+            int ng = n_slots >= 16 ? 2 : 1;
+            if (const char* e = std::getenv("ASM_BATCH_GROUPS")) ng = std::max(1, std::atoi(e));
+            batch_make_groups(b, ng);
         } catch (const std::exception&) { rc = ASM_ERR_HIP; }
     }
     if (rc != ASM_OK) {
+        batch_free_groups(b);
         for (asm_handle* h : b->slots) (void)asm_destroy(h);
-        (void)hipStreamDestroy(b->stream);
         delete b;
         return rc;
     }
@@ -3954,13 +4042,20 @@ int asm_batch_create(int device, int n_slots, asm_batch** out) {
 int asm_batch_destroy(asm_batch* b) {
     if (!b) return ASM_ERR_ARG;
     (void)hipSetDevice(b->device);
-    (void)hipStreamSynchronize(b->stream);
+    for (BatchGroup* g : b->groups) (void)hipStreamSynchronize(g->stream);
     for (asm_handle* h : b->slots) (void)asm_destroy(h);
-    b->sched.release();
-    (void)hipStreamDestroy(b->stream);
+    batch_free_groups(b);
     delete b;
     return ASM_OK;
 }
+
+int asm_batch_set_groups(asm_batch* b, int n_groups) {
+    return bguarded(b, [&] {
+        if (n_groups < 1) throw std::invalid_argument("asm_batch_set_groups: at least one group");
+        batch_make_groups(b, n_groups);
+    });
+}
+int asm_batch_groups(const asm_batch* b) { return b ? (int)b->groups.size() : 0; }
 
 const char* asm_batch_last_error(const asm_batch* b) { return b ? b->err.c_str() : "null batch"; }
 int asm_batch_slots(const asm_batch* b) { return b ? (int)b->slots.size() : 0; }
@@ -4045,13 +4140,12 @@ int asm_batch_slp_run(asm_batch* b, int64_t n_scen, const double* c_lb, const do
             b->J_ref = h0->hint[0].ns_J;
         }
         const int count = (int)std::min<int64_t>(n_scen, (int64_t)b->slots.size());
-        int64_t next = 0;
+        std::atomic<int64_t> next{0};
         run_fibers(b, count, [&](int s) {
             asm_handle* h = b->slots[s];
             for (;;) {
-                const int64_t sc = next;
+                const int64_t sc = next.fetch_add(1);
                 if (sc >= n_scen) break;
-                next = sc + 1;
                 bcheck(b, s, asm_sublp_set_bounds(h, c_lb + sc * m, c_ub + sc * m, v_lb + sc * n, v_ub + sc * n), "asm_sublp_set_bounds");
                 // every scenario starts from the batch's reference basis columns (results do not depend on which slot solved what before)
                 if (!b->J_ref.empty()) h->hint[0].ns_J = b->J_ref;

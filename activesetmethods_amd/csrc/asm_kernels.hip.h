@@ -1237,9 +1237,7 @@ __global__ __launch_bounds__(256) void k_tile_nzflags(AsmBt abt, const double* _
 // (pitch = 2 mod 32 doubles).
 #define ASM_TP 66
 template <int WB>
-__global__ __launch_bounds__(256) void k_trtri_init(AsmBt abt, const double* __restrict__ Linv, int Ms, double* __restrict__ Binv) {
-    ASM_BARGS(abt, Linv, Ms, Binv);
-    const int B = blockIdx.x, i = blockIdx.y / (WB / ASM_NB), j = blockIdx.y % (WB / ASM_NB);
+__device__ __forceinline__ void trtri_init_tile(const double* __restrict__ Linv, int Ms, double* __restrict__ Binv, int B, int i, int j) {
     const int b0 = B * WB;
     const int nsub = min((WB / ASM_NB), (Ms - b0 + ASM_NB - 1) / ASM_NB);
     double* X = Binv + (int64_t)B * WB * WB;
@@ -1252,11 +1250,13 @@ __global__ __launch_bounds__(256) void k_trtri_init(AsmBt abt, const double* __r
     }
 }
 template <int WB>
-__global__ __launch_bounds__(256) void k_trtri_level(AsmBt abt, const double* __restrict__ L, int64_t ld, int Ms, double* __restrict__ Binv, double* __restrict__ Tbuf, int h, int stage) {
-    ASM_BARGS(abt, L, ld, Ms, Binv, Tbuf, h, stage);
-    __shared__ double Pa[ASM_NB * ASM_TP];      // left operand  P[r][k]
-    __shared__ double Qt[ASM_NB * ASM_TP];      // right operand transposed  Qt[c][k] = Q[k][c]
-    const int B = blockIdx.x, pr = blockIdx.y, ti = asm_bz(abt) / h, tj = asm_bz(abt) % h;
+__global__ __launch_bounds__(256) void k_trtri_init(AsmBt abt, const double* __restrict__ Linv, int Ms, double* __restrict__ Binv) {
+    ASM_BARGS(abt, Linv, Ms, Binv);
+    trtri_init_tile<WB>(Linv, Ms, Binv, blockIdx.x, blockIdx.y / (WB / ASM_NB), blockIdx.y % (WB / ASM_NB));
+}
+template <int WB>
+__device__ __forceinline__ void trtri_level_tile(double* __restrict__ Pa, double* __restrict__ Qt, const double* __restrict__ L, int64_t ld, int Ms, double* __restrict__ Binv,
+                                                 double* __restrict__ Tbuf, int h, int stage, int B, int pr, int ti, int tj) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int b0 = B * WB;
     const int c0 = pr * 2 * h * ASM_NB, r0 = c0 + h * ASM_NB;          // inside the wide block: cols of "1", rows of "2"
@@ -1316,6 +1316,13 @@ __global__ __launch_bounds__(256) void k_trtri_level(AsmBt abt, const double* __
             int row = w * 16 + (lane >> 4) + 4 * r, col = t * 16 + (lane & 15);
             out[(int64_t)(r0 + ti * ASM_NB + row) * WB + c0 + tj * ASM_NB + col] = sgn * acc[t][r];
         }
+}
+template <int WB>
+__global__ __launch_bounds__(256) void k_trtri_level(AsmBt abt, const double* __restrict__ L, int64_t ld, int Ms, double* __restrict__ Binv, double* __restrict__ Tbuf, int h, int stage) {
+    ASM_BARGS(abt, L, ld, Ms, Binv, Tbuf, h, stage);
+    __shared__ double Pa[ASM_NB * ASM_TP];      // left operand  P[r][k]
+    __shared__ double Qt[ASM_NB * ASM_TP];      // right operand transposed  Qt[c][k] = Q[k][c]
+    trtri_level_tile<WB>(Pa, Qt, L, ld, Ms, Binv, Tbuf, h, stage, blockIdx.x, blockIdx.y, asm_bz(abt) / h, asm_bz(abt) % h);
 }
 
 // forward, wide block B:  z_B = X_B w_B   (one wavefront per row: 128 workgroups of 4 rows; all loads of a row in flight)
@@ -1466,10 +1473,7 @@ __global__ __launch_bounds__(256) void k_wtrsv_bwd_diag(AsmBt abt, const double*
 }
 // XT_B = X_B'  (LDS-tiled transpose of every 512 x 512 block inverse)
 template <int WB>
-__global__ __launch_bounds__(256) void k_transpose_wb(AsmBt abt, const double* __restrict__ Binv, double* __restrict__ BinvT) {
-    ASM_BARGS(abt, Binv, BinvT);
-    __shared__ double tile[64 * 65];
-    const int B = blockIdx.x, ti = blockIdx.y / (WB / ASM_NB), tj = blockIdx.y % (WB / ASM_NB);
+__device__ __forceinline__ void transpose_wb_tile(double* __restrict__ tile, const double* __restrict__ Binv, double* __restrict__ BinvT, int B, int ti, int tj) {
     const double* X = Binv + (int64_t)B * WB * WB;
     double* XT = BinvT + (int64_t)B * WB * WB;
     _Pragma("unroll") for (int e_it = 0; e_it < 16; ++e_it) {
@@ -1482,6 +1486,65 @@ __global__ __launch_bounds__(256) void k_transpose_wb(AsmBt abt, const double* _
         const int e = threadIdx.x + 256 * e_it;
         int r = e >> 6, c = e & 63;
         XT[(int64_t)(tj * 64 + r) * WB + ti * 64 + c] = tile[c * 65 + r];
+    }
+}
+template <int WB>
+__global__ __launch_bounds__(256) void k_transpose_wb(AsmBt abt, const double* __restrict__ Binv, double* __restrict__ BinvT) {
+    ASM_BARGS(abt, Binv, BinvT);
+    __shared__ double tile[64 * 65];
+    transpose_wb_tile<WB>(tile, Binv, BinvT, blockIdx.x, blockIdx.y / (WB / ASM_NB), blockIdx.y % (WB / ASM_NB));
+}
+
+// The whole explicit inverse of ONE wide block (a factor of order <= WB: the k x k systems of the null-space form, dense 500 x 500 LPs) in
+// one launch instead of 2 + 2 log2(WB / 64) dependent ones: the same tile products in the same order (bit-identical), the launches'
+// boundaries replaced by grid-wide barriers.  ASM_TRTRI_WGS workgroups (all resident: far fewer than compute units); a level has at most
+// WB / 128 * (WB / 128) / ... tiles = 64 at WB = 1024, so more workgroups would idle.  bar[0] = arrivals, bar[1] = generation (zeroed once
+// at allocation, the barrier leaves bar[0] = 0); bounded spin: a lost workgroup must not hang the GPU (tmo as for the panel kernel).
+#define ASM_TRTRI_WGS 64
+__device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned G, unsigned* tmo) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned gen = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned prev = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == G - 1) {
+            __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            unsigned spins = 0;
+            while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 24)) { __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+template <int WB>
+__global__ __launch_bounds__(256) void k_trtri_fused(AsmBt abt, const double* __restrict__ L, int64_t ld, int Ms, const double* __restrict__ Linv, double* __restrict__ Binv,
+                                                     double* __restrict__ BinvT, unsigned* __restrict__ bar, unsigned* __restrict__ tmo) {
+    ASM_BARGS(abt, L, ld, Ms, Linv, Binv, BinvT, bar, tmo);
+    __shared__ double Pa[ASM_NB * ASM_TP];
+    __shared__ double Qt[ASM_NB * ASM_TP];
+    constexpr int WSUB = WB / ASM_NB;
+    const int G = gridDim.x, wg = blockIdx.x;
+    for (int it = wg; it < WSUB * WSUB; it += G) trtri_init_tile<WB>(Linv, Ms, Binv, 0, it / WSUB, it % WSUB);
+    grid_barrier(bar, (unsigned)G, tmo);
+    for (int hh = 1; hh < WSUB; hh *= 2)
+        for (int stage = 0; stage < 2; ++stage) {
+            const int npr = WSUB / (2 * hh), nit = npr * hh * hh;
+            for (int it = wg; it < nit; it += G) {
+                const int pr = it / (hh * hh), z = it % (hh * hh);
+                __syncthreads();                  // the LDS operands of the previous tile have been consumed
+                trtri_level_tile<WB>(Pa, Qt, L, ld, Ms, Binv, BinvT, hh, stage, 0, pr, z / hh, z % hh);
+            }
+            grid_barrier(bar, (unsigned)G, tmo);
+        }
+    for (int it = wg; it < WSUB * WSUB; it += G) {
+        __syncthreads();
+        transpose_wb_tile<WB>(Pa, Binv, BinvT, 0, it / WSUB, it % WSUB);
     }
 }
 

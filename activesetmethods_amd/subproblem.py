@@ -195,6 +195,10 @@ class HipSubOptimizer:
             self._check(self._lib.asm_kernel_stats_reset(self._h))
         return out
 
+    def kernel_timing(self, level):
+        """0 off, 1 every launch of the rank-K and panel kernels, 2 every kernel family (asm_kernel_timing)."""
+        self._check(self._lib.asm_kernel_timing(self._h, int(level)))
+
     # ------------------------------------------------------------------ device-side evaluators (include/asm_hip.h: asm_eval_*)
     def eval_setup(self, fm):
         """Hand the flattened function store of a FunctionModel (moi_evaluator.py) and its NLP block kernel to the handle."""

@@ -103,7 +103,7 @@ def run_batch(args, rank, world, local_rank, dist, torch):
     if args.batch_mode == "pool":
         return run_batch_pool(args, rank, world, local_rank, dist, torch, base, problems, total, per_gpu)
     n_slots = max(1, min(args.slots, hi - lo))
-    hb = batch.HipBatch(problems[lo], n_slots, device=local_rank)
+    hb = batch.HipBatch(problems[lo], n_slots, device=local_rank, groups=args.groups)
     if args.warmup:
         # every slot allocates its null-space buffers in its first LP and the batch selects its reference basis columns: outside the clock
         wpr = [acopf.function_model(acopf.scenario_case(base, 10 ** 6 + rank * 4096 + k)).to_problem("warm-up") for k in range(n_slots)]
@@ -150,7 +150,7 @@ def run_batch(args, rank, world, local_rank, dist, torch):
                                          "(asm_batch_slp_run: launches of different scenarios merged, scenario index in the grid)" % (per_gpu, n_slots),
                           "inputs": "scenario NLPs built on the host before the timed region; bounds uploads and solves inside it"},
                "batch_stats": stats,
-               "lockstep": {"slots": n_slots, "rounds": d["rounds"], "recorded_launches": d["ops"], "launches": d["launches"],
+               "lockstep": {"slots": n_slots, "groups": hb.groups, "rounds": d["rounds"], "recorded_launches": d["ops"], "launches": d["launches"],
                             "merge_ratio": d["ops"] / max(d["launches"], 1), "argument_table_MB": d["blob_bytes"] / 1e6,
                             "emit_ms": d["emit_ms"], "device_wait_ms": d["wait_ms"], "solver_host_ms": d["host_ms"], "wall_ms": d["wall_ms"]},
                "lp_outcomes": {"paths": hist, "lps": int(sum(r.lp_solves for r in runs)), "non_canonical_answers": int(sum(r.paths[9] + r.paths[10] for r in runs)),
@@ -476,6 +476,7 @@ def main():
     ap.add_argument("--scenarios-per-gpu", type=int, default=None, help="workload c5: scenarios per GPU (alias of --steps)")
     ap.add_argument("--max-iter", type=int, default=100, help="workload c5: SLP iteration cap per scenario")
     ap.add_argument("--slots", type=int, default=64, help="workload c5: scenarios advancing in lockstep per GPU (slots of the asm_batch)")
+    ap.add_argument("--groups", type=int, default=None, help="workload c5: groups of slots (one stream + one host thread each; library default: 2 from 16 slots on)")
     ap.add_argument("--batch-mode", default="lockstep", choices=["lockstep", "pool"], help="workload c5: lockstep batch (default) or the round-3 stream pool")
     ap.add_argument("--concurrency", type=int, default=2, help="workload c5, --batch-mode pool: scenarios in flight per GPU (one handle / HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -133,7 +133,9 @@ int asm_sublp_last_stats(const asm_handle* h, asm_solve_stats* out);
 /* Device time per kernel family, measured with HIP events on the handle's stream. */
 /* ASM_K_SYRK: the Schur build; ASM_K_CHOL / ASM_K_TRSV: whole factorisation / solve (many launches);
  * ASM_K_SYRK_KERNEL: every single launch of the rank-K MFMA kernels k_syrk_upd (Cholesky updates) and k_syrk<T> (Schur builds). */
-enum { ASM_K_ASSEMBLE = 0, ASM_K_SCALE, ASM_K_GEMV, ASM_K_SYRK, ASM_K_CHOL, ASM_K_TRSV, ASM_K_SYRK_KERNEL, ASM_K_COUNT };
+/* ASM_K_PANEL_KERNEL: every single launch of the dataflow panel kernels k_chol_panel / k_chol_panel_solo (the 64-wide steps of the Cholesky
+ * factorisations: the dependent chain the path is bound by since round 3). */
+enum { ASM_K_ASSEMBLE = 0, ASM_K_SCALE, ASM_K_GEMV, ASM_K_SYRK, ASM_K_CHOL, ASM_K_TRSV, ASM_K_SYRK_KERNEL, ASM_K_PANEL_KERNEL, ASM_K_COUNT };
 typedef struct {
     double  ms[ASM_K_COUNT];      /* accumulated device milliseconds */
     int64_t calls[ASM_K_COUNT];   /* number of timed regions */
@@ -142,6 +144,9 @@ typedef struct {
 } asm_kernel_stats;
 int asm_kernel_stats_get(asm_handle* h, asm_kernel_stats* out);
 int asm_kernel_stats_reset(asm_handle* h);
+/* 0: no HIP-event timing; 1: every launch of the rank-K and panel kernels (ASM_K_SYRK_KERNEL, ASM_K_PANEL_KERNEL); 2: every family
+ * (perturbs latency-bound workloads).  Default from the environment (ASM_HIP_TIMING), else 1. */
+int asm_kernel_timing(asm_handle* h, int level);
 
 /* ---- per-iteration reductions that consume J, lambda already in HBM (common.jl:35-44) ----------- */
 /* KT_residuals(df, lambda, mult_x_U, mult_x_L, J) with J = the Jacobian assembled by the last
@@ -229,6 +234,10 @@ int asm_batch_create(int device, int n_slots, asm_batch** out);
 int asm_batch_destroy(asm_batch* b);
 const char* asm_batch_last_error(const asm_batch* b);
 int asm_batch_slots(const asm_batch* b);
+/* The slots are split into groups: one stream and one host thread each (group 0 on the calling thread), so that one group's host work
+ * (merging, launching) overlaps the other groups' device work.  Default: 2 groups from 16 slots on (ASM_BATCH_GROUPS overrides). */
+int asm_batch_set_groups(asm_batch* b, int n_groups);
+int asm_batch_groups(const asm_batch* b);
 /* the handle of a slot: the per-handle entries (statistics, asm_sublp_active_set, ...) work on it between batch calls */
 asm_handle* asm_batch_handle(asm_batch* b, int slot);
 /* asm_sublp_setup / asm_eval_setup for every slot (same pattern, same functions) */

@@ -126,7 +126,7 @@ def test_batch_sublp_solve_equals_handle_solves_bit_for_bit(kind):
 
 
 def test_batched_slp_runs_equal_per_scenario_runs_bit_for_bit():
-    """Eight case300-sized scenarios (the C5 workload of bench.py) through asm_batch_slp_run with eight slots, with three slots (slots take
+    """Eight case300-sized scenarios (the C5 workload of bench.py) through asm_batch_slp_run with eight slots in two groups, with three slots (slots take
     the next scenario when they finish one) and one by one through asm_slp_run on a single handle: identical iterates, multipliers,
     iteration / LP counts and solver paths, all converged; with eight slots most launches are shared."""
     import activesetmethods_amd as A
@@ -134,12 +134,13 @@ def test_batched_slp_runs_equal_per_scenario_runs_bit_for_bit():
     base = acopf.synthetic_case("case300", 1, 0.5)
     prs = [acopf.function_model(acopf.scenario_case(base, s)).to_problem("case300-sized scenario %d" % s) for s in range(8)]
     par = A.Parameters(algorithm="Line Search", max_iter=100, device_eval=True)
-    hb = batch.HipBatch(prs[0], 8)
+    hb = batch.HipBatch(prs[0], 8, groups=2)             # two groups of four slots: two streams, two host threads
+    assert hb.groups == 2
     runs8, stats, bst = batch.solve_batch_lockstep(prs, par, 8, batch=hb)
     J = hb.ns_basis()
     hb.close()
     assert stats["scenarios"] == 8 and stats["converged"] == 8, stats
-    assert len(J) > 0 and bst["ops"] >= 3 * bst["launches"], bst
+    assert len(J) > 0 and bst["ops"] >= 2 * bst["launches"], bst
     hb3 = batch.HipBatch(prs[0], 3)
     hb3.set_ns_basis(J)
     runs3, _, _ = batch.solve_batch_lockstep(prs, par, 3, batch=hb3)
