@@ -56,6 +56,7 @@ const double RED_TAU = 100.0, RED_MIN_FRAC = 0.1;
 const int NS_MIN_E = 64;
 const double NS_MAX_RATIO = 0.3, NS_WARM_THR = 1e-6, NS_ZWARM_THR = 0.25, NS_BIG = 0.5e128, NS_RERR = 1e-6;
 const int NS_CMAX = 2;
+const double EQP_RUNAWAY = 1e3;  // oracle/lp_solver.py: growth of the primal residual between two rounds of a bulk correction that ends the attempt
 const int64_t RCM_MAX_PAIRS = 50000000;      // sum over the columns of (rows in the column)^2 beyond which no row order is computed
 const double IPM_ACCEPT = 1e-10;
 const int NS_MAX_SPLIT = 8;
@@ -319,7 +320,7 @@ struct asm_handle {
     bool fused_panel = true;        // Cholesky inner panels as one dataflow launch (k_chol_panel) instead of three launches per 64-wide step
     int panel_wgs = 240;            // its grid bound: every workgroup must be able to become resident
     int num_cus = 256;              // compute units of the device (hipDeviceProp_t::multiProcessorCount)
-    unsigned *d_pflags = nullptr, *d_ptmo = nullptr, *d_gbar = nullptr;      // panel flags, timeout word, grid barrier of k_trtri_fused
+    unsigned *d_pflags = nullptr, *d_ptmo = nullptr;
     unsigned panel_epoch = 0;
     int timing = 1;                 // HIP-event timing: 0 off, 1 the dominant kernel only (every k_syrk launch), 2 every kernel family
     bool verbose = false;
@@ -800,15 +801,7 @@ struct Dev {
         // explicit inverses of the wide diagonal blocks by divide and conquer over the 64-wide sub-blocks: diagonal
         // blocks from k_potrf_diag, then log2 levels of two launches each (the scratch T uses the buffer of the
         // transposed copy, which is written afterwards)
-        static const bool fuse_trtri = [] { const char* v = std::getenv("ASM_TRTRI_FUSED"); return !(v && v[0] == '0'); }();
-        if (Ms <= fwb && fuse_trtri && !asmb::in_fiber()) {
-            // one wide block: the whole inverse in one launch (grid barriers instead of launch boundaries; a scenario batch keeps the separate
-            // launches - merged across scenarios they are not latency-bound, and the fused kernel's workgroups must all be resident)
-            if (fwb == 1024)
-                asmb::launch_resident((k_trtri_fused<1024>), dim3(ASM_TRTRI_WGS), dim3(256), 0, h->stream, (const double*)fS, fld, Ms, (const double*)fLinv, fBinv, fBinvT, h->d_gbar, h->d_ptmo);
-            else
-                asmb::launch_resident((k_trtri_fused<512>), dim3(ASM_TRTRI_WGS / 2), dim3(256), 0, h->stream, (const double*)fS, fld, Ms, (const double*)fLinv, fBinv, fBinvT, h->d_gbar, h->d_ptmo);
-        } else if (fwb == 1024) trtri_launches<1024>(Ms); else trtri_launches<512>(Ms);
+        if (fwb == 1024) trtri_launches<1024>(Ms); else trtri_launches<512>(Ms);
         end(id);
         h->stats.nfact += 1;
     }
@@ -2056,6 +2049,7 @@ struct Solver {
     bool eqp_loop(const double* p_ref, const double* y_ref, int rounds) {
         int cur = 0, nx = 1, prev = 2;
         bool have_prev = false;
+        double pr_last = -1.0;
         double t_round = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
         for (int k = 0; k <= rounds; ++k) {
             asmb::barrier(btag + 60 + k);
@@ -2077,6 +2071,9 @@ struct Solver {
             }
             if (pr <= TOL_P && du <= TOL_D) return true;
             if (k == rounds) break;
+            // oracle: EQP_RUNAWAY - a correction that made the primal residual 1000 times worse has left the neighbourhood of the partition
+            if (pr_last >= 0.0 && pr > EQP_RUNAWAY * std::max(pr_last, TOL_P)) break;
+            pr_last = pr;
             if (h->h_ascnt[AC_NCHG] == 0 || (have_prev && h->h_ascnt[AC_NDIFF] == 0)) break;
             const int old_prev = prev;
             prev = cur; cur = nx; nx = old_prev;
@@ -2497,8 +2494,8 @@ void free_device(asm_handle* h) {
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     if (h->h_seq) (void)hipHostFree(h->h_seq);
     h->d_ipm = nullptr; h->d_ipm_i = nullptr; h->h_scal = nullptr; h->h_seq = nullptr; h->d_hscal = nullptr; h->d_hseq = nullptr;
-    F(h->d_pflags); F(h->d_ptmo); F(h->d_gbar);
-    h->d_pflags = h->d_ptmo = h->d_gbar = nullptr;
+    F(h->d_pflags); F(h->d_ptmo);
+    h->d_pflags = h->d_ptmo = nullptr;
     for (void* q : h->ns_bufs) F(q);
     h->ns_bufs.clear();
     h->ns_cap = false; h->ns_kcap = 0; h->ns_ccap = 0; h->ns_Zk = 0; h->ns_fC = FacBuf(); h->d_nsqi = nullptr; h->d_nsq = nullptr;
@@ -2534,8 +2531,7 @@ void check_panel_timeout(asm_handle* h) {
     HIPCHK(hipMemcpy(&tmo, h->d_ptmo, sizeof(unsigned), hipMemcpyDeviceToHost));
     if (tmo != 0) {
         HIPCHK(hipMemset(h->d_ptmo, 0, sizeof(unsigned)));      // reported once: the handle stays usable
-        HIPCHK(hipMemset(h->d_gbar, 0, 4 * sizeof(unsigned)));
-        throw HipError("k_chol_panel / k_trtri_fused: a workgroup timed out waiting for a producer (grid not resident?)");
+        throw HipError("k_chol_panel: a workgroup timed out waiting for a producer (grid not resident?)");
     }
 }
 
@@ -2650,8 +2646,6 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     dmalloc(&h->d_Linv, (h->Mp / ASM_NB + 1) * ASM_NB * ASM_NB);
     dmalloc(&h->d_pflags, ASM_PNL_NS * (ASM_PNL_NS + 1));
     dmalloc(&h->d_ptmo, 4);
-    dmalloc(&h->d_gbar, 4);
-    HIPCHK(hipMemsetAsync(h->d_gbar, 0, 4 * sizeof(unsigned), h->stream));
     HIPCHK(hipMemsetAsync(h->d_ptmo, 0, 4 * sizeof(unsigned), h->stream));
     HIPCHK(hipMemsetAsync(h->d_pflags, 0, ASM_PNL_NS * (ASM_PNL_NS + 1) * sizeof(unsigned), h->stream));
     h->wb = h->M > 1536 ? 1024 : 512;      // wide-block width of the triangular solves (k_wtrsv_*<WB>)

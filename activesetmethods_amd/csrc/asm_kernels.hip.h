@@ -1495,59 +1495,6 @@ __global__ __launch_bounds__(256) void k_transpose_wb(AsmBt abt, const double* _
     transpose_wb_tile<WB>(tile, Binv, BinvT, blockIdx.x, blockIdx.y / (WB / ASM_NB), blockIdx.y % (WB / ASM_NB));
 }
 
-// The whole explicit inverse of ONE wide block (a factor of order <= WB: the k x k systems of the null-space form, dense 500 x 500 LPs) in
-// one launch instead of 2 + 2 log2(WB / 64) dependent ones: the same tile products in the same order (bit-identical), the launches'
-// boundaries replaced by grid-wide barriers.  ASM_TRTRI_WGS workgroups (all resident: far fewer than compute units); a level has at most
-// WB / 128 * (WB / 128) / ... tiles = 64 at WB = 1024, so more workgroups would idle.  bar[0] = arrivals, bar[1] = generation (zeroed once
-// at allocation, the barrier leaves bar[0] = 0); bounded spin: a lost workgroup must not hang the GPU (tmo as for the panel kernel).
-#define ASM_TRTRI_WGS 64
-__device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned G, unsigned* tmo) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned gen = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned prev = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev == G - 1) {
-            __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            unsigned spins = 0;
-            while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 24)) { __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            }
-        }
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
-template <int WB>
-__global__ __launch_bounds__(256) void k_trtri_fused(AsmBt abt, const double* __restrict__ L, int64_t ld, int Ms, const double* __restrict__ Linv, double* __restrict__ Binv,
-                                                     double* __restrict__ BinvT, unsigned* __restrict__ bar, unsigned* __restrict__ tmo) {
-    ASM_BARGS(abt, L, ld, Ms, Linv, Binv, BinvT, bar, tmo);
-    __shared__ double Pa[ASM_NB * ASM_TP];
-    __shared__ double Qt[ASM_NB * ASM_TP];
-    constexpr int WSUB = WB / ASM_NB;
-    const int G = gridDim.x, wg = blockIdx.x;
-    for (int it = wg; it < WSUB * WSUB; it += G) trtri_init_tile<WB>(Linv, Ms, Binv, 0, it / WSUB, it % WSUB);
-    grid_barrier(bar, (unsigned)G, tmo);
-    for (int hh = 1; hh < WSUB; hh *= 2)
-        for (int stage = 0; stage < 2; ++stage) {
-            const int npr = WSUB / (2 * hh), nit = npr * hh * hh;
-            for (int it = wg; it < nit; it += G) {
-                const int pr = it / (hh * hh), z = it % (hh * hh);
-                __syncthreads();                  // the LDS operands of the previous tile have been consumed
-                trtri_level_tile<WB>(Pa, Qt, L, ld, Ms, Binv, BinvT, hh, stage, 0, pr, z / hh, z % hh);
-            }
-            grid_barrier(bar, (unsigned)G, tmo);
-        }
-    for (int it = wg; it < WSUB * WSUB; it += G) {
-        __syncthreads();
-        transpose_wb_tile<WB>(Pa, Binv, BinvT, 0, it / WSUB, it % WSUB);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // Sparse matrix-vector products on the fixed Jacobian pattern (ACOPF: 0.03 % fill).  The dense row-major matrix stays
 // the operand of the MFMA kernels; these read a gathered copy of its pattern entries (CSR values, CSC via positions).

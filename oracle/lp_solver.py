@@ -937,10 +937,14 @@ def _same(a, b):
     return all(np.array_equal(x, y) for x, y in zip(a, b))
 
 
+EQP_RUNAWAY = 1e3    # growth of the primal residual between two rounds of a bulk correction that ends the attempt
+
+
 def eqp_loop(lp, sets, p_ref, y_ref, rounds, stats, nsp=None):
     """`nsp`: the LP's NullSpace - the solves then go through it (eqp_ns; only with the reference point of the unique-optimum polish)."""
     prev = None
     p = s = y = None
+    pr_last = None
     for k in range(rounds + 1):
         if nsp is not None:
             sol = eqp_ns(lp, nsp, sets)
@@ -959,6 +963,11 @@ def eqp_loop(lp, sets, p_ref, y_ref, rounds, stats, nsp=None):
             return True, p, s, y, sets
         if k == rounds:
             break
+        # a correction that made the primal residual EQP_RUNAWAY times worse has left the neighbourhood of the partition (observed: 2e3 ->
+        # 1.5e55 in one round on a restoration LP): further rounds only factor ever larger working sets - the attempt ends here
+        if pr_last is not None and pr > EQP_RUNAWAY * max(pr_last, TOL_P):
+            break
+        pr_last = pr
         nxt, nchg = correct(lp, p, s, y, sets)
         if nchg == 0 or (prev is not None and _same(nxt, prev)):
             break

@@ -10,28 +10,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _random_function_model(seed, n=30, sense="MIN_SENSE"):
-    from activesetmethods_amd.moi_evaluator import FunctionModel, ScalarFunction
-    rng = np.random.default_rng(seed)
-    fm = FunctionModel(n, -np.ones(n), np.ones(n))
-    fm.sense = sense
-
-    def func(quad):
-        aff = [(float(rng.standard_normal()), int(rng.integers(1, n + 1))) for _ in range(int(rng.integers(0, 6)))]
-        q = []
-        if quad:
-            for _ in range(int(rng.integers(1, 5))):
-                a, b = int(rng.integers(1, n + 1)), int(rng.integers(1, n + 1))
-                if rng.random() < 0.4:
-                    b = a
-                q.append((float(rng.standard_normal()), a, b))
-        return ScalarFunction(float(rng.standard_normal()), aff, q)
-    for kind in ("le", "ge", "eq"):
-        for _ in range(int(rng.integers(1, 5))):
-            fm.add_constraint(func(False), kind, float(rng.standard_normal()))
-        for _ in range(int(rng.integers(1, 5))):
-            fm.add_constraint(func(True), kind, float(rng.standard_normal()))
-    fm.objective = func(True)
-    return fm
+    from tests.util import random_function_model
+    return random_function_model(seed, n, sense)
 
 
 def _optimizer_for(pr):
@@ -58,6 +38,11 @@ def test_affine_quadratic_evaluator_is_bit_identical(seed, sense):
         assert np.array_equal(opt.jacobian_values(), pr.eval_jac_g(x, np.zeros(pr.nnz)))
         ft, Et = opt.eval_constraints(0.5 * x)
         assert ft == pr.eval_f(0.5 * x) and np.array_equal(Et, pr.eval_g(0.5 * x, np.zeros(pr.m)))
+        # ... and the oracle's independent restatement of MOI_wrapper.jl:776-944 (oracle/moi_eval.py: no code shared with the product)
+        from tests.util import oracle_wrapper_model, oracle_evaluate
+        fo, go, Eo, dEo, j_str = oracle_evaluate(oracle_wrapper_model(fm), x)
+        assert f == fo and np.array_equal(df, go) and np.array_equal(E, Eo) and np.array_equal(opt.jacobian_values(), dEo)
+        assert [tuple(t) for t in zip(pr.j_row, pr.j_col)] == j_str
     opt.close()
 
 
@@ -80,6 +65,11 @@ def test_acopf_device_evaluator(case, seed):
     assert f == pr.eval_f(x) and np.array_equal(df, pr.eval_grad_f(x, np.zeros(pr.n)))
     assert np.array_equal(E[:k], Eh[:k]) and np.array_equal(dEd[:nf], dEh[:nf])
     assert rel_err(E[k:], Eh[k:]) < 1e-13 and rel_err(dEd[nf:], dEh[nf:]) < 1e-13
+    if case == "case118":            # the same against the oracle's restatement of the wrapper block (pure Python: the small size only)
+        from tests.util import oracle_wrapper_model, oracle_evaluate
+        fo, go, Eo, dEo, j_str = oracle_evaluate(oracle_wrapper_model(fm), x)
+        assert f == fo and np.array_equal(df, go) and np.array_equal(E[:k], Eo[:k]) and np.array_equal(dEd[:nf], dEo[:nf])
+        assert [tuple(t) for t in zip(pr.j_row, pr.j_col)] == j_str
     opt.close()
 
 

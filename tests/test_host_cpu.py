@@ -209,3 +209,20 @@ def test_function_model_follows_the_wrapper():
     assert list(fm.start_point()) == [0.0, 0.0, 0.0]
     pr = fm.to_problem()
     assert pr.m == 3 and pr.nnz == 6 and list(pr.j_row) == [1, 2, 2, 3, 3, 3]
+
+
+@pytest.mark.parametrize("seed,sense", [(1, "MIN_SENSE"), (2, "MAX_SENSE"), (3, "FEASIBILITY_SENSE")])
+def test_host_evaluator_equals_the_oracle_restatement(seed, sense):
+    """The product's host evaluator (activesetmethods_amd/moi_evaluator.py) against oracle/moi_eval.py - two restatements of
+    MOI_wrapper.jl:683-944 that share no code: pattern, f, grad f, g and the Jacobian values bit for bit."""
+    from tests.util import random_function_model, oracle_wrapper_model, oracle_evaluate
+    fm = random_function_model(seed, sense=sense)
+    pr = fm.to_problem()
+    om = oracle_wrapper_model(fm)
+    rng = np.random.default_rng(seed + 7)
+    for _ in range(3):
+        x = rng.uniform(-1.0, 1.0, pr.n)
+        fo, go, Eo, dEo, j_str = oracle_evaluate(om, x)
+        assert [tuple(t) for t in zip(pr.j_row, pr.j_col)] == j_str
+        assert pr.eval_f(x) == fo and np.array_equal(pr.eval_grad_f(x, np.zeros(pr.n)), go)
+        assert np.array_equal(pr.eval_g(x, np.zeros(pr.m)), Eo) and np.array_equal(pr.eval_jac_g(x, np.zeros(pr.nnz)), dEo)

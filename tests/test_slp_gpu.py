@@ -60,6 +60,19 @@ def test_synthetic_dense_small_trace(alg, iters):
     assert all(r['stats']['polished'] == 1 for r in sh.trace)
 
 
+def test_full_size_c2_trust_region_trace():
+    """BASELINE.json configs[1] at its full size (n = 1000, m = 500, dense Jacobian, 500 000 entries): the first three Trust-Region LPs of the
+    SLP run against the oracle's run - same status, phase, working sets (rows / bounds) at every LP, step and multipliers within 1e-9."""
+    from activesetmethods_amd import problems
+    pr = problems.synthetic_dense_nlp(1000, 500)
+    mh, sh = _hip_run(pr, algorithm="Trust Region", max_iter=3)
+    mo, so = _oracle_run(pr, algorithm="Trust Region", max_iter=3)
+    assert so.lp_solves == sh.lp_solves >= 3 and so.iter == sh.iter
+    _compare_traces(so, sh)
+    assert rel_err(mh.x, mo.x) < 1e-9
+    assert all(r['stats']['polished'] == 1 for r in sh.trace)
+
+
 @pytest.mark.parametrize("kind", ["dense", "sparse"])
 def test_reductions_on_resident_jacobian(kind):
     """KT_residuals / row norms computed from the HBM-resident Jacobian (common.jl:35-44); the sparse case runs the

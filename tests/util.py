@@ -171,3 +171,59 @@ def banded_subproblem(seed, n=400, m=600, neq=120, nrange=30, width=6, per_row=4
     df = rng.standard_normal(n)
     return dict(n=n, m=m, j_row=rows + 1, j_col=cols + 1, dE=vals, df=df, f=0.1, E=E, x_k=x_k,
                 c_lb=c_lb, c_ub=c_ub, v_lb=v_lb, v_ub=v_ub, delta=delta, J=J)
+
+
+def random_function_model(seed, n=30, sense="MIN_SENSE"):
+    """A random model in the MOI wrapper's six lists (affine and quadratic functions, duplicates, diagonal quadratic terms)."""
+    from activesetmethods_amd.moi_evaluator import FunctionModel, ScalarFunction
+    rng = np.random.default_rng(seed)
+    fm = FunctionModel(n, -np.ones(n), np.ones(n))
+    fm.sense = sense
+
+    def func(quad):
+        aff = [(float(rng.standard_normal()), int(rng.integers(1, n + 1))) for _ in range(int(rng.integers(0, 6)))]
+        q = []
+        if quad:
+            for _ in range(int(rng.integers(1, 5))):
+                a, b = int(rng.integers(1, n + 1)), int(rng.integers(1, n + 1))
+                if rng.random() < 0.4:
+                    b = a
+                q.append((float(rng.standard_normal()), a, b))
+        return ScalarFunction(float(rng.standard_normal()), aff, q)
+    for kind in ("le", "ge", "eq"):
+        for _ in range(int(rng.integers(1, 5))):
+            fm.add_constraint(func(False), kind, float(rng.standard_normal()))
+        for _ in range(int(rng.integers(1, 5))):
+            fm.add_constraint(func(True), kind, float(rng.standard_normal()))
+    fm.objective = func(True)
+    return fm
+
+
+def oracle_wrapper_model(fm):
+    """The plain-dict model of oracle/moi_eval.py from the RAW data of a FunctionModel (constants and term lists as they were given to it -
+    nothing of the product's evaluation or flattening code is used): the independent checker of rows a2 / f3."""
+    def fn(f):
+        return {"constant": float(f.constant), "affine": [(float(c), int(v)) for c, v in f.affine],
+                "quadratic": [(float(c), int(a), int(b)) for c, a, b in f.quadratic]}
+    m = {"n": fm.n, "sense": fm.sense, "objective": None if fm.objective is None else fn(fm.objective)}
+    for name in ("linear_le", "linear_ge", "linear_eq", "quadratic_le", "quadratic_ge", "quadratic_eq"):
+        m[name] = [fn(f) for f, _ in getattr(fm, name)]
+    m["nlp"] = None
+    if fm.nlp is not None:
+        blk = fm.nlp
+        m["nlp"] = {"m": blk.m, "pattern": list(zip(blk.rows.tolist(), blk.cols.tolist())),
+                    "eval_g": lambda x: blk.eval_g(np.asarray(x, float), np.zeros(blk.m)),
+                    "eval_jac": lambda x: blk.eval_jac_g(np.asarray(x, float), np.zeros(len(blk.rows)))}
+    return m
+
+
+def oracle_evaluate(om, x):
+    """(f, grad f, g, Jacobian values, j_str) of a wrapper model through oracle/moi_eval.py."""
+    from oracle import moi_eval as W
+    xs = [float(v) for v in x]
+    j_str = W.jacobian_structure(om)
+    m = W.nlp_constraint_offset(om) + (om["nlp"]["m"] if om["nlp"] is not None else 0)
+    g = W.eval_constraint(om, [0.0] * m, xs)
+    vals = W.eval_constraint_jacobian(om, [0.0] * len(j_str), xs)
+    grad = W.eval_objective_gradient(om, [0.0] * om["n"], xs)
+    return W.eval_objective(om, xs), np.array(grad), np.array(g, float), np.array(vals, float), j_str
