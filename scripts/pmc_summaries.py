@@ -43,6 +43,19 @@ doc = {"_comment": "HBM traffic per launch of the dominant kernel family (k_syrk
        "workload": wl, "kernel": "k_syrk_upd + k_syrk<T,NW,KC,WPE> (all rank-K launches)", "launches": L,
        "fetch_bytes_per_launch": sum(v["fetch_bytes"] for v in per.values()) / L, "write_bytes_per_launch": sum(v["write_bytes"] for v in per.values()) / L,
        "traffic_bytes_per_launch": sum(v["fetch_bytes"] + v["write_bytes"] for v in per.values()) / L, "per_instantiation": per}
+# every kernel (bench.py reads the entry of the kernel family it reports as dominant; the rank-K family without k_syrk_upd where that
+# kernel only occurs in the cold first LP of the run, which the timed region does not contain)
+allk = {}
+for k in F:
+    n = F[k].get("_launches", 0) or 1
+    allk[k] = dict(launches=n, fetch_bytes_per_launch=2.0 * F[k].get("FETCH_SIZE", 0.0) * 1024.0 / n, write_bytes_per_launch=W.get(k, {}).get("WRITE_SIZE", 0.0) * 1024.0 / n,
+                   ms_per_launch=F[k].get("_duration_ns", 0.0) / 1e6 / n)
+doc["per_kernel"] = allk
+def fam(names):
+    ks = [k for k in allk if any(k.startswith(nm) for nm in names)]
+    n = sum(allk[k]["launches"] for k in ks) or 1
+    return dict(kernels=ks, launches=n, traffic_bytes_per_launch=sum((allk[k]["fetch_bytes_per_launch"] + allk[k]["write_bytes_per_launch"]) * allk[k]["launches"] for k in ks) / n)
+doc["families"] = {"panel_kernel": fam(["k_chol_panel"]), "syrk_kernel": fam(["k_syrk"]), "syrk_kernel_without_upd": fam(["k_syrk<"])}
 json.dump(doc, open("gpurun_out/%s_%s_pmc_traffic.json" % (tag, wl), "w"), indent=1)
 with open("gpurun_out/%s_%s_pmc_traffic.txt" % (tag, wl), "w") as f:
     f.write("# HBM traffic of the k_syrk kernels (PMC, separate passes, one counter per pass), MI355X, round %s\n" % tag[1:])

@@ -343,6 +343,14 @@ def test_converged_iterate_last_resort_scenario_27():
         assert o_out[5] == 1 and o_out[6]['stats']['path'] == 'ipm-conv', o_out[6]['stats']
         assert abs(sp['df'] @ (o_out[0] - rec['p'])) <= 1e-8 * max(1.0, abs(sp['df'] @ rec['p']))
         assert rel_err(rec['p'], o_out[0]) < 1e-6
+        # the non-canonical answer against an independent LP code: HiGHS optimal value of the same LP, and the GPU's step is feasible for it
+        from oracle import sparse_lp
+        lp = sparse_lp.build(pr.n, pr.m, pr.j_row, pr.j_col, sp['dE'], sp['df'], sp['E'], pr.g_L, pr.g_U, pr.x_L, pr.x_U, x, rec['delta'], False)
+        st, obj, _, _, _ = sparse_lp.solve_highs(lp)
+        assert st == 1 and abs(sp['df'] @ rec['p'] - obj) <= 1e-7 * max(1.0, abs(obj))
+        Ap = lp['A_ub'] @ rec['p'] - lp['b_ub']
+        assert Ap.max(initial=0.0) <= 1e-7 and np.abs(lp['A_eq'] @ rec['p'] - lp['b_eq']).max(initial=0.0) <= 1e-7
+        assert np.all(rec['p'] >= lp['bounds'][:pr.n, 0] - 1e-9) and np.all(rec['p'] <= lp['bounds'][:pr.n, 1] + 1e-9)
 
 
 def test_scenario_batch_is_independent_of_the_stream_pool():
