@@ -18,9 +18,13 @@
 #include <sys/mman.h>
 #include <ucontext.h>
 #include <cstdint>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <functional>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -140,6 +144,8 @@ struct Sched {
     // statistics
     uint64_t n_rounds = 0, n_ops = 0, n_launches = 0, n_releases = 0, blob_bytes = 0;
     double t_emit_ms = 0, t_wait_ms = 0, t_host_ms = 0;
+    bool verbose = false;                                   // ASM_BATCH_VERBOSE=1: per-kernel merge statistics at release
+    std::map<const void*, std::pair<uint64_t, uint64_t>> per_kernel;      // kernel -> (operations recorded, launches made)
 
     static void chk(hipError_t e, const char* what) {
         if (e != hipSuccess) throw BatchError(std::string(what) + ": " + hipGetErrorString(e));
@@ -161,6 +167,7 @@ struct Sched {
     }
     void init(int dev, hipStream_t s, int pwgs) {
         device = dev; stream = s; panel_wgs = pwgs;
+        if (const char* v = std::getenv("ASM_BATCH_VERBOSE")) verbose = v[0] == '1';
         chk(hipHostMalloc((void**)&h_sig, 64, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc(sig)");
         chk(hipHostGetDevicePointer((void**)&d_sig, h_sig, 0), "hipHostGetDevicePointer(sig)");
         *h_sig = 0;
@@ -168,6 +175,17 @@ struct Sched {
         reserve_out((size_t)1 << 20);
     }
     void release() {
+        if (verbose && !per_kernel.empty()) {
+            std::vector<std::pair<uint64_t, const void*>> v;
+            for (auto& kv : per_kernel) v.push_back({kv.second.second, kv.first});
+            std::sort(v.rbegin(), v.rend());
+            std::fprintf(stderr, "[asm batch] rounds %llu, launches by kernel (launches, operations, operations per launch):\n", (unsigned long long)n_rounds);
+            for (size_t i = 0; i < v.size() && i < 40; ++i) {
+                const auto& pk = per_kernel[v[i].second];
+                const char* nm = hipKernelNameRefByPtr(v[i].second, stream);
+                std::fprintf(stderr, "[asm batch]   %8llu %9llu %6.1f  %.60s\n", (unsigned long long)pk.second, (unsigned long long)pk.first, (double)pk.first / (double)pk.second, nm ? nm : "?");
+            }
+        }
         for (Fiber* f : fibers) {
             if (f->stack) munmap(f->stack, f->stack_size);
             delete f;
@@ -278,6 +296,7 @@ struct Sched {
                 if (group.size() < cap && f->cursor < f->ops.size() && (f == lead || same(f->ops[f->cursor], X))) group.push_back(f);
             bo = (bo + 15) & ~(size_t)15;
             launches.push_back({&X, bo, (unsigned)group.size()});
+            if (verbose) { auto& pk = per_kernel[X.kfn]; pk.first += group.size(); pk.second += 1; }
             for (Fiber* f : group) {
                 std::memcpy(h_blob + bo, f->args.data() + f->ops[f->cursor].arg_off, X.arg_size);
                 bo += X.arg_size;

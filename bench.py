@@ -50,7 +50,8 @@ def _cpu_throttled_s():
     return 0.0
 
 
-HOST_THREADS = max(1, min(8, _host_cpu_quota() // 2))      # half the quota: BLAS workers spin-wait after every call
+# half of this rank's share of the quota: BLAS workers spin-wait after every call (ranks of one node share the cgroup)
+HOST_THREADS = max(1, min(8, _host_cpu_quota() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))) // 2))
 for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
     os.environ.setdefault(_v, str(HOST_THREADS))
 
@@ -103,7 +104,13 @@ def run_batch(args, rank, world, local_rank, dist, torch):
     if args.batch_mode == "pool":
         return run_batch_pool(args, rank, world, local_rank, dist, torch, base, problems, total, per_gpu)
     n_slots = max(1, min(args.slots, hi - lo))
-    hb = batch.HipBatch(problems[lo], n_slots, device=local_rank, groups=args.groups)
+    groups = args.groups
+    if groups is None:
+        # one host thread per group: never more groups than this rank's share of the CPU quota (a spinning thread that is descheduled
+        # stalls its whole group)
+        share = max(1, _host_cpu_quota() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
+        groups = max(1, min(3 if n_slots >= 48 else (2 if n_slots >= 16 else 1), share - 1 if share > 1 else 1))
+    hb = batch.HipBatch(problems[lo], n_slots, device=local_rank, groups=groups)
     if args.warmup:
         # every slot allocates its null-space buffers in its first LP and the batch selects its reference basis columns: outside the clock
         wpr = [acopf.function_model(acopf.scenario_case(base, 10 ** 6 + rank * 4096 + k)).to_problem("warm-up") for k in range(n_slots)]

@@ -235,7 +235,7 @@ int asm_batch_destroy(asm_batch* b);
 const char* asm_batch_last_error(const asm_batch* b);
 int asm_batch_slots(const asm_batch* b);
 /* The slots are split into groups: one stream and one host thread each (group 0 on the calling thread), so that one group's host work
- * (merging, launching) overlaps the other groups' device work.  Default: 2 groups from 16 slots on (ASM_BATCH_GROUPS overrides). */
+ * (merging, launching) overlaps the other groups' device work.  Default: 2 groups from 16 slots on, 3 from 48 on (ASM_BATCH_GROUPS overrides). */
 int asm_batch_set_groups(asm_batch* b, int n_groups);
 int asm_batch_groups(const asm_batch* b);
 /* the handle of a slot: the per-handle entries (statistics, asm_sublp_active_set, ...) work on it between batch calls */
