@@ -1604,12 +1604,13 @@ struct Solver {
             ns_gemv_t_dense(tk, k, zz);
             hipLaunchKernelGGL(k_ns_e1, dim3(gN), dim3(256), 0, h->stream, P, (const double*)d0, (const double*)zz, e, ldn);
         }
-        hipLaunchKernelGGL(k_ns_neg, dim3(gN), dim3(256), 0, h->stream, (const double*)e, dpb, ldn);
-        HIPCHK(hipMemsetAsync(P.scal + SC_NSERR, 0, sizeof(double), h->stream));
-        dev.gemv_n_dev(h->d_Ah, dpb, aM);
-        hipLaunchKernelGGL(k_ns_wm, dim3(gM), dim3(256), 0, h->stream, X, thI, (const double*)aM, yM, M);
-        dev.gemv_t_dev(h->d_Ah, yM, atw);
-        hipLaunchKernelGGL(k_ns_kx, dim3(gN), dim3(256), 0, h->stream, th, (const double*)dpb, (const double*)atw, (const double*)nullptr, kdpb, ldn);
+        // (fused launches: negation + clearing of the residual measure; sparse product + its row- / column-wise kernel)
+        const double* vals = dev.sparse_vals(h->d_Ah);
+        hipLaunchKernelGGL(k_ns_neg_clear, dim3(gN), dim3(256), 0, h->stream, (const double*)e, dpb, ldn, P.scal + SC_NSERR);
+        hipLaunchKernelGGL(k_ns_spmvn_wm, dim3(gM), dim3(256), 0, h->stream, (const int*)h->d_sp_ptr, (const int*)h->d_sp_col, vals, (const double*)dpb, X, thI, yM, M);
+        hipLaunchKernelGGL(k_ns_spmvt_kx, dim3((unsigned)((ldn * 8 + 255) / 256)), dim3(256), 0, h->stream, (const int*)h->d_sc_ptr, (const int*)h->d_sc_row, (const int*)h->d_sc_pos, vals,
+                           (const double*)yM, th, (const double*)dpb, kdpb, lp.n, ldn);
+        (void)aM; (void)atw;
     }
     // One Newton solve in null-space form (oracle: IPM.run, solve_ns): mode 0 affine, 1 Mehrotra corrector on `base`.  The relative residual of
     // the reduced solve (after its refinement sweep) is accumulated in SC_NSERR.
@@ -1623,10 +1624,10 @@ struct Solver {
         const double* th = h->d_nsth;
         const double* thI = h->d_nsth + ldn;
         const double res = 1.0;
-        hipLaunchKernelGGL(k_ipm_rhs1, dim3(g), dim3(256), 0, h->stream, P, base, mode, 0.0, 0.0, MCC_BMIN, MCC_BMAX);
-        hipLaunchKernelGGL(k_ns_bi, dim3(gM), dim3(256), 0, h->stream, P, X, thI, res, bI, yM);
-        dev.gemv_t_dev(h->d_Ah, yM, atw);
-        hipLaunchKernelGGL(k_ns_ht, dim3(gN), dim3(256), 0, h->stream, th, (const double*)P.hp, (const double*)atw, (const double*)kdpb, res, ht, v, n, ldn);
+        const double* vals = dev.sparse_vals(h->d_Ah);
+        hipLaunchKernelGGL(k_ns_rhs1_bi, dim3(g), dim3(256), 0, h->stream, P, base, mode, X, thI, res, bI, yM);
+        hipLaunchKernelGGL(k_ns_spmvt_ht, dim3((unsigned)((ldn * 8 + 255) / 256)), dim3(256), 0, h->stream, (const int*)h->d_sc_ptr, (const int*)h->d_sc_row, (const int*)h->d_sc_pos, vals,
+                           (const double*)yM, th, (const double*)P.hp, (const double*)kdpb, res, ht, v, n, ldn);
         gemv_rows((const double*)h->d_nsG, h->ns_ldg, (const double*)v, ru, (int64_t)k, ldn);
         if (k <= ASM_SMALL_USE) {
             // solve, refinement sweep on the unregularised matrix and the residual check in ONE one-workgroup launch
@@ -1644,8 +1645,8 @@ struct Solver {
         }
         ns_gemv_t_dense(du, k, v);
         hipLaunchKernelGGL(k_ns_dp, dim3(gN), dim3(256), 0, h->stream, P, D, th, (const double*)dpb, res, (const double*)v, ldn);
-        dev.gemv_n_dev(h->d_Ah, D.dp, aM);
-        hipLaunchKernelGGL(k_ns_rows, dim3(gM), dim3(256), 0, h->stream, P, D, X, thI, (const double*)bI, (const double*)aM, yM);
+        hipLaunchKernelGGL(k_ns_spmvn_rows, dim3(gM), dim3(256), 0, h->stream, (const int*)h->d_sp_ptr, (const int*)h->d_sp_col, vals, P, D, X, thI, (const double*)bI, yM);
+        (void)aM; (void)atw;
     }
     // out[n] = Zt' u   (Zt dense, k rows of pitch ldg)
     void ns_gemv_t_dense(const double* u, int k, double* out) {
@@ -1891,8 +1892,11 @@ struct Solver {
                 continue;
             }
             const double eta = ip.mu >= 1.0 ? 0.995 : std::min(std::max(0.995, 1.0 - ip.mu / lp.scale_q), 0.999999);
-            hipLaunchKernelGGL(k_ipm_update, dim3(grid_all()), dim3(256), 0, h->stream, P, dirC, std::min(1.0, eta * ap), std::min(1.0, eta * ad));
-            if (use_ns) hipLaunchKernelGGL(k_ns_scale, dim3((unsigned)((h->ldn + 255) / 256)), dim3(256), 0, h->stream, nsv(14), 1.0 - std::min(1.0, eta * ap), h->ldn);
+            if (use_ns)
+                hipLaunchKernelGGL(k_ns_update, dim3(grid_all()), dim3(256), 0, h->stream, P, dirC, std::min(1.0, eta * ap), std::min(1.0, eta * ad), nsv(14),
+                                   1.0 - std::min(1.0, eta * ap), h->ldn);
+            else
+                hipLaunchKernelGGL(k_ipm_update, dim3(grid_all()), dim3(256), 0, h->stream, P, dirC, std::min(1.0, eta * ap), std::min(1.0, eta * ad));
             if (use_col && cg_max > COL_MAX_CG) ip.col_off = true;
             if (use_red && cg_max > RED_MAX_CG) ip.red_off = true;
         }
@@ -3979,7 +3983,10 @@ void batch_make_groups(asm_batch* b, int n_groups) {
         HIPCHK(hipStreamCreate(&g->stream));
         g->lo = (int)((int64_t)n * k / n_groups);
         g->hi = (int)((int64_t)n * (k + 1) / n_groups);
-        g->sched.init(b->device, g->stream, b->slots[0]->panel_wgs);
+        // the all-resident panel kernels of the groups run side by side: together they must fit the chip (workgroups are dealt to the XCDs
+        // round-robin and each XCD places its share on its own - a consumer can become resident before its producer, and with the chip
+        // full of spinning consumers the producer never would)
+        g->sched.init(b->device, g->stream, std::max(16, b->slots[0]->panel_wgs / n_groups));
         if (const char* nb = std::getenv("ASM_BATCH_NO_BARRIERS")) g->sched.use_barriers = !(nb[0] == '1');
         for (int s = g->lo; s < g->hi; ++s) { b->slots[s]->stream = g->stream; b->slots[s]->stream2 = g->stream; }
     }

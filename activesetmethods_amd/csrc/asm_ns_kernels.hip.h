@@ -393,6 +393,154 @@ __global__ __launch_bounds__(256) void k_ns_rows(AsmBt abt, IpmPtrs P, IpmDir D,
     D.dg[i] = dg;
     wM[i] = w;
 }
+// ---- fused forms of the null-space Newton solve (round 4: a null-space iteration is a chain of ~45 small launches; every pair
+// "sparse product, then a row- or column-wise kernel on its result" and every pair of adjacent element-wise kernels is one launch here).
+// The arithmetic of each element is the separate kernels' own, statement by statement.
+// k_ipm_rhs1 (complementarity right-hand sides) + k_ns_bi (its inequality-row part: row i needs only rcg[i])
+__global__ __launch_bounds__(256) void k_ns_rhs1_bi(AsmBt abt, IpmPtrs P, IpmDir A, int mode, NsIdx X, const double* __restrict__ thI, double res_bi, double* __restrict__ bI, double* __restrict__ yM) {
+    ASM_BARGS(abt, P, A, mode, X, thI, res_bi, bI, yM);
+    int64_t t = blockIdx.x * 256 + threadIdx.x;
+    const double sm = mode ? P.scal[SC_SM] : 0.0;
+    const double res = 1.0;
+    if (t < P.n) {
+        bool fr = P.ub[t] > P.lb[t];
+        double rcL = sm - P.tL[t] * P.muL[t];
+        double rcU = sm - P.tU[t] * P.muU[t];
+        if (mode) {
+            rcL -= A.dp[t] * A.dmuL[t];
+            rcU += A.dp[t] * A.dmuU[t];
+        }
+        P.rcL[t] = rcL;
+        P.rcU[t] = rcU;
+        double hp = fr ? -res * P.rdp[t] + rcL / P.tL[t] - rcU / P.tU[t] : 0.0;
+        P.hp[t] = hp;
+        P.tmpn[t] = P.thp_inv[t] * hp;
+    }
+    if (t < P.ns) {
+        double rcs = sm - P.ts[t] * P.mus[t];
+        if (mode) rcs -= A.ds[t] * A.dmus[t];
+        P.rcs[t] = rcs;
+        P.hs[t] = -res * P.rds[t] + rcs / P.ts[t];
+    }
+    if (t < P.M) {
+        double rcg = sm - P.g[t] * P.pi[t];
+        if (mode) rcg -= A.dg[t] * A.dpi[t];
+        P.rcg[t] = rcg;
+        const int ip = X.Ipos[t];
+        double b = 0.0, y = 0.0;
+        if (ip >= 0) {
+            b = -res_bi * P.rp[t] + (double)P.rtype[t] * rcg / P.pi[t];
+            y = thI[ip] * b;
+        }
+        bI[t] = b;
+        yM[t] = y;
+    }
+}
+// k_spmv_t (atw = Ah' yM, eight lanes per column) + k_ns_ht
+__global__ __launch_bounds__(256) void k_ns_spmvt_ht(AsmBt abt, const int* __restrict__ cptr, const int* __restrict__ row, const int* __restrict__ pos, const double* __restrict__ vals, const double* __restrict__ y,
+                                                     const double* __restrict__ th, const double* __restrict__ hp, const double* __restrict__ kdpb, double res, double* __restrict__ ht, double* __restrict__ v, int64_t n, int64_t ldn) {
+    ASM_BARGS(abt, cptr, row, pos, vals, y, th, hp, kdpb, res, ht, v, n, ldn);
+    const int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int sub = threadIdx.x & 7;
+    double acc = 0.0;
+    if (j < n)
+        for (int k = cptr[j] + sub; k < cptr[j + 1]; k += 8) acc += vals[pos[k]] * y[row[k]];
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (sub == 0 && j < ldn) {
+        double h = 0.0, o = 0.0;
+        if (j < n && th[j] != 0.0) {
+            h = hp[j] + acc;
+            o = h - res * kdpb[j];
+        }
+        ht[j] = h;
+        v[j] = o;
+    }
+}
+// k_spmv_t (atw = Ah' wM) + k_ns_kx (h == nullptr form)
+__global__ __launch_bounds__(256) void k_ns_spmvt_kx(AsmBt abt, const int* __restrict__ cptr, const int* __restrict__ row, const int* __restrict__ pos, const double* __restrict__ vals, const double* __restrict__ y,
+                                                     const double* __restrict__ th, const double* __restrict__ x, double* __restrict__ out, int64_t n, int64_t ldn) {
+    ASM_BARGS(abt, cptr, row, pos, vals, y, th, x, out, n, ldn);
+    const int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int sub = threadIdx.x & 7;
+    double acc = 0.0;
+    if (j < n)
+        for (int k = cptr[j] + sub; k < cptr[j + 1]; k += 8) acc += vals[pos[k]] * y[row[k]];
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (sub == 0 && j < ldn) {
+        const double t = th[j];
+        out[j] = t != 0.0 ? t * x[j] + acc : 0.0;
+    }
+}
+// k_spmv_n (aM = Ah dpbar) + k_ns_wm
+__global__ __launch_bounds__(256) void k_ns_spmvn_wm(AsmBt abt, const int* __restrict__ ptr, const int* __restrict__ col, const double* __restrict__ vals, const double* __restrict__ x, NsIdx X,
+                                                     const double* __restrict__ thI, double* __restrict__ wM, int64_t M) {
+    ASM_BARGS(abt, ptr, col, vals, x, X, thI, wM, M);
+    int64_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    double acc = 0.0;
+    for (int k = ptr[i]; k < ptr[i + 1]; ++k) acc += vals[k] * x[col[k]];
+    const int ip = X.Ipos[i];
+    wM[i] = ip >= 0 ? thI[ip] * acc : 0.0;
+}
+// k_spmv_n (aM = Ah dp) + k_ns_rows
+__global__ __launch_bounds__(256) void k_ns_spmvn_rows(AsmBt abt, const int* __restrict__ ptr, const int* __restrict__ col, const double* __restrict__ vals, IpmPtrs P, IpmDir D, NsIdx X,
+                                                       const double* __restrict__ thI, const double* __restrict__ bI, double* __restrict__ wM) {
+    ASM_BARGS(abt, ptr, col, vals, P, D, X, thI, bI, wM);
+    int64_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.M) return;
+    double acc = 0.0;
+    for (int k = ptr[i]; k < ptr[i + 1]; ++k) acc += vals[k] * D.dp[col[k]];
+    const int ip = X.Ipos[i];
+    double dy = 0.0, dpi = 0.0, dg = 0.0, w = 0.0;
+    if (ip >= 0) {
+        dy = thI[ip] * (bI[i] - acc);
+        dpi = (double)P.rtype[i] * dy;
+        dg = (P.rcg[i] - P.g[i] * dpi) / P.pi[i];
+        w = thI[ip] * acc;
+    }
+    D.dy[i] = dy;
+    D.dpi[i] = dpi;
+    D.dg[i] = dg;
+    wM[i] = w;
+}
+// k_ipm_update + k_ns_scale of e (the component of the iterate outside pbar + null(A_EF) shrinks by 1 - a)
+__global__ __launch_bounds__(256) void k_ns_update(AsmBt abt, IpmPtrs P, IpmDir C, double al, double be, double* __restrict__ e, double es, int64_t ldn) {
+    ASM_BARGS(abt, P, C, al, be, e, es, ldn);
+    int64_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < P.n) {
+        bool fr = P.ub[t] > P.lb[t];
+        P.p[t] += al * C.dp[t];
+        P.tL[t] = fr ? P.tL[t] + al * C.dp[t] : 1.0;
+        P.tU[t] = fr ? P.tU[t] - al * C.dp[t] : 1.0;
+        P.muL[t] += be * C.dmuL[t];
+        P.muU[t] += be * C.dmuU[t];
+    }
+    if (t < P.ns) {
+        P.s[t] += al * C.ds[t];
+        P.ts[t] += al * C.ds[t];
+        P.mus[t] += be * C.dmus[t];
+    }
+    if (t < P.M) {
+        bool ineq = P.rtype[t] != 0;
+        P.g[t] = ineq ? P.g[t] + al * C.dg[t] : 1.0;
+        double pi = P.pi[t] + be * C.dpi[t];
+        P.pi[t] = pi;
+        P.y[t] = ineq ? (double)P.rtype[t] * pi : P.y[t] + be * C.dy[t];
+    }
+    if (t < ldn) e[t] *= es;
+}
+// k_ns_neg (dpbar = -e) + clearing the accumulated residual measure of the iteration's reduced solves
+__global__ __launch_bounds__(256) void k_ns_neg_clear(AsmBt abt, const double* __restrict__ x, double* __restrict__ out, int64_t len, double* __restrict__ clear) {
+    ASM_BARGS(abt, x, out, len, clear);
+    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < len) out[j] = -x[j];
+    if (j == 0) *clear = 0.0;
+}
+
 // out[Eidx[e]] = tE[e]   (add != 0: += )
 __global__ __launch_bounds__(256) void k_ns_scatter_e(AsmBt abt, NsIdx X, const double* __restrict__ tE, double* __restrict__ out, int add) {
     ASM_BARGS(abt, X, tE, out, add);

@@ -538,6 +538,12 @@ def main():
     os.environ.setdefault("ASM_HIP_TIMING", "2" if args.kernel_breakdown else "1")
     if args.workload == "c5":
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # one hardware queue per concurrent scenario stream (ROCm default: 4)
+        import torch as _t
+        nvis = _t.cuda.device_count()
+        if nvis and world > nvis:
+            # rehearsal of N ranks on fewer GPUs: the ranks that share a device share its compute units - the all-resident panel kernels of
+            # all of them must fit it together (asm_create reads ASM_PANEL_WGS)
+            os.environ.setdefault("ASM_PANEL_WGS", str(max(16, 480 // ((world + nvis - 1) // nvis))))
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
