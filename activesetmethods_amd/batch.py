@@ -234,3 +234,46 @@ def solve_batch_lockstep(problems, parameters, n_slots, device=0, rank=0, world=
     if own:
         batch.close()
     return runs, reduce_stats(st, reduce_device), bst
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Dynamic assignment across ranks ("consider dynamic work assignment via a host-side counter"): instead of the
+# static block partition every rank claims chunks of scenario indices from one counter in the process group's key-value store.  It pays
+# when a rank has more scenarios than batch slots AND the iteration counts differ between ranks; with as many slots as scenarios per
+# GPU (the default shape: 64 / 64) every scenario of a rank runs concurrently and a rank's time is its slowest scenario - nothing to steal.
+# ------------------------------------------------------------------------------------------------------------------------------
+def claim_chunks(total, chunk, store=None, key="asm_batch_next"):
+    """Yield (lo, hi) ranges of [0, total) claimed from a counter shared by the ranks: `store.add(key, chunk)` is atomic across processes
+    (torch.distributed TCPStore / the default group's store).  Without a store: one local counter (single process)."""
+    total, chunk = int(total), max(1, int(chunk))
+    if store is None:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            from torch.distributed import distributed_c10d
+            store = distributed_c10d._get_default_store()
+    local = [0]
+    while True:
+        if store is not None:
+            hi = int(store.add(key, chunk))
+        else:
+            local[0] += chunk
+            hi = local[0]
+        lo = hi - chunk
+        if lo >= total:
+            return
+        yield lo, min(hi, total)
+
+
+def solve_batch_dynamic(problem_of, total, parameters, n_slots, batch, chunk=None, store=None, reduce_device=None):
+    """Lockstep batch with dynamic assignment: this rank claims chunks of `chunk` scenarios (default: n_slots) until the counter runs out;
+    `problem_of(s)` returns the Problem of scenario s.  Returns ({scenario: NativeRun}, reduced statistics)."""
+    chunk = int(chunk or n_slots)
+    t0 = time.perf_counter()
+    mine = {}
+    for lo, hi in claim_chunks(total, chunk, store):
+        prs = [problem_of(s) for s in range(lo, hi)]
+        runs = batch.slp_run(np.stack([p.g_L for p in prs]), np.stack([p.g_U for p in prs]), np.stack([p.x_L for p in prs]),
+                             np.stack([p.x_U for p in prs]), np.stack([p.x0 for p in prs]), parameters)
+        mine.update({lo + k: r for k, r in enumerate(runs)})
+    st = local_stats(list(mine.values()), time.perf_counter() - t0)
+    return mine, reduce_stats(st, reduce_device)

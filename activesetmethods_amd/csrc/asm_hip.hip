@@ -1245,7 +1245,23 @@ struct Solver {
     // buffers sized by the null-space dimension: right-hand-side blocks R, X (k x nEp), Gt = [Zt | GI'] (k x ldg), the k x k factor
     void ns_reserve(int k) {
         if (k <= h->ns_kcap) return;
-        if (h->ns_kcap > 0) throw HipError("null-space form: dimension grew beyond the reserved buffers");      // (caller falls back; see ns_setup)
+        if (h->ns_kcap > 0) {
+            // the null space grew beyond what the first LP of the form reserved (fewer fixed columns than then): the k-sized buffers are
+            // released and re-made; the carried basis goes with them
+            if (h->verbose) std::fprintf(stderr, "[asm] null-space form: dimension %d exceeds the reserved %d - buffers re-allocated\n", k, h->ns_kcap);
+            HIPCHK(hipStreamSynchronize(h->stream));
+            auto drop = [&](void* q) {
+                if (!q) return;
+                auto it = std::find(h->ns_bufs.begin(), h->ns_bufs.end(), q);
+                if (it != h->ns_bufs.end()) h->ns_bufs.erase(it);
+                (void)hipFree(q);
+            };
+            drop(h->d_nsR); drop(h->d_nsX); drop(h->d_nsG); drop(h->d_nsN0); drop(h->d_nsNp); drop(h->d_nsZT); drop(h->d_nsJ); drop(h->d_nsqi); drop(h->d_nsq);
+            for (FacBuf* f : {&h->ns_fN, &h->ns_fC}) { drop(f->S); drop(f->Linv); drop(f->Binv); drop(f->BinvT); *f = FacBuf(); }
+            h->d_nsR = h->d_nsX = h->d_nsG = h->d_nsN0 = h->d_nsNp = h->d_nsZT = h->d_nsq = nullptr;
+            h->d_nsJ = h->d_nsqi = nullptr;
+            h->ns_kcap = 0; h->ns_ccap = 0; h->ns_Zk = 0;
+        }
         const int cap = (int)round_up(k + k / 4 + 64, 64);
         h->d_nsR = ns_dalloc(h, (int64_t)cap * h->ns_nEp);
         h->d_nsX = ns_dalloc(h, (int64_t)cap * h->ns_nEp);
@@ -1380,7 +1396,6 @@ struct Solver {
         dev.use_main();
         const int64_t k = nF - (nE - dropped);
         if (k < 1 || (double)k > 1.5 * NS_MAX_RATIO * (double)lp.M + 8.0) return false;
-        if (k > h->ns_kcap && h->ns_kcap > 0) return false;
         ns_reserve((int)k);
         hipLaunchKernelGGL(k_transpose_dense, dim3((unsigned)((nE + 63) / 64), (unsigned)((nE + 63) / 64)), dim3(256), 0, h->stream, (const double*)h->ns_f0.S, h->ns_f0.ld,
                            (int64_t)nE, (int64_t)nE, h->d_nsLt, h->ns_f0.ld, (int64_t)(h->ns_f0.band > 0 ? h->ns_f0.band : nE));
@@ -3016,7 +3031,7 @@ void do_solve(asm_handle* h, double delta, int feasibility, double* p_out, doubl
             bool fixed = L.ub[j] <= L.lb[j];
             double mL = sol.as.bst[j] < 0 ? std::max(sol.z[j], 0.0) : 0.0;
             double mU = sol.as.bst[j] > 0 ? std::min(sol.z[j], 0.0) : 0.0;
-            if (fixed) mU = std::min(sol.z[j], 0.0);
+            if (fixed) { mU = std::min(sol.z[j], 0.0); mL = std::max(sol.z[j], 0.0); }      // a fixed column reports both halves of its reduced cost
             if (p_out[j] < h->v_ub[j] - h->x_k[j]) mU = 0.0;
             if (p_out[j] > h->v_lb[j] - h->x_k[j]) mL = 0.0;
             mult_x_L[j] = mL;

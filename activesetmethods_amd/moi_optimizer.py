@@ -232,7 +232,7 @@ class Optimizer:
         if c.kind == "SVL":                                               # upper-bound dual (:519)
             return min(float(self.z[j]), 0.0) if (self.bstate[j] > 0 or self.lb[j] == self.ub[j]) else 0.0
         if c.kind == "SVG" and c.value <= self.n:                          # lower-bound dual (:520)
-            return max(float(self.z[j]), 0.0) if self.bstate[j] < 0 else 0.0
+            return max(float(self.z[j]), 0.0) if (self.bstate[j] < 0 or self.lb[j] == self.ub[j]) else 0.0
         return 0.0
 
     def get_solver_name(self):

@@ -90,6 +90,7 @@ class AbstractSlpOptimizer:
         if self._fm is not None:                          # f, df, E come back; the Jacobian values stay in HBM
             self._ensure_optimizer(upload=False)
             self.f, self.df, self.E = self.optimizer.eval_functions(self.x)
+            self._x_dev = self.x.copy()                   # the iterate the device evaluator holds
             self._uploaded = True
             return
         self.f = pr.eval_f(self.x)
@@ -184,10 +185,9 @@ class AbstractSlpOptimizer:
     # slp.jl:79-115
     def compute_phi(self, x, alpha, p):
         pr = self.problem
-        if self._fm is not None:
-            # the device evaluator holds the iterate of the last eval_functions(): the merit is taken there, not at an arbitrary x
-            if x is not self.x:
-                raise ValueError("compute_phi with the device evaluator is defined at the current iterate self.x only")
+        if self._fm is not None and self._on_device(x):
+            # the device evaluator holds the iterate of the last eval_functions(): the merit is taken there; any other x goes through the
+            # host callbacks below (the reference's signature accepts any point)
             return self.optimizer.slp_merit(0, alpha, p, self.nu, self.p_slack, self.feasibility_restoration, self.prim_infeas)
         xp = x + alpha * p
         E = self.E if alpha == 0.0 else pr.eval_g(xp, np.zeros(pr.m))
@@ -200,6 +200,11 @@ class AbstractSlpOptimizer:
             return float(phi + self.nu @ np.maximum(0.0, np.maximum(lhs - pr.g_U, pr.g_L - lhs)))
         phi = pr.eval_f(xp)
         return float(phi + self.nu @ np.maximum(0.0, np.maximum(E - pr.g_U, pr.g_L - E)))
+
+    def _on_device(self, x):
+        """x is the iterate of the last device evaluation (same object or an equal copy)."""
+        xd = getattr(self, "_x_dev", None)
+        return xd is not None and (x is xd or np.array_equal(x, xd))
 
     # slp.jl:122-147
     def compute_derivative(self):
@@ -246,7 +251,7 @@ class SlpLS(AbstractSlpOptimizer):
 
     def compute_alpha(self):                                     # slp_line_search.jl:222-244
         o = self.options
-        if self._fm is not None:
+        if self._fm is not None and self._on_device(self.x):
             # the trial points are evaluated on the device, eight per read-back (same alpha as the loop below)
             self.alpha, _, self.ls_trials, ok = self.optimizer.slp_line_search(self.p, self.nu, self.p_slack, self.feasibility_restoration, self.prim_infeas,
                                                                                self.phi, self.directional_derivative, o.eta, o.tau, o.min_alpha)

@@ -100,7 +100,8 @@ def run_batch(args, rank, world, local_rank, dist, torch):
     par = A.Parameters(algorithm=args.algorithm, max_iter=args.max_iter, device_eval=True)
     # the scenario NLPs of this rank as host objects (function lists, bounds, start points) before the timed region: inputs are in place
     # when the clock starts, as for the other workloads; bounds uploads (per scenario) and every solve are inside it
-    problems = {s: acopf.function_model(acopf.scenario_case(base, s)).to_problem("case300-sized scenario %d" % s) for s in range(lo, hi)}
+    own = range(0, total) if args.dynamic else range(lo, hi)      # dynamic assignment: any rank may claim any scenario
+    problems = {s: acopf.function_model(acopf.scenario_case(base, s)).to_problem("case300-sized scenario %d" % s) for s in own}
     if args.batch_mode == "pool":
         return run_batch_pool(args, rank, world, local_rank, dist, torch, base, problems, total, per_gpu)
     n_slots = max(1, min(args.slots, hi - lo))
@@ -124,7 +125,12 @@ def run_batch(args, rank, world, local_rank, dist, torch):
     torch.cuda.synchronize()
     thr0 = _cpu_throttled_s()
     t0 = time.perf_counter()
-    runs, stats, st1 = batch.solve_batch_lockstep(plist, par, n_slots, rank=rank, world=world, reduce_device=args.reduce_device, batch=hb)
+    if args.dynamic:
+        # chunks of n_slots scenarios claimed from a counter in the process group's store (activesetmethods_amd.batch.claim_chunks)
+        mine, stats = batch.solve_batch_dynamic(problems.__getitem__, total, par, n_slots, hb, reduce_device=args.reduce_device)
+        runs, st1 = list(mine.values()), hb.stats()
+    else:
+        runs, stats, st1 = batch.solve_batch_lockstep(plist, par, n_slots, rank=rank, world=world, reduce_device=args.reduce_device, batch=hb)
     torch.cuda.synchronize()
     mine = time.perf_counter() - t0
     if dist is not None:
@@ -152,9 +158,9 @@ def run_batch(args, rank, world, local_rank, dist, torch):
                "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / per_gpu, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": WORKLOADS["c5"]["desc"], "algorithm": args.algorithm, "max_iter": args.max_iter,
-                          "scenarios_total": total,
-                          "parallelism": "scenarios block-partitioned, %d per GPU; per GPU ONE lockstep batch of %d slots on one stream and one host thread "
-                                         "(asm_batch_slp_run: launches of different scenarios merged, scenario index in the grid)" % (per_gpu, n_slots),
+                          "scenarios_total": total, "assignment": "dynamic (chunks claimed from a shared counter)" if args.dynamic else "static block partition",
+                          "parallelism": "scenarios block-partitioned, %d per GPU; per GPU ONE lockstep batch of %d slots in %d groups (one stream + one host thread each; "
+                                         "asm_batch_slp_run: launches of different scenarios merged, scenario index in the grid)" % (per_gpu, n_slots, hb.groups),
                           "inputs": "scenario NLPs built on the host before the timed region; bounds uploads and solves inside it"},
                "batch_stats": stats,
                "lockstep": {"slots": n_slots, "groups": hb.groups, "rounds": d["rounds"], "recorded_launches": d["ops"], "launches": d["launches"],
@@ -512,6 +518,7 @@ def main():
     ap.add_argument("--max-iter", type=int, default=100, help="workload c5: SLP iteration cap per scenario")
     ap.add_argument("--slots", type=int, default=64, help="workload c5: scenarios advancing in lockstep per GPU (slots of the asm_batch)")
     ap.add_argument("--groups", type=int, default=None, help="workload c5: groups of slots (one stream + one host thread each; library default: 2 from 16 slots on)")
+    ap.add_argument("--dynamic", action="store_true", help="workload c5: ranks claim chunks of scenarios from a shared counter instead of the static block partition")
     ap.add_argument("--batch-mode", default="lockstep", choices=["lockstep", "pool"], help="workload c5: lockstep batch (default) or the round-3 stream pool")
     ap.add_argument("--concurrency", type=int, default=2, help="workload c5, --batch-mode pool: scenarios in flight per GPU (one handle / HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -184,7 +184,8 @@ class QpModel:
             fixed = lp.ub <= lp.lb
             mult_x_L[:] = np.where(bst < 0, np.maximum(z, 0.0), 0.0)                 # :519-520
             mult_x_U[:] = np.where(bst > 0, np.minimum(z, 0.0), 0.0)
-            mult_x_U[:] = np.where(fixed, np.minimum(z, 0.0), mult_x_U)
+            mult_x_U[:] = np.where(fixed, np.minimum(z, 0.0), mult_x_U)            # a fixed column reports both halves of its reduced cost
+            mult_x_L[:] = np.where(fixed, np.maximum(z, 0.0), mult_x_L)
             mult_x_U[Xsol < d.v_ub - x_k] = 0.0                                      # :522-529
             mult_x_L[Xsol > d.v_lb - x_k] = 0.0
         # INFEASIBLE -> all zero (:532-536); other statuses: outputs undefined in the reference (:537-538)

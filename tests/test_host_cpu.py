@@ -226,3 +226,40 @@ def test_host_evaluator_equals_the_oracle_restatement(seed, sense):
         assert [tuple(t) for t in zip(pr.j_row, pr.j_col)] == j_str
         assert pr.eval_f(x) == fo and np.array_equal(pr.eval_grad_f(x, np.zeros(pr.n)), go)
         assert np.array_equal(pr.eval_g(x, np.zeros(pr.m)), Eo) and np.array_equal(pr.eval_jac_g(x, np.zeros(pr.nnz)), dEo)
+
+
+def _claim_worker(rank, world, port, q):
+    import time as _t
+    import torch.distributed as dist
+    from activesetmethods_amd.batch import claim_chunks
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    got = []
+    for lo, hi in claim_chunks(23, 4):
+        got.append((lo, hi))
+        _t.sleep(0.002 * (1 + 3 * rank))            # the ranks work at different speeds: the faster one claims more
+    dist.barrier()
+    q.put((rank, got))
+    dist.destroy_process_group()
+
+
+def test_dynamic_scenario_assignment_gloo_world2():
+    """`claim_chunks`: the ranks of a batch claim chunks of scenario indices from one counter in the process group's store (world 2, gloo):
+    every index is claimed exactly once, the last chunk is cut at the total, and the faster rank gets more."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_claim_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    spans = sorted(res[0] + res[1])
+    assert spans[0][0] == 0 and spans[-1][1] == 23 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert all(hi - lo == 4 for lo, hi in spans[:-1]) and spans[-1][1] - spans[-1][0] == 3
+    assert len(res[0]) >= len(res[1]) and len(res[0]) + len(res[1]) == 6
+    # without a process group: one local counter
+    from activesetmethods_amd.batch import claim_chunks
+    assert list(claim_chunks(10, 4)) == [(0, 4), (4, 8), (8, 10)]

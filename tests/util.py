@@ -69,7 +69,7 @@ def equality_rich_subproblem(seed, n=300, neq=260, nineq=160, per_row=4, delta=0
     c_lb[neq + k:] = act[neq + k:] - rng.uniform(0, 0.05, nineq - k)
     df = rng.standard_normal(n)
     return dict(n=n, m=m, j_row=rows + 1, j_col=cols + 1, dE=vals, df=df, f=0.1, E=E, x_k=x_k,
-                c_lb=c_lb, c_ub=c_ub, v_lb=v_lb, v_ub=v_ub, delta=delta, J=J)
+                c_lb=c_lb, c_ub=c_ub, v_lb=v_lb, v_ub=v_ub, delta=delta, J=J, p_star=p_star)
 
 
 def oracle_solve(sp, feasibility=False, qp=None):
@@ -170,7 +170,7 @@ def banded_subproblem(seed, n=400, m=600, neq=120, nrange=30, width=6, per_row=4
         c_ub[bad] = act[bad] - 5.0
     df = rng.standard_normal(n)
     return dict(n=n, m=m, j_row=rows + 1, j_col=cols + 1, dE=vals, df=df, f=0.1, E=E, x_k=x_k,
-                c_lb=c_lb, c_ub=c_ub, v_lb=v_lb, v_ub=v_ub, delta=delta, J=J)
+                c_lb=c_lb, c_ub=c_ub, v_lb=v_lb, v_ub=v_ub, delta=delta, J=J, p_star=p_star)
 
 
 def random_function_model(seed, n=30, sense="MIN_SENSE"):
