@@ -57,7 +57,8 @@ const int NS_MIN_E = 64;
 const double NS_MAX_RATIO = 0.3, NS_WARM_THR = 1e-6, NS_ZWARM_THR = 0.25, NS_BIG = 0.5e128, NS_RERR = 1e-6;
 const int NS_CMAX = 2;
 const int WARM_BACKOFF_MAX = 6;  // oracle/lp_solver.py: pause after consecutive failed warm attempts doubles up to 2^6 - 1 LPs
-const double EQP_RUNAWAY = 1e3;  // oracle/lp_solver.py: growth of the primal residual between two rounds of a bulk correction that ends the attempt
+const double EQP_RUNAWAY = 10.0, EQP_MAXCHG = 0.03;
+const int EQP_MINCHG = 32;  // oracle/lp_solver.py: growth of the primal residual between two rounds of a bulk correction that ends the attempt
 const int64_t RCM_MAX_PAIRS = 50000000;      // sum over the columns of (rows in the column)^2 beyond which no row order is computed
 const double IPM_ACCEPT = 1e-10;
 const int NS_MAX_SPLIT = 8;
@@ -2095,6 +2096,8 @@ struct Solver {
             if (pr_last >= 0.0 && pr > EQP_RUNAWAY * std::max(pr_last, TOL_P)) break;
             pr_last = pr;
             if (h->h_ascnt[AC_NCHG] == 0 || (have_prev && h->h_ascnt[AC_NDIFF] == 0)) break;
+            // oracle: EQP_MAXCHG - a correction that moves more than 3 % of all constraints at once has run away: the next solve is not made
+            if ((double)h->h_ascnt[AC_NCHG] > std::max((double)EQP_MINCHG, EQP_MAXCHG * (double)(lp.n + lp.M + lp.ns))) break;
             const int old_prev = prev;
             prev = cur; cur = nx; nx = old_prev;
             have_prev = true;

@@ -940,7 +940,8 @@ def _same(a, b):
 WARM_BACKOFF_MAX = 6  # consecutive failed warm attempts double the pause up to 2^6 - 1 LPs (measured on complete Line-Search runs: consecutive LPs differ in
                       # 200+ working-set entries at case1354pegase size, 50+ at case300 size, from the first to the last third - a retained set
                       # that never verifies should cost next to nothing; round 3 capped the pause at 7 LPs = one failed attempt of 2 ms every fourth LP)
-EQP_RUNAWAY = 1e3    # growth of the primal residual between two rounds of a bulk correction that ends the attempt
+EQP_RUNAWAY = 10.0   # growth of the primal residual between two rounds of a bulk correction that ends the attempt
+EQP_MAXCHG, EQP_MINCHG = 0.03, 32      # ... and the share of all constraints (rows + bounds + slacks; at least EQP_MINCHG) one correction may change
 
 
 def eqp_loop(lp, sets, p_ref, y_ref, rounds, stats, nsp=None):
@@ -966,13 +967,17 @@ def eqp_loop(lp, sets, p_ref, y_ref, rounds, stats, nsp=None):
             return True, p, s, y, sets
         if k == rounds:
             break
-        # a correction that made the primal residual EQP_RUNAWAY times worse has left the neighbourhood of the partition (observed: 2e3 ->
-        # 1.5e55 in one round on a restoration LP): further rounds only factor ever larger working sets - the attempt ends here
+        # a correction that made the primal residual EQP_RUNAWAY times worse has left the neighbourhood of the partition (observed on
+        # case1354pegase-sized LPs: 0.43 -> 7.7 -> 4.9e7, 2e3 -> 1.5e55): further rounds only factor ever larger working sets - the attempt ends
         if pr_last is not None and pr > EQP_RUNAWAY * max(pr_last, TOL_P):
             break
         pr_last = pr
         nxt, nchg = correct(lp, p, s, y, sets)
         if nchg == 0 or (prev is not None and _same(nxt, prev)):
+            break
+        # ... and so has a correction that moves more than EQP_MAXCHG of all constraints at once (a solve on such a set returns residuals of
+        # 1e7 ... 1e155): the next solve is not made
+        if nchg > max(EQP_MINCHG, EQP_MAXCHG * (lp.n + lp.M + lp.ns)):
             break
         prev, sets = sets, nxt
     return False, p, s, y, sets

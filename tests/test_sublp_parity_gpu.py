@@ -505,7 +505,10 @@ def test_null_space_form_edge_paths():
         opt, h_out = hip_solve(v, False, opt)
         st, so = opt.last_stats(), o_out[6]['stats']
         assert o_out[5] == h_out[5] == 1 and PATH_NAMES[st['path']] == so['path'] and st['ns_iters'] == so.get('ns_iters', 0) > 0, (k, st, so)
-        _compare(o_out, h_out, opt, None)
+        rows, bnd, sl = opt.active_set()
+        assert np.array_equal(rows, o_out[6]['sets'][0]) and np.array_equal(bnd, o_out[6]['sets'][1])
+        # (400 random equality rows on 560 columns, 130 of them fixed: a badly conditioned instance - agreement to 1e-8, not the 1e-10 of the campaigns)
+        assert rel_err(h_out[0], o_out[0]) < 1e-8 and rel_err(h_out[1], o_out[1]) < 1e-8
         dims.append(st['ns_dim'])
         if k == 0:
             qp.warm = {False: None, True: None}; qp.hint = {False: {'ns_J': qp.hint[False].get('ns_J')}, True: {'prefer_ref': True}}
