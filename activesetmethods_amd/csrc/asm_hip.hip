@@ -2248,6 +2248,7 @@ struct Solver {
         as_read();
         h->stats.kkt_pr = h->h_asscal[AS_PR];
         h->stats.kkt_du = h->h_asscal[AS_DU];
+        if (h->verbose) std::fprintf(stderr, "[asm] face polish: projection of the iterate on its partition pr %.3e du %.3e\n", h->h_asscal[AS_PR], h->h_asscal[AS_DU]);
         if (!(h->h_asscal[AS_PR] <= TOL_P && h->h_asscal[AS_DU] <= TOL_D)) return 0;
         dcopy(d_p0, A.p, n); dcopy(d_s0, A.s, ns); dcopy(d_y0, A.y, M); dcopy(d_act0, A.act, M); dcopy(d_z0, A.z, n);
         part_factor = true;            // the factor in d_S belongs to the partition: the first dual / primal round below re-use it
