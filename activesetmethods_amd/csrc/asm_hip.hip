@@ -56,6 +56,7 @@ const double RED_TAU = 100.0, RED_MIN_FRAC = 0.1;
 const int NS_MIN_E = 64;
 const double NS_MAX_RATIO = 0.3, NS_WARM_THR = 1e-6, NS_ZWARM_THR = 0.25, NS_BIG = 0.5e128, NS_RERR = 1e-6;
 const int NS_CMAX = 2;
+const double IPM_DEGRADE = 10.0;  // oracle/lp_solver.py: a stage that ends this much worse than the best stage so far is undone (best-iterate safeguard)
 const int WARM_BACKOFF_MAX = 6;  // oracle/lp_solver.py: pause after consecutive failed warm attempts doubles up to 2^6 - 1 LPs
 const double EQP_RUNAWAY = 10.0, EQP_MAXCHG = 0.03;
 const int EQP_MINCHG = 32;  // oracle/lp_solver.py: growth of the primal residual between two rounds of a bulk correction that ends the attempt
@@ -275,6 +276,7 @@ struct asm_handle {
     int *d_nsqi = nullptr;          // sel | bpos | rpos | cnt
     double *d_nsq = nullptr;        // Csel | d, u, lam, v, w | pbar, tbar, u0, qh
     std::vector<void*> ns_bufs;     // everything above, for release
+    double* d_ipm_snap = nullptr;   // best-iterate safeguard: copy of the iterate at the end of the best interior-point stage so far
     double* d_ipm = nullptr;        // arena of the device-resident interior-point state
     int* d_ipm_i = nullptr;
     double* d_as = nullptr;         // arena of the device-resident active-set machinery (asm_as_kernels.hip.h)
@@ -2328,6 +2330,7 @@ struct Solver {
 
     // oracle: solve_scaled
     double t_warm = 0, t_ipm = 0, t_polish = 0;
+    bool snap_e = false;      // the snapshot of the best iterate holds the null-space form's component e
     int solve_scaled(const ActiveSet* warm, SolveHint& hint) {
         int st = solve_scaled_impl(warm, hint);
         if (h->verbose) std::fprintf(stderr, "[asm] phases: warm %.2f ms, ipm %.2f ms (%d its), polish %.2f ms, path %d\n", t_warm, t_ipm, ip.iters, t_polish, h->stats.path);
@@ -2382,6 +2385,8 @@ struct Solver {
         const double tols[3] = {1e-9, 1e-10, 1e-12};      // oracle: IPM_STAGES
         const int more[3] = {IPM_MAXIT, 6, 6};
         bool have_sets = false;
+        double best_m = INF;
+        bool have_snap = false;
         for (int stage = 0; stage < 3; ++stage) {
             double t0 = now_ms();
             btag = 100 + 100 * stage;
@@ -2393,6 +2398,23 @@ struct Solver {
             h->stats.ns_iters = ip.ns_iters;
             h->stats.ipm_pinf = ip.pinf; h->stats.ipm_dinf = ip.dinf; h->stats.ipm_gap = ip.gap;
             if (st == ASM_INFEASIBLE) { h->stats.path = 6; return ASM_INFEASIBLE; }
+            {
+                // best-iterate safeguard (oracle: solve_scaled): a stage that ends IPM_DEGRADE times worse than the best one so far is undone -
+                // the best iterate comes back, the final attempts run on it and on the partition identified from it
+                const double m_now = std::max(ip.pinf, std::max(ip.dinf, ip.gap));
+                double* e_ns = (ip.ns_ok && ip.ns_e_ready) ? nsv(14) : nullptr;
+                if (have_snap && have_sets && m_now > IPM_DEGRADE * best_m) {
+                    hipLaunchKernelGGL(k_ipm_snapshot, dim3(grid_all()), dim3(256), 0, h->stream, P, h->d_ipm_snap, snap_e ? nsv(14) : (double*)nullptr, h->ldn, h->Mp, h->nsp, 1);
+                    ipm_measures();
+                    if (h->verbose) std::fprintf(stderr, "[asm] stage %d ended %.1e against %.1e before: best iterate restored (pinf %.3e dinf %.3e gap %.3e)\n", stage, m_now, best_m, ip.pinf, ip.dinf, ip.gap);
+                    h->stats.ipm_pinf = ip.pinf; h->stats.ipm_dinf = ip.dinf; h->stats.ipm_gap = ip.gap;
+                    break;
+                }
+                if (m_now < best_m) {
+                    hipLaunchKernelGGL(k_ipm_snapshot, dim3(grid_all()), dim3(256), 0, h->stream, P, h->d_ipm_snap, e_ns, h->ldn, h->Mp, h->nsp, 0);
+                    best_m = m_now; have_snap = true; snap_e = e_ns != nullptr;
+                }
+            }
             if (st == ASM_OTHER && stage == 0) {
                 // the IPM is only the identifier: a jammed / slow run that is already close is still handed to
                 // the active-set solve, whose LP optimality test decides (oracle: solve_scaled)
@@ -2503,6 +2525,7 @@ void free_device(asm_handle* h) {
     F(h->d_dE); F(h->d_J); F(h->d_Ah); F(h->d_S); F(h->d_c); F(h->d_rho); F(h->d_theta); F(h->d_diag); F(h->d_diag0);
     F(h->d_vecN); F(h->d_vecM); F(h->d_vecM2); F(h->d_partial); F(h->d_idx); F(h->d_Linv); F(h->d_Binv); F(h->d_wpart); F(h->d_BinvT); F(h->d_wt);
     h->d_Binv = h->d_wpart = h->d_BinvT = h->d_wt = nullptr; F(h->d_ipm); F(h->d_ipm_i); F(h->d_nz);
+    F(h->d_ipm_snap); h->d_ipm_snap = nullptr;
     h->d_nz = nullptr; h->nz_valid = false; h->nz_frac_cache[0] = h->nz_frac_cache[1] = -1.0;
     F(h->d_idxI); F(h->d_rdI); F(h->d_rce); F(h->d_rze); F(h->d_sdiag);
     F(h->d_redpart); F(h->d_redcnt); h->d_redpart = nullptr; h->d_redcnt = nullptr;
@@ -2715,6 +2738,7 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
         int64_t nd = 24 * h->ldn + 23 * h->Mp + 16 * h->nsp + 64;
         dmalloc(&h->d_ipm, nd);
         HIPCHK(hipMemsetAsync(h->d_ipm, 0, nd * sizeof(double), h->stream));
+        dmalloc(&h->d_ipm_snap, 6 * h->ldn + 3 * h->Mp + 3 * h->nsp);
         dmalloc(&h->d_ipm_i, 3 * h->Mp + h->nsp);
         std::vector<int> iv(3 * h->Mp + h->nsp, -1);
         for (int64_t i = 0; i < h->M; ++i) iv[i] = h->rtype[i];

@@ -487,6 +487,34 @@ __global__ __launch_bounds__(256) void k_ipm_update(AsmBt abt, IpmPtrs P, IpmDir
     }
 }
 
+// best-iterate safeguard (oracle: IPM.snapshot / restore): the iterate - p, tL, tU, muL, muU | g, y, pi | s, ts, mus | e (null-space form) -
+// saved to (dir = 0) or brought back from (dir = 1) `snap` (6 ldn + 3 Mp + 3 nsp doubles)
+__global__ __launch_bounds__(256) void k_ipm_snapshot(AsmBt abt, IpmPtrs P, double* __restrict__ snap, double* __restrict__ e, int64_t ldn, int64_t Mp, int64_t nsp, int dir) {
+    ASM_BARGS(abt, P, snap, e, ldn, Mp, nsp, dir);
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double* sn = snap;
+    double* vn[5] = {P.p, P.tL, P.tU, P.muL, P.muU};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        if (t < P.n) { if (dir) vn[k][t] = sn[t]; else sn[t] = vn[k][t]; }
+        sn += ldn;
+    }
+    if (e) { if (t < ldn) { if (dir) e[t] = sn[t]; else sn[t] = e[t]; } }
+    sn += ldn;
+    double* vm[3] = {P.g, P.y, P.pi};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (t < P.M) { if (dir) vm[k][t] = sn[t]; else sn[t] = vm[k][t]; }
+        sn += Mp;
+    }
+    double* vs[3] = {P.s, P.ts, P.mus};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (t < P.ns) { if (dir) vs[k][t] = sn[t]; else sn[t] = vs[k][t]; }
+        sn += nsp;
+    }
+}
+
 // starting point (oracle: IPM.__init__); act = Ah p0 must already be in P.act
 __global__ __launch_bounds__(256) void k_ipm_init_p(AsmBt abt, IpmPtrs P) {
     ASM_BARGS(abt, P);

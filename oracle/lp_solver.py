@@ -453,6 +453,19 @@ class IPM:
     def ns_live(self):
         return bool(self.ns_ok and not self.ns_off and self.ns is not None and self.ns.valid)
 
+    _SNAP = ('p', 's', 'g', 'y', 'tL', 'tU', 'muL', 'muU', 'ts', 'mus', 'pi')
+
+    def snapshot(self):
+        """The iterate (primal, slacks of the complementarity pairs, multipliers; in null-space form the split-off component e)."""
+        snap = {k: getattr(self, k).copy() for k in self._SNAP}
+        snap['ns_e'] = None if self.ns_e is None else self.ns_e.copy()
+        return snap
+
+    def restore(self, snap):
+        for k in self._SNAP:
+            setattr(self, k, snap[k].copy())
+        self.ns_e = None if snap['ns_e'] is None else snap['ns_e'].copy()
+
     def ns_finish_y(self):
         """Least-squares multipliers of the equality rows for the current iterate (null-space form carries them as 0)."""
         nsp = self.ns
@@ -937,6 +950,7 @@ def _same(a, b):
     return all(np.array_equal(x, y) for x, y in zip(a, b))
 
 
+IPM_DEGRADE = 10.0    # a stage that ends this much worse (largest of the three measures) than the best stage so far is undone (best-iterate safeguard)
 WARM_BACKOFF_MAX = 6  # consecutive failed warm attempts double the pause up to 2^6 - 1 LPs (measured on complete Line-Search runs: consecutive LPs differ in
                       # 200+ working-set entries at case1354pegase size, 50+ at case300 size, from the first to the last third - a retained set
                       # that never verifies should cost next to nothing; round 3 capped the pause at 7 LPs = one failed attempt of 2 ms every fourth LP)
@@ -1401,6 +1415,7 @@ def solve_scaled(lp, warm=None, stats=None, hint=None):
     if nsp is None:
         ip.ns_ok = False
     sets0 = None
+    best_m, snap = np.inf, None
     for stage, (tol, more) in enumerate(IPM_STAGES):
         st = ip.run(tol, more)
         stats['nfact'] += ip.iters - stats['ipm_iters']
@@ -1411,6 +1426,19 @@ def solve_scaled(lp, warm=None, stats=None, hint=None):
         if st == INFEASIBLE:
             stats['path'] = 'ipm-infeasible'
             return INFEASIBLE, None, None, None, None
+        # best-iterate safeguard: late iterations can DEGRADE the iterate once the complementarity has underflowed (observed on
+        # case1354pegase-sized restoration LPs: primal residual 1e-10 -> 7e-7 over a stage, each later identification worse than the one
+        # before).  A stage that ends IPM_DEGRADE times worse than the best stage so far is undone: the best iterate comes back and the
+        # final attempts (corrections from its projection) run on it and on the partition identified from it.
+        m_now = max(ip.log[-1][1:])
+        if snap is not None and sets0 is not None and m_now > IPM_DEGRADE * best_m:
+            ip.restore(snap)
+            pinf, dinf, gap = ip.measures()
+            ip.log.append((ip.iters, pinf, dinf, gap))
+            stats['restored'] = stats.get('restored', 0) + 1
+            break
+        if m_now < best_m:
+            best_m, snap = m_now, ip.snapshot()
         if st == OTHER and stage == 0:
             # the IPM is only the identifier: a jammed / slow run that is already close is still handed to the
             # active-set solve, whose LP optimality test decides
