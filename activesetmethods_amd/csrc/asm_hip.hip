@@ -2385,7 +2385,7 @@ struct Solver {
         const double tols[3] = {1e-9, 1e-10, 1e-12};      // oracle: IPM_STAGES
         const int more[3] = {IPM_MAXIT, 6, 6};
         bool have_sets = false;
-        double best_m = INF;
+        double best_m = INF, m_last = INF;
         bool have_snap = false;
         for (int stage = 0; stage < 3; ++stage) {
             double t0 = now_ms();
@@ -2399,20 +2399,12 @@ struct Solver {
             h->stats.ipm_pinf = ip.pinf; h->stats.ipm_dinf = ip.dinf; h->stats.ipm_gap = ip.gap;
             if (st == ASM_INFEASIBLE) { h->stats.path = 6; return ASM_INFEASIBLE; }
             {
-                // best-iterate safeguard (oracle: solve_scaled): a stage that ends IPM_DEGRADE times worse than the best one so far is undone -
-                // the best iterate comes back, the final attempts run on it and on the partition identified from it
-                const double m_now = std::max(ip.pinf, std::max(ip.dinf, ip.gap));
+                // best-iterate safeguard, first half (oracle: solve_scaled): the iterate at the end of the best stage so far is kept
+                m_last = std::max(ip.pinf, std::max(ip.dinf, ip.gap));
                 double* e_ns = (ip.ns_ok && ip.ns_e_ready) ? nsv(14) : nullptr;
-                if (have_snap && have_sets && m_now > IPM_DEGRADE * best_m) {
-                    hipLaunchKernelGGL(k_ipm_snapshot, dim3(grid_all()), dim3(256), 0, h->stream, P, h->d_ipm_snap, snap_e ? nsv(14) : (double*)nullptr, h->ldn, h->Mp, h->nsp, 1);
-                    ipm_measures();
-                    if (h->verbose) std::fprintf(stderr, "[asm] stage %d ended %.1e against %.1e before: best iterate restored (pinf %.3e dinf %.3e gap %.3e)\n", stage, m_now, best_m, ip.pinf, ip.dinf, ip.gap);
-                    h->stats.ipm_pinf = ip.pinf; h->stats.ipm_dinf = ip.dinf; h->stats.ipm_gap = ip.gap;
-                    break;
-                }
-                if (m_now < best_m) {
+                if (m_last < best_m) {
                     hipLaunchKernelGGL(k_ipm_snapshot, dim3(grid_all()), dim3(256), 0, h->stream, P, h->d_ipm_snap, e_ns, h->ldn, h->Mp, h->nsp, 0);
-                    best_m = m_now; have_snap = true; snap_e = e_ns != nullptr;
+                    best_m = m_last; have_snap = true; snap_e = e_ns != nullptr;
                 }
             }
             if (st == ASM_OTHER && stage == 0) {
@@ -2457,6 +2449,15 @@ struct Solver {
         }
         btag = 400;
         asmb::barrier(btag);
+        if (have_snap && have_sets && m_last > IPM_DEGRADE * best_m) {
+            // best-iterate safeguard, second half (oracle: solve_scaled): no stage ended in a successful polish and the last one ended IPM_DEGRADE
+            // times worse than the best - the best iterate comes back, the final attempts run on it and on the partition identified from it
+            hipLaunchKernelGGL(k_ipm_snapshot, dim3(grid_all()), dim3(256), 0, h->stream, P, h->d_ipm_snap, snap_e ? nsv(14) : (double*)nullptr, h->ldn, h->Mp, h->nsp, 1);
+            ipm_measures();
+            if (h->verbose) std::fprintf(stderr, "[asm] last stage ended %.1e against %.1e at best: best iterate restored (pinf %.3e dinf %.3e gap %.3e)\n", m_last, best_m, ip.pinf, ip.dinf, ip.gap);
+            h->stats.ipm_pinf = ip.pinf; h->stats.ipm_dinf = ip.dinf; h->stats.ipm_gap = ip.gap;
+            identify_dev(3);
+        }
         if (have_sets) {
             double t1 = now_ms();
             // non-unique optimum: canonical (least-norm) pair of the optimal faces the partition describes (oracle: face_polish)

@@ -1426,17 +1426,8 @@ def solve_scaled(lp, warm=None, stats=None, hint=None):
         if st == INFEASIBLE:
             stats['path'] = 'ipm-infeasible'
             return INFEASIBLE, None, None, None, None
-        # best-iterate safeguard: late iterations can DEGRADE the iterate once the complementarity has underflowed (observed on
-        # case1354pegase-sized restoration LPs: primal residual 1e-10 -> 7e-7 over a stage, each later identification worse than the one
-        # before).  A stage that ends IPM_DEGRADE times worse than the best stage so far is undone: the best iterate comes back and the
-        # final attempts (corrections from its projection) run on it and on the partition identified from it.
+        # best-iterate safeguard, first half: remember the iterate at the end of the best stage so far
         m_now = max(ip.log[-1][1:])
-        if snap is not None and sets0 is not None and m_now > IPM_DEGRADE * best_m:
-            ip.restore(snap)
-            pinf, dinf, gap = ip.measures()
-            ip.log.append((ip.iters, pinf, dinf, gap))
-            stats['restored'] = stats.get('restored', 0) + 1
-            break
         if m_now < best_m:
             best_m, snap = m_now, ip.snapshot()
         if st == OTHER and stage == 0:
@@ -1478,6 +1469,18 @@ def solve_scaled(lp, warm=None, stats=None, hint=None):
         if ok:
             stats['path'] = 'ipm%d+ln' % stage
             return OPTIMAL, p, s, y, sets
+    # best-iterate safeguard, second half: late iterations can DEGRADE the iterate once the complementarity has underflowed (observed on
+    # case1354pegase-sized restoration LPs: primal residual 1e-10 -> 7e-7 over a stage, each later identification worse than the one
+    # before).  When no stage ended in a successful polish and the last one ended IPM_DEGRADE times worse than the best, the best iterate
+    # comes back: the final attempts (corrections from its projection) run on it and on the partition identified from it.  The stages
+    # themselves are never cut short (a first version that stopped at the first degraded stage lost LP 60 of the case1354pegase-sized run,
+    # whose third stage polishes although its second ended 27x worse than its first).
+    if snap is not None and sets0 is not None and max(ip.log[-1][1:]) > IPM_DEGRADE * best_m:
+        ip.restore(snap)
+        pinf, dinf, gap = ip.measures()
+        ip.log.append((ip.iters, pinf, dinf, gap))
+        stats['restored'] = stats.get('restored', 0) + 1
+        sets0 = identify(lp, ip)
     if sets0 is not None:
         # non-unique optimum: canonical (least-norm) pair of the optimal faces the partition describes
         how, p, s, y, sets = (None,) * 5 if prefer_ref else face_polish(lp, sets0, np.clip(ip.p, lp.lb, lp.ub), ip.y, stats)
