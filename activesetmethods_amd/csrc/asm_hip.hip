@@ -791,13 +791,20 @@ struct Dev {
     }
     // want_inverse = false: the caller only solves against the factor and the factor is a "small" one (one-workgroup solves): the
     // explicit inverses of the wide blocks are not built
+    bool panel_inv_now = false;      // the panel launches of the factorisation in progress also make the explicit inverse
     void chol(int Ms, double thr = 1e-14, bool want_inverse = true) {
         if (Ms <= 0) return;
         // a banded factor (band b) costs about Ms (b + 64)^2 flops and touches Ms (b + 64) entries, not Ms^3 / 3 and Ms^2 / 2
         const double bw = fband > 0 ? (double)std::min<int64_t>(Ms, (int64_t)fband + 64) : (double)Ms;
         int id = begin(ASM_K_CHOL, fband > 0 ? (double)Ms * bw * bw : (double)Ms * Ms * Ms / 3.0, 8.0 * 1.5 * Ms * bw);
+        const bool skip_inv = !want_inverse && fsmall && Ms <= ASM_SMALL_USE;
+        // a factor of ONE wide block gets its explicit inverse inside the panel launches (helper workgroups of k_chol_panel_inv)
+        static const bool inv_env = [] { const char* v = std::getenv("ASM_PANEL_INV"); return !(v && v[0] == '0'); }();
+        panel_inv_now = !skip_inv && inv_env && h->fused_panel && Ms <= fwb && fband == 0 && fBinv && fBinvT && ASM_PNL_WT * (ASM_PNL_NS + 1) <= h->panel_wgs;
+        const bool inv_done = panel_inv_now;
         chol_launches(Ms, thr);
-        if (!want_inverse && fsmall && Ms <= ASM_SMALL_USE) {
+        panel_inv_now = false;
+        if (skip_inv || inv_done) {
             end(id);
             h->stats.nfact += 1;
             return;
@@ -837,7 +844,13 @@ struct Dev {
                 int pid = begin(ASM_K_PANEL_KERNEL, pfl, 8.0 * 2.0 * (double)(Mi - I0) * (double)(std::min(I1, Mi) - I0), cur);
                 struct PEnd { Dev* d; int id; ~PEnd() { d->end(id); } } pend_{this, pid};
                 // beside the trailing update the register-capped build must be used (its wavefronts have to fit into freed update slots)
-                if (beside_updates)
+                if (panel_inv_now && !beside_updates) {
+                    // one wide block: its explicit inverse is made inside the launch by helper workgroups, one per 64 x 64 tile of the block
+                    // rows this inner panel finishes (k_chol_panel_inv) - no k_trtri_* launches afterwards
+                    const int nst = (std::min(I1, Ms) - I0 + ASM_NB - 1) / ASM_NB, T = (Ms + ASM_NB - 1) / ASM_NB;
+                    asmb::launch_resident(k_chol_panel_inv, dim3((unsigned)(G + nst * T)), dim3(256), 0, cur, fS, fld, I0, std::min(I1, Ms), Mi, (const double*)h->d_diag0, thr,
+                                       fLinv, h->d_pflags, h->d_ptmo, h->panel_epoch, fBinv, fBinvT, fwb, G);
+                } else if (beside_updates)
                     asmb::launch_resident(k_chol_panel, dim3((unsigned)G), dim3(256), 0, cur, fS, fld, I0, std::min(I1, Ms), Mi, (const double*)h->d_diag0, thr,
                                        fLinv, h->d_pflags, h->d_ptmo, h->panel_epoch);
                 else
@@ -2692,10 +2705,10 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     dmalloc(&h->d_partial, (int64_t)ASM_TMAXCHUNKS * h->ldn);
     dmalloc(&h->d_idx, h->Mp);
     dmalloc(&h->d_Linv, (h->Mp / ASM_NB + 1) * ASM_NB * ASM_NB);
-    dmalloc(&h->d_pflags, ASM_PNL_NS * (ASM_PNL_NS + 1));
+    dmalloc(&h->d_pflags, ASM_PNL_FLAGS);
     dmalloc(&h->d_ptmo, 4);
     HIPCHK(hipMemsetAsync(h->d_ptmo, 0, 4 * sizeof(unsigned), h->stream));
-    HIPCHK(hipMemsetAsync(h->d_pflags, 0, ASM_PNL_NS * (ASM_PNL_NS + 1) * sizeof(unsigned), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_pflags, 0, ASM_PNL_FLAGS * sizeof(unsigned), h->stream));
     h->wb = h->M > 1536 ? 1024 : 512;      // wide-block width of the triangular solves (k_wtrsv_*<WB>)
     if (h->M >= RED_MIN_M) {
         dmalloc(&h->d_idxI, h->Mp); dmalloc(&h->d_rdI, h->Mp); dmalloc(&h->d_rce, h->Mp); dmalloc(&h->d_rze, h->Mp); dmalloc(&h->d_sdiag, h->Mp);

@@ -912,13 +912,12 @@ __global__ __launch_bounds__(256) void k_pnl_wait_probe(AsmBt abt, unsigned* fla
 // M = 18637: first panel launch 5.2 ms instead of 1.0 ms).
 __device__ __forceinline__ void chol_panel_body(double* __restrict__ sm, double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms,
                                                 const double* __restrict__ diag0, double thr, double* __restrict__ Linv,
-                                                unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch) {
+                                                unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch, const int G, const int wg) {
     double* B0 = sm;                                  // the tile being solved, then X
     double* B1 = sm + ASM_NB * ASM_XP;                // block inverse, then the right operand X(tj)
     potrf_T_t* Tt = reinterpret_cast<potrf_T_t*>(sm + 2 * ASM_NB * ASM_XP);
     double* d0 = sm + 2 * ASM_NB * ASM_XP + 4 * 16 * 17;
     double* dinv = d0 + ASM_NB;
-    const int G = gridDim.x, wg = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nsteps = (I1 - I0 + ASM_NB - 1) / ASM_NB;
     const int nrt = (Ms - I0 + ASM_NB - 1) / ASM_NB;
@@ -1071,12 +1070,150 @@ __device__ __forceinline__ void chol_panel_body(double* __restrict__ sm, double*
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chol_panel(AsmBt abt, double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms, const double* __restrict__ diag0, double thr, double* __restrict__ Linv, unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch) {
     ASM_BARGS(abt, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch);
     __shared__ __attribute__((aligned(16))) double sm[ASM_PNL_LDS];
-    chol_panel_body(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch);
+    chol_panel_body(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, (int)gridDim.x, (int)blockIdx.x);
 }
 __global__ __launch_bounds__(256) void k_chol_panel_solo(AsmBt abt, double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms, const double* __restrict__ diag0, double thr, double* __restrict__ Linv, unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch) {
     ASM_BARGS(abt, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch);
     __shared__ __attribute__((aligned(16))) double sm[ASM_PNL_LDS];
-    chol_panel_body(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch);
+    chol_panel_body(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, (int)gridDim.x, (int)blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The explicit inverse of a factor that is ONE wide block (Ms <= wb), made INSIDE the panel launch by helper workgroups instead of
+// 2 log2(wb / 64) + 2 dependent launches afterwards (k_trtri_*): block row r of W = L^-1 follows from the rows above it,
+//     W[r][r] = Linv_r,      W[r][j] = -Linv_r * sum_{i=j}^{r-1} L[r][i] W[i][j]      (j < r),
+// and everything on the right is final soon after the factorisation reaches block row r: L[r][i] once step i has solved row tile r
+// (panel-tile flag), W[i][j] once its own helper is done (flags[FW + ...]), Linv_r with the diagonal flag.  Helper hx owns tile
+// (r, j) = (s0 + hx / T, hx % T): it accumulates the sum as its terms arrive, so after the last diagonal block only two 64^3
+// products remain.  It writes X(r, j) and the transposed copy XT(j, r) (zeros above the diagonal, as k_trtri_init leaves them);
+// rows past the end of the matrix: identity on the diagonal, zero elsewhere (Linv_r carries the identity there, the rows of L
+// read as zero).  Helpers come after the main workgroups in the grid and only wait for workgroups with smaller indices.
+#define ASM_PNL_FW (ASM_PNL_NS * (ASM_PNL_NS + 1))
+#define ASM_PNL_WT 16          // most 64-blocks of one wide block (wb <= 1024)
+#define ASM_PNL_FLAGS (ASM_PNL_FW + ASM_PNL_NS * ASM_PNL_WT)
+__device__ __forceinline__ void pnl_wait_helper(unsigned* flag, unsigned epoch, unsigned* tmo) {
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+            __builtin_amdgcn_s_sleep(24);          // helpers are not on the critical path of the factorisation: they poll rarely
+            ++spins;
+            if (spins > (1u << 20) || ((spins & 63u) == 0 && __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void chol_inv_tile(double* __restrict__ sm, const double* __restrict__ S, int64_t ldS, int I0, int Ms, const double* __restrict__ Linv,
+                                              unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch, double* __restrict__ X, double* __restrict__ XT,
+                                              int wb, int hx) {
+    double* Pa = sm;                                  // left operand P[r][k]; afterwards the finished tile
+    double* Qt = sm + ASM_NB * ASM_XP;                // right operand transposed Qt[c][k] = Q[k][c]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int T = (Ms + ASM_NB - 1) / ASM_NB, s0 = I0 / ASM_NB;
+    const int r = s0 + hx / T, j = hx % T, rl = r - s0;
+    v4f64 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    if (j < r) {
+        for (int i = j; i <= r; ++i) {
+            // terms i < r: P = L[r][i], Q = W[i][j];   the closing product i == r: P = -Linv_r, Q = the sum (read back from the accumulators)
+            const double* Qsrc = nullptr;             // 64 x 64 row-major block (Linv) or rows of pitch wb (X)
+            int64_t qld = ASM_NB;
+            if (i < r) {
+                if (i >= s0) pnl_wait_helper(flags + ASM_PNL_NS + ASM_PNL_NS * (i - s0) + rl, epoch, tmo);      // L[r][i]: step i - s0 has solved row tile rl
+                if (i == j) {
+                    if (j >= s0) pnl_wait_helper(flags + (j - s0), epoch, tmo);
+                    Qsrc = Linv + (int64_t)j * ASM_NB * ASM_NB;
+                } else {
+                    if (i >= s0) pnl_wait_helper(flags + ASM_PNL_FW + ASM_PNL_WT * (i - s0) + j, epoch, tmo);
+                    Qsrc = X + (int64_t)i * ASM_NB * wb + (int64_t)j * ASM_NB;
+                    qld = wb;
+                }
+            } else {
+                pnl_wait_helper(flags + rl, epoch, tmo);
+            }
+            double pv[ASM_NB * ASM_NB / 256], qv[ASM_NB * ASM_NB / 256];
+#pragma unroll
+            for (int it = 0; it < ASM_NB * ASM_NB / 256; ++it) {
+                const int e = tid + 256 * it, rr = e >> 6, c = e & 63;
+                if (i < r) {
+                    const int gi = r * ASM_NB + rr;
+                    const double v = S[(int64_t)min(gi, Ms - 1) * ldS + i * ASM_NB + c];
+                    pv[it] = gi < Ms ? v : 0.0;
+                    qv[it] = Qsrc[(int64_t)rr * qld + c];
+                } else {
+                    pv[it] = -Linv[(int64_t)r * ASM_NB * ASM_NB + e];
+                    qv[it] = 0.0;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                          // the previous product has consumed the LDS images
+            if (i == r) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = w * 16 + (lane >> 4) + 4 * q, col = t * 16 + (lane & 15);
+                        Qt[col * ASM_XP + row] = acc[t][q];
+                        acc[t][q] = 0.0;
+                    }
+            }
+#pragma unroll
+            for (int it = 0; it < ASM_NB * ASM_NB / 256; ++it) {
+                const int e = tid + 256 * it, rr = e >> 6, c = e & 63;
+                Pa[rr * ASM_XP + c] = pv[it];
+                if (i < r) Qt[c * ASM_XP + rr] = qv[it];
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int kk = 0; kk < ASM_NB; kk += 4) {
+                double af = Pa[(w * 16 + (lane & 15)) * ASM_XP + kk + (lane >> 4)];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    double bf = Qt[(t * 16 + (lane & 15)) * ASM_XP + kk + (lane >> 4)];
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Pa[(w * 16 + (lane >> 4) + 4 * q) * ASM_XP + t * 16 + (lane & 15)] = acc[t][q];
+    } else if (j == r) {
+        pnl_wait_helper(flags + rl, epoch, tmo);
+#pragma unroll
+        for (int it = 0; it < ASM_NB * ASM_NB / 256; ++it) {
+            const int e = tid + 256 * it;
+            Pa[(e >> 6) * ASM_XP + (e & 63)] = Linv[(int64_t)r * ASM_NB * ASM_NB + e];
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < ASM_NB * ASM_NB / 256; ++it) {
+            const int e = tid + 256 * it;
+            Pa[(e >> 6) * ASM_XP + (e & 63)] = 0.0;
+        }
+    }
+    __syncthreads();
+    // the tile and its transpose, both with coalesced rows; write-through (read by the helpers of later block rows)
+#pragma unroll
+    for (int it = 0; it < ASM_NB * ASM_NB / 256; ++it) {
+        const int e = tid + 256 * it, rr = e >> 6, c = e & 63;
+        __hip_atomic_store(X + (int64_t)(r * ASM_NB + rr) * wb + j * ASM_NB + c, Pa[rr * ASM_XP + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        XT[(int64_t)(j * ASM_NB + rr) * wb + r * ASM_NB + c] = Pa[c * ASM_XP + rr];
+    }
+    if (j < r) pnl_publish(flags + ASM_PNL_FW + ASM_PNL_WT * rl + j, epoch);
+}
+// k_chol_panel_inv: k_chol_panel_solo plus the helper workgroups of the inverse (grid = G + steps * T)
+__global__ __launch_bounds__(256) void k_chol_panel_inv(AsmBt abt, double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms, const double* __restrict__ diag0, double thr, double* __restrict__ Linv, unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch, double* __restrict__ Binv, double* __restrict__ BinvT, int wb, int G) {
+    ASM_BARGS(abt, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, Binv, BinvT, wb, G);
+    __shared__ __attribute__((aligned(16))) double sm[ASM_PNL_LDS];
+    if ((int)blockIdx.x < G) chol_panel_body(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, G, (int)blockIdx.x);
+    else chol_inv_tile(sm, S, ldS, I0, Ms, Linv, flags, tmo, epoch, Binv, BinvT, wb, (int)blockIdx.x - G);
 }
 
 // out[i] = || A[i, :] ||_2   (one wavefront per row) - KT_residuals / compute_nu! (common.jl:41, slp.jl:58)
