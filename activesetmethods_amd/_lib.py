@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libasmhip.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("ASM_HIP_LIB", "libasmhip.so"))      # ASM_HIP_LIB: another build in the package directory (A/B timing in one GPU call)
 
 OPTIMAL, INFEASIBLE, DUAL_INFEASIBLE, OTHER = 1, 2, 3, 4
 K_NAMES = ("assemble", "scale", "gemv", "syrk", "chol", "trsv", "syrk_kernel", "panel_kernel")
