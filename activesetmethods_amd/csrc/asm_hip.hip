@@ -592,7 +592,13 @@ struct Dev {
     void gemm_nt(const double* A, int64_t lda, const double* B, int64_t ldb, const double* C0, int64_t ldc0, double* C, int64_t ldc, int Ma, int Mb, int K, int mode) {
         if (Ma <= 0 || Mb <= 0) return;
         int id = begin(ASM_K_TRSV, 2.0 * Ma * (double)Mb * K, 8.0 * ((double)(Ma + Mb) * K + (double)Ma * Mb));
-        hipLaunchKernelGGL(k_gemm_nt, dim3((unsigned)((Mb + 63) / 64), (unsigned)((Ma + 63) / 64)), dim3(256), 0, h->stream, A, lda, B, ldb, C0, ldc0, C, ldc, Ma, Mb, K, mode);
+        // 64 x 64 tiles leave CUs idle when there are few right-hand sides: 32-row tiles then (same sums, same order)
+        const int64_t t64 = (int64_t)((Mb + 63) / 64) * ((Ma + 63) / 64);
+        static const int ta_env = [] { const char* v = std::getenv("ASM_GEMM_TA"); return v ? std::atoi(v) : 0; }();
+        if ((ta_env == 32 || (ta_env == 0 && t64 < 2 * (int64_t)h->num_cus)) && Ma > 32)
+            hipLaunchKernelGGL(k_gemm_nt32, dim3((unsigned)((Mb + 63) / 64), (unsigned)((Ma + 31) / 32)), dim3(256), 0, h->stream, A, lda, B, ldb, C0, ldc0, C, ldc, Ma, Mb, K, mode);
+        else
+            hipLaunchKernelGGL(k_gemm_nt, dim3((unsigned)((Mb + 63) / 64), (unsigned)((Ma + 63) / 64)), dim3(256), 0, h->stream, A, lda, B, ldb, C0, ldc0, C, ldc, Ma, Mb, K, mode);
         end(id);
     }
     // Rows of R (nrhs x ldr, zero beyond column Ms) are right-hand sides of  L x = r  (forward) and then  L' x = z  (backward) with the

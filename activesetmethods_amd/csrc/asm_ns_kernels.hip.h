@@ -18,24 +18,26 @@
 // double-buffered in LDS through registers - the generic k_syrk<2, 4, 32, 1> with two operand matrices and a full rectangle.
 // Used by the multi-right-hand-side triangular solves (rows of A = right-hand sides, rows of B = rows of the factor / of the
 // explicit inverse of a wide diagonal block).
-__global__ __launch_bounds__(256) void k_gemm_nt(AsmBt abt, const double* __restrict__ A, int64_t lda, const double* __restrict__ B, int64_t ldb, const double* C0, int64_t ldc0, double* C, int64_t ldc, int Ma, int Mb, int K, int mode) {
-    ASM_BARGS(abt, A, lda, B, ldb, C0, ldc0, C, ldc, Ma, Mb, K, mode);
-    constexpr int TS = 64, KC = 32, PITCH = KC + 2;
-    __shared__ __attribute__((aligned(16))) double As[2][TS * PITCH];
+// TA = rows of A per workgroup: 64, or 32 when 64 x 64 tiles would leave CUs idle (519 right-hand sides against one wide block: 9 x 16 = 144
+// workgroups on 256 CUs; with 32-row tiles 17 x 16 = 272) - every entry of C is the same sum in the same order either way.
+template <int TA>
+__device__ __forceinline__ void gemm_nt_body(const double* __restrict__ A, int64_t lda, const double* __restrict__ B, int64_t ldb, const double* C0, int64_t ldc0, double* C, int64_t ldc, int Ma, int Mb, int K, int mode) {
+    constexpr int TS = 64, KC = 32, PITCH = KC + 2, NI = TA / 32, HA = TA / 2;
+    __shared__ __attribute__((aligned(16))) double As[2][TA * PITCH];
     __shared__ __attribute__((aligned(16))) double Bs[2][TS * PITCH];
     const int bi = blockIdx.y, bj = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 1, wc = w & 1;
-    v4f64 acc[2][2];
+    v4f64 acc[NI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
             if (mode != 0 && C0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = bi * TS + wr * 32 + i * 16 + (lane >> 4) + 4 * r;
+                    const int row = bi * TA + wr * HA + i * 16 + (lane >> 4) + 4 * r;
                     const int col = bj * TS + wc * 32 + j * 16 + (lane & 15);
                     const double v = C0[(int64_t)min(row, Ma - 1) * ldc0 + min(col, Mb - 1)];
                     acc[i][j][r] = (row < Ma && col < Mb) ? v : 0.0;
@@ -43,32 +45,32 @@ __global__ __launch_bounds__(256) void k_gemm_nt(AsmBt abt, const double* __rest
             }
         }
     const double asign = mode != 0 ? -1.0 : 1.0;
-    // staging: 64 rows x 32 doubles per operand; thread moves 2 doubles per pass, 16 threads per row, 16 rows per pass, 4 passes
+    // staging: TA / 64 rows x 32 doubles per operand; thread moves 2 doubles per pass, 16 threads per row, 16 rows per pass
     const int lr = tid >> 4, lk = (tid & 15) * 2;
-    const double* arow[4];
+    const double* arow[TA / 16];
     const double* brow[4];
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-        const int r = ps * 16 + lr;
-        const int ga = bi * TS + r, gb = bj * TS + r;
+    for (int ps = 0; ps < TA / 16; ++ps) {
+        const int ga = bi * TA + ps * 16 + lr;
         arow[ps] = ga < Ma ? A + (int64_t)ga * lda : nullptr;
+    }
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int gb = bj * TS + ps * 16 + lr;
         brow[ps] = gb < Mb ? B + (int64_t)gb * ldb : nullptr;
     }
-    double2 ra[4], rb[4];
+    double2 ra[TA / 16], rb[4];
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            ra[ps] = arow[ps] ? *reinterpret_cast<const double2*>(arow[ps] + k0 + lk) : make_double2(0.0, 0.0);
-            rb[ps] = brow[ps] ? *reinterpret_cast<const double2*>(brow[ps] + k0 + lk) : make_double2(0.0, 0.0);
-        }
+        for (int ps = 0; ps < TA / 16; ++ps) ra[ps] = arow[ps] ? *reinterpret_cast<const double2*>(arow[ps] + k0 + lk) : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) rb[ps] = brow[ps] ? *reinterpret_cast<const double2*>(brow[ps] + k0 + lk) : make_double2(0.0, 0.0);
     };
     auto lstore = [&](int st) {
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            const int r = ps * 16 + lr;
-            *reinterpret_cast<double2*>(&As[st][r * PITCH + lk]) = make_double2(asign * ra[ps].x, asign * ra[ps].y);
-            *reinterpret_cast<double2*>(&Bs[st][r * PITCH + lk]) = rb[ps];
-        }
+        for (int ps = 0; ps < TA / 16; ++ps) *reinterpret_cast<double2*>(&As[st][(ps * 16 + lr) * PITCH + lk]) = make_double2(asign * ra[ps].x, asign * ra[ps].y);
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) *reinterpret_cast<double2*>(&Bs[st][(ps * 16 + lr) * PITCH + lk]) = rb[ps];
     };
     const int nchunks = K / KC;
     if (nchunks > 0) {
@@ -81,13 +83,13 @@ __global__ __launch_bounds__(256) void k_gemm_nt(AsmBt abt, const double* __rest
         if (c + 1 < nchunks) gload((c + 1) * KC);
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 4) {
-            double af[2], bf[2];
+            double af[NI], bf[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = As[st][(wr * 32 + i * 16 + (lane & 15)) * PITCH + kk + (lane >> 4)];
+            for (int i = 0; i < NI; ++i) af[i] = As[st][(wr * HA + i * 16 + (lane & 15)) * PITCH + kk + (lane >> 4)];
 #pragma unroll
             for (int j = 0; j < 2; ++j) bf[j] = Bs[st][(wc * 32 + j * 16 + (lane & 15)) * PITCH + kk + (lane >> 4)];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
@@ -95,15 +97,23 @@ __global__ __launch_bounds__(256) void k_gemm_nt(AsmBt abt, const double* __rest
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = bi * TS + wr * 32 + i * 16 + (lane >> 4) + 4 * r;
+                const int row = bi * TA + wr * HA + i * 16 + (lane >> 4) + 4 * r;
                 const int col = bj * TS + wc * 32 + j * 16 + (lane & 15);
                 if (row < Ma && col < Mb) C[(int64_t)row * ldc + col] = acc[i][j][r];
             }
+}
+__global__ __launch_bounds__(256) void k_gemm_nt(AsmBt abt, const double* __restrict__ A, int64_t lda, const double* __restrict__ B, int64_t ldb, const double* C0, int64_t ldc0, double* C, int64_t ldc, int Ma, int Mb, int K, int mode) {
+    ASM_BARGS(abt, A, lda, B, ldb, C0, ldc0, C, ldc, Ma, Mb, K, mode);
+    gemm_nt_body<64>(A, lda, B, ldb, C0, ldc0, C, ldc, Ma, Mb, K, mode);
+}
+__global__ __launch_bounds__(256) void k_gemm_nt32(AsmBt abt, const double* __restrict__ A, int64_t lda, const double* __restrict__ B, int64_t ldb, const double* C0, int64_t ldc0, double* C, int64_t ldc, int Ma, int Mb, int K, int mode) {
+    ASM_BARGS(abt, A, lda, B, ldb, C0, ldc0, C, ldc, Ma, Mb, K, mode);
+    gemm_nt_body<32>(A, lda, B, ldb, C0, ldc0, C, ldc, Ma, Mb, K, mode);
 }
 
 // ---------------------------------------------------------------------------------------------------
