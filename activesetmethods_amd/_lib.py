@@ -13,7 +13,7 @@ K_NAMES = ("assemble", "scale", "gemv", "syrk", "chol", "trsv", "syrk_kernel", "
 class SolveStats(C.Structure):
     _fields_ = [("path", C.c_int32), ("polished", C.c_int32), ("ipm_iters", C.c_int32), ("nfact", C.c_int32),
                 ("eqp", C.c_int32), ("M", C.c_int32), ("n", C.c_int32), ("ns", C.c_int32), ("col_iters", C.c_int32),
-                ("ns_iters", C.c_int32), ("ns_dim", C.c_int32), ("ns_cold", C.c_int32),
+                ("ns_iters", C.c_int32), ("ns_dim", C.c_int32), ("ns_cold", C.c_int32), ("restored", C.c_int32),
                 ("ipm_pinf", C.c_double), ("ipm_dinf", C.c_double), ("ipm_gap", C.c_double),
                 ("kkt_pr", C.c_double), ("kkt_du", C.c_double), ("wall_ms", C.c_double)]
 

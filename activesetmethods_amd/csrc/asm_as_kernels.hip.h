@@ -104,6 +104,22 @@ __global__ __launch_bounds__(256) void k_as_sl(AsmBt abt, AsPtrs A) {
     A.sl[i] = a;
 }
 
+// last-resort answer of a restoration LP (oracle: solve_scaled, 'ipm-conv'): every slack keeps its own value s (no basic slack is recomputed
+// from its row): sl[i] = sum of scoef * s over the row's slack columns, ksoft := -1.  (k_as_sl restores sl at the start of the next LP.)
+__global__ __launch_bounds__(256) void k_as_sl_values(AsmBt abt, AsPtrs A) {
+    ASM_BARGS(abt, A);
+    int64_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= A.M) return;
+    double a = 0.0;
+    if (A.ns) {
+        int k0 = A.rs0[i], k1 = A.rs1[i];
+        if (k0 >= 0) a += A.scoef[k0] * A.s[k0];
+        if (k1 >= 0) a += A.scoef[k1] * A.s[k1];
+    }
+    A.sl[i] = a;
+    A.ksoft[i] = -1;
+}
+
 // s = max(src, slo)
 __global__ __launch_bounds__(256) void k_as_smax(AsmBt abt, const double* __restrict__ src, const double* __restrict__ slo, double* __restrict__ dst, int64_t ns) {
     ASM_BARGS(abt, src, slo, dst, ns);

@@ -61,7 +61,7 @@ const int WARM_BACKOFF_MAX = 6;  // oracle/lp_solver.py: pause after consecutive
 const double EQP_RUNAWAY = 10.0, EQP_MAXCHG = 0.03;
 const int EQP_MINCHG = 32;  // oracle/lp_solver.py: growth of the primal residual between two rounds of a bulk correction that ends the attempt
 const int64_t RCM_MAX_PAIRS = 50000000;      // sum over the columns of (rows in the column)^2 beyond which no row order is computed
-const double IPM_ACCEPT = 1e-10;
+const double IPM_ACCEPT = 1e-8, IPM_ACCEPT_DUAL = 1e-8;      // oracle/lp_solver.py: last-resort acceptance of a converged iterate (primal residual and gap; dual residual)
 const int NS_MAX_SPLIT = 8;
 const double NS_SEL_THR[4] = {1e-2, 1e-4, 1e-7, 1e-10};
 const int PCG_MAXIT = 20;       // conjugate-gradient steps per Newton solve (preconditioner = the Cholesky factor)
@@ -2359,6 +2359,7 @@ struct Solver {
         const int64_t n = lp.n, M = lp.M, ns = lp.ns;
         h->stats.path = -1;
         h->stats.polished = 1;
+        h->stats.restored = 0;
         cur_hint = &hint;
         btag = 30;
         asmb::barrier(btag);
@@ -2475,6 +2476,7 @@ struct Solver {
             ipm_measures();
             if (h->verbose) std::fprintf(stderr, "[asm] last stage ended %.1e against %.1e at best: best iterate restored (pinf %.3e dinf %.3e gap %.3e)\n", m_last, best_m, ip.pinf, ip.dinf, ip.gap);
             h->stats.ipm_pinf = ip.pinf; h->stats.ipm_dinf = ip.dinf; h->stats.ipm_gap = ip.gap;
+            h->stats.restored = 1;
             identify_dev(3);
         }
         if (have_sets) {
@@ -2507,10 +2509,23 @@ struct Solver {
         }
         // last resort (oracle: solve_scaled, 'ipm-conv'): an iterate converged to IPM_ACCEPT in all three measures is an optimal point of the
         // LP to that accuracy; it is handed out through the active-set arena (clipped into the box, partition of the last identification)
-        if (have_sets && ip.pinf <= IPM_ACCEPT && ip.dinf <= IPM_ACCEPT && ip.gap <= IPM_ACCEPT) {
+        bool conv = have_sets && ip.pinf <= IPM_ACCEPT && ip.dinf <= IPM_ACCEPT_DUAL && ip.gap <= IPM_ACCEPT;
+        if (!conv && have_sets && have_snap && best_m <= IPM_ACCEPT) {
+            // ... or the best stage end did (the last iterations drifted out of the acceptance, but by less than IPM_DEGRADE): that iterate then
+            hipLaunchKernelGGL(k_ipm_snapshot, dim3(grid_all()), dim3(256), 0, h->stream, P, h->d_ipm_snap, snap_e ? nsv(14) : (double*)nullptr, h->ldn, h->Mp, h->nsp, 1);
+            ipm_measures();
+            h->stats.ipm_pinf = ip.pinf; h->stats.ipm_dinf = ip.dinf; h->stats.ipm_gap = ip.gap;
+            h->stats.restored = 1;
+            identify_dev(3);
+            conv = true;
+        }
+        if (conv) {
             hipLaunchKernelGGL(k_as_clip0, dim3((unsigned)((lp.n + 255) / 256)), dim3(256), 0, h->stream, A.lb, A.ub, (const double*)P.p, A.p, lp.n);
             dcopy(A.y, P.y, lp.M);
-            if (lp.ns) hipLaunchKernelGGL(k_as_smax, dim3((unsigned)((lp.ns + 255) / 256)), dim3(256), 0, h->stream, (const double*)P.s, A.slo, A.s, lp.ns);
+            if (lp.ns) {
+                hipLaunchKernelGGL(k_as_smax, dim3((unsigned)((lp.ns + 255) / 256)), dim3(256), 0, h->stream, (const double*)P.s, A.slo, A.s, lp.ns);
+                hipLaunchKernelGGL(k_as_sl_values, dim3((unsigned)((lp.M + 255) / 256 + 1)), dim3(256), 0, h->stream, A);      // the tail kernel must not recompute slacks from a stale working set
+            }
             dev.gemv_n_dev(h->d_Ah, A.p, A.t);
             dev.gemv_t_dev(h->d_Ah, A.y, A.tN);
             hipLaunchKernelGGL(k_as_finish, dim3(1), dim3(1024), 0, h->stream, A, S_[3], S_[1], S_[2], 0, TOL_P, TOL_D);

@@ -123,6 +123,8 @@ class AbstractSlpOptimizer:
         st = self.optimizer.last_stats()
         rec = dict(iter=self.iter, fr=bool(self.feasibility_restoration), status=out[5], delta=float(Delta), x=self.x.copy(),
                    p=out[0].copy(), lam=out[1].copy(), mult_x_U=out[2].copy(), mult_x_L=out[3].copy(), stats=st)
+        if self.feasibility_restoration:
+            rec['p_slack'] = out[4]                         # slack values of the restoration LP (subproblem.jl:531-541)
         if out[5] == OPTIMAL:
             rec['sets'] = self.optimizer.active_set()
         self.trace.append(rec)

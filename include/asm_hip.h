@@ -124,6 +124,8 @@ typedef struct {
     int32_t ns_iters;      /* interior-point iterations that factored the k x k null-space form (normal-phase LPs with many equality rows) */
     int32_t ns_dim;        /* k = dimension of null(A_EF) when that form was set up, else 0 */
     int32_t ns_cold;       /* 1: the basis columns were selected from scratch in this LP (0: the previous LP's columns were re-used) */
+    int32_t restored;      /* 1: no interior-point stage ended in a successful polish and the last stage ended 10x worse than the best one - the best
+                            * iterate was brought back for the final attempts (best-iterate safeguard) */
     double  ipm_pinf, ipm_dinf, ipm_gap;
     double  kkt_pr, kkt_du;
     double  wall_ms;       /* host wall time of the solve */

