@@ -459,7 +459,16 @@ inline unsigned copy_grid(size_t bytes) { return (unsigned)std::min<size_t>(64, 
 
 inline hipError_t memcpy_async(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st) {
     Fiber* f = cur;
-    if (!f) return ::hipMemcpyAsync(dst, src, bytes, kind, st);
+    if (!f) {
+        // outside a batch: device-to-device copies of the solver's vectors (4 - 150 KB, ~60 per LP) as a copy kernel of this library - the
+        // runtime's blit path brackets each copy with its own barrier / signal packets
+        static const bool own = [] { const char* v = std::getenv("ASM_HIP_OWN_COPIES"); return !(v && v[0] == '0'); }();
+        if (own && kind == hipMemcpyDeviceToDevice && bytes > 0 && bytes <= ((size_t)64 << 20)) {
+            k_bcopy<<<dim3((unsigned)std::min<size_t>(256, std::max<size_t>(1, (bytes + 16383) / 16384))), dim3(256), 0, st>>>(AsmBt{nullptr, 0, 1}, (char*)dst, (const char*)src, (int64_t)bytes);
+            return hipGetLastError();
+        }
+        return ::hipMemcpyAsync(dst, src, bytes, kind, st);
+    }
     if (bytes == 0) return hipSuccess;
     if (kind == hipMemcpyHostToDevice) {
         const size_t po = (f->payload.size() + 15) & ~(size_t)15;
@@ -481,7 +490,14 @@ inline hipError_t memcpy_async(void* dst, const void* src, size_t bytes, hipMemc
 }
 inline hipError_t memset_async(void* dst, int value, size_t bytes, hipStream_t st) {
     Fiber* f = cur;
-    if (!f) return ::hipMemsetAsync(dst, value, bytes, st);
+    if (!f) {
+        static const bool own = [] { const char* v = std::getenv("ASM_HIP_OWN_COPIES"); return !(v && v[0] == '0'); }();
+        if (own && bytes > 0 && bytes <= ((size_t)64 << 20)) {
+            k_bfill<<<dim3((unsigned)std::min<size_t>(256, std::max<size_t>(1, (bytes + 16383) / 16384))), dim3(256), 0, st>>>(AsmBt{nullptr, 0, 1}, (char*)dst, value, (int64_t)bytes);
+            return hipGetLastError();
+        }
+        return ::hipMemsetAsync(dst, value, bytes, st);
+    }
     if (bytes == 0) return hipSuccess;
     record<char*, int, int64_t>(f, k_bfill, dim3(copy_grid(bytes)), dim3(256), 0, 0u, (char*)dst, value, (int64_t)bytes);
     return hipSuccess;

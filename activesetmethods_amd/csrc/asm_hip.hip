@@ -1741,14 +1741,22 @@ struct Solver {
     }
     // one Newton solve with the current factor (oracle: IPM.run.solve); mode 0 affine, 1 Mehrotra corrector built on
     // `base`, 2 Gondzio centrality corrector for `base` at the trial steps (tp, td)
-    void ipm_solve(int mode, const IpmDir& base, IpmDir& D, double tp = 0.0, double td = 0.0) {
+    // spec = 0: as the oracle states it.  spec = 1 / 2 (first / later solve of an iteration, only with the factor of S itself as preconditioner):
+    // the residual check is not waited for - its verdict travels in scal[SC_SPEC] with the next block the iteration reads (ipm_run redoes the
+    // iteration's solves with spec = 0 when one of them missed its tolerance: one host round trip per solve less in the common case).
+    void ipm_solve(int mode, const IpmDir& base, IpmDir& D, double tp = 0.0, double td = 0.0, int spec = 0) {
         const unsigned g = grid_all();
         
         hipLaunchKernelGGL(k_ipm_rhs1, dim3(g), dim3(256), 0, h->stream, P, base, mode, tp, td, MCC_BMIN, MCC_BMAX);
         dev.gemv_n_dev(h->d_Ah, P.tmpn, P.t1);
         hipLaunchKernelGGL(k_ipm_rhs2, dim3(g), dim3(256), 0, h->stream, P, mode == 2 ? 0.0 : 1.0);
         precond(P.rhs, D.dy);
-        {
+        if (spec) {
+            dev.gemv_t_dev(h->d_Ah, D.dy, d_tN);
+            hipLaunchKernelGGL(k_vec_mul, dim3((unsigned)((lp.n + 255) / 256)), dim3(256), 0, h->stream, d_tN, P.thp_inv, lp.n);
+            dev.gemv_n_dev(h->d_Ah, d_tN, d_sres);
+            hipLaunchKernelGGL(k_ipm_res, dim3(1), dim3(1024), 0, h->stream, P, d_sres, D.dy, 0u, spec, 1e-10, PCG_KAPPA * ip.rpmax);
+        } else {
             // preconditioned CG on the unregularised Schur system, the Cholesky factor as preconditioner (oracle: IPM.run.solve).
             // The residual of this system is exactly the primal residual the step leaves behind, hence the tolerance.
             auto applyS = [&](const double* v) {          // d_sres = Ah Th^-1 Ah' v
@@ -1758,7 +1766,7 @@ struct Solver {
             };
             applyS(D.dy);
             unsigned pub = pub_next();
-            hipLaunchKernelGGL(k_ipm_res, dim3(1), dim3(1024), 0, h->stream, P, d_sres, D.dy, pub);
+            hipLaunchKernelGGL(k_ipm_res, dim3(1), dim3(1024), 0, h->stream, P, d_sres, D.dy, pub, 0, 0.0, 0.0);
             read_scal(pub);
             // the approximate preconditioner (column form) gets the tighter floor (oracle: IPM.run.solve)
             const double tol = std::max(((use_col || use_red) ? 1e-13 : 1e-10) * h->h_scal[SC_RMAX], PCG_KAPPA * ip.rpmax);
@@ -1890,30 +1898,42 @@ struct Solver {
             }
             ip.iters += 1;
             done += 1;
-            cg_max = 0;
-            cg_fail = false;
-            if (use_ns) ns_newton(0, dirA, dirA); else ipm_solve(0, dirA, dirA);
-            hipLaunchKernelGGL(k_ipm_steps, dim3(red_grid()), dim3(1024), 0, h->stream, P, dirA, 0u);
-            hipLaunchKernelGGL(k_ipm_muaff, dim3(red_grid()), dim3(1024), 0, h->stream, P, dirA);
-            if (use_ns) ns_newton(1, dirA, dirC); else ipm_solve(1, dirA, dirC);
-            unsigned pub = pub_next();
-            hipLaunchKernelGGL(k_ipm_steps, dim3(red_grid()), dim3(1024), 0, h->stream, P, dirC, pub);
-            read_scal(pub);
-            double ap = h->h_scal[SC_AP], ad = h->h_scal[SC_AD];
-            // Gondzio multiple centrality correctors (oracle: IPM.run): dirA is free again and receives the candidate
-            for (int kc = 0; kc < (use_ns ? 0 : IPM_MCC); ++kc) {      // (no correctors in null-space form: a Newton solve costs more than the factorisation there)
-                    if (std::min(ap, ad) >= 0.9) break;
-                const double tp = std::min(1.0, ap + MCC_DELTA), td = std::min(1.0, ad + MCC_DELTA);
-                ipm_solve(2, dirC, dirA, tp, td);
-                hipLaunchKernelGGL(k_ipm_diradd, dim3(grid_all()), dim3(256), 0, h->stream, P, dirA, dirC);
-                pub = pub_next();
-                hipLaunchKernelGGL(k_ipm_steps, dim3(red_grid()), dim3(1024), 0, h->stream, P, dirA, pub);
+            double ap = 0.0, ad = 0.0;
+            // the solves of the iteration; deferred = the residual checks of the solves are not waited for one by one (ipm_solve, spec):
+            // false when one of them missed its tolerance - the solves are then redone as the oracle states them (same iterate, same
+            // factor: every vector they write is written again)
+            auto solves = [&](const bool deferred) -> bool {
+                cg_max = 0;
+                cg_fail = false;
+                if (use_ns) ns_newton(0, dirA, dirA); else ipm_solve(0, dirA, dirA, 0.0, 0.0, deferred ? 1 : 0);
+                hipLaunchKernelGGL(k_ipm_steps, dim3(red_grid()), dim3(1024), 0, h->stream, P, dirA, 0u);
+                hipLaunchKernelGGL(k_ipm_muaff, dim3(red_grid()), dim3(1024), 0, h->stream, P, dirA);
+                if (use_ns) ns_newton(1, dirA, dirC); else ipm_solve(1, dirA, dirC, 0.0, 0.0, deferred ? 2 : 0);
+                unsigned pub = pub_next();
+                hipLaunchKernelGGL(k_ipm_steps, dim3(red_grid()), dim3(1024), 0, h->stream, P, dirC, pub);
                 read_scal(pub);
-                const double ap2 = h->h_scal[SC_AP], ad2 = h->h_scal[SC_AD];
-                if (!(ap2 >= ap && ad2 >= ad && ap2 + ad2 >= ap + ad + MCC_GAMMA * MCC_DELTA)) break;
-                std::swap(dirA, dirC);
-                ap = ap2; ad = ad2;
-            }
+                if (deferred && h->h_scal[SC_SPEC] != 0.0) return false;
+                ap = h->h_scal[SC_AP]; ad = h->h_scal[SC_AD];
+                // Gondzio multiple centrality correctors (oracle: IPM.run): dirA is free again and receives the candidate
+                for (int kc = 0; kc < (use_ns ? 0 : IPM_MCC); ++kc) {      // (no correctors in null-space form: a Newton solve costs more than the factorisation there)
+                    if (std::min(ap, ad) >= 0.9) break;
+                    const double tp = std::min(1.0, ap + MCC_DELTA), td = std::min(1.0, ad + MCC_DELTA);
+                    ipm_solve(2, dirC, dirA, tp, td, deferred ? 2 : 0);
+                    hipLaunchKernelGGL(k_ipm_diradd, dim3(grid_all()), dim3(256), 0, h->stream, P, dirA, dirC);
+                    pub = pub_next();
+                    hipLaunchKernelGGL(k_ipm_steps, dim3(red_grid()), dim3(1024), 0, h->stream, P, dirA, pub);
+                    read_scal(pub);
+                    if (deferred && h->h_scal[SC_SPEC] != 0.0) return false;
+                    const double ap2 = h->h_scal[SC_AP], ad2 = h->h_scal[SC_AD];
+                    if (!(ap2 >= ap && ad2 >= ad && ap2 + ad2 >= ap + ad + MCC_GAMMA * MCC_DELTA)) break;
+                    std::swap(dirA, dirC);
+                    ap = ap2; ad = ad2;
+                }
+                return true;
+            };
+            static const bool spec_env = [] { const char* v = std::getenv("ASM_IPM_DEFER_CHECK"); return !(v && v[0] == '0'); }();
+            const bool defer = spec_env && !use_ns && !use_col && !use_red;      // the factor of S itself is the preconditioner
+            if (!(defer && solves(true))) solves(false);
             if (h->verbose) std::fprintf(stderr, "[asm]     ap %.3e ad %.3e  cg steps so far %lld\n", ap, ad, (long long)h->stats_pcg);
             if (use_ns && h->h_scal[SC_NSERR] > NS_RERR) {
                 ns_finish_y();

@@ -25,7 +25,7 @@ struct IpmPtrs {
 struct IpmDir {
     double *dp, *ds, *dg, *dy, *dmuL, *dmuU, *dmus, *dpi;
 };
-enum { SC_PINF = 0, SC_DINF, SC_MU, SC_YMAX, SC_AP, SC_AD, SC_SM, SC_EMAX, SC_RMAX, SC_RZ, SC_RPMAX, SC_RZ0, SC_STOP, SC_NSERR, SC_COUNT };   // SC_NSERR: dual-equation error of a null-space Newton step
+enum { SC_PINF = 0, SC_DINF, SC_MU, SC_YMAX, SC_AP, SC_AD, SC_SM, SC_EMAX, SC_RMAX, SC_RZ, SC_RPMAX, SC_RZ0, SC_STOP, SC_NSERR, SC_SPEC, SC_COUNT };   // SC_SPEC: a solve whose residual check was deferred (k_ipm_res, spec != 0) missed its tolerance;   // SC_NSERR: dual-equation error of a null-space Newton step
 
 // Hand the scalar block to the host without a copy command or a stream synchronisation: the single workgroup that has just written
 // P.scal stores the block into host-mapped memory, fences at system scope and sets the sequence word the host is spinning on
@@ -271,8 +271,11 @@ __global__ __launch_bounds__(256) void k_vec_mul(AsmBt abt, double* __restrict__
 }
 
 // res = rhs - (sres + dS dy) ; scal[EMAX] = max|res| ; scal[RMAX] = max(1, max|rhs|)
-__global__ __launch_bounds__(1024) void k_ipm_res(AsmBt abt, IpmPtrs P, const double* __restrict__ sres, const double* __restrict__ dy, unsigned pub) {
-    ASM_BARGS(abt, P, sres, dy, pub);
+// spec != 0: the host does not read this check before it goes on (the factor of S itself is the preconditioner: the residual of the first
+// solve is at rounding level); the verdict "emax > max(crel rmax, floor)" is kept in scal[SC_SPEC] instead - set by the first solve of an
+// iteration (spec == 1), or-ed by the later ones (spec == 2) - and arrives with the next block the iteration reads anyway.
+__global__ __launch_bounds__(1024) void k_ipm_res(AsmBt abt, IpmPtrs P, const double* __restrict__ sres, const double* __restrict__ dy, unsigned pub, int spec, double crel, double floor_) {
+    ASM_BARGS(abt, P, sres, dy, pub, spec, crel, floor_);
     __shared__ double sh[16];
     double emax = 0.0, rmax = 1.0;
     for (int64_t i = threadIdx.x; i < P.M; i += 1024) {
@@ -286,6 +289,10 @@ __global__ __launch_bounds__(1024) void k_ipm_res(AsmBt abt, IpmPtrs P, const do
     if (threadIdx.x == 0) {
         P.scal[SC_EMAX] = emax;
         P.scal[SC_RMAX] = rmax;
+        if (spec) {
+            const double bad = emax > fmax(crel * rmax, floor_) ? 1.0 : 0.0;
+            P.scal[SC_SPEC] = spec == 1 ? bad : fmax(P.scal[SC_SPEC], bad);
+        }
     }
     scal_publish(P, pub);
 }
