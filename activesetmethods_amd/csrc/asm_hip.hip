@@ -1623,11 +1623,11 @@ struct Solver {
             dev.launch_syrk(T, h->d_nsG, h->ns_ldg, nullptr, 0, k, (int)h->ns_ldg, h->d_nsth, nullptr, h->d_nsNp, h->ns_fN.ld, 0, 0, -1, nullptr, 0, -1.0, nsplit, pstride);
             dev.end(id);
             hipLaunchKernelGGL(k_ns_reduce_lower, dim3((unsigned)((k + 255) / 256), (unsigned)k), dim3(256), 0, h->stream, (const double*)h->d_nsNp, nsplit, pstride, h->ns_fN.ld,
-                               h->ns_fN.S, h->d_nsN0, k);
+                               h->ns_fN.S, h->d_nsN0, k, k <= ASM_SMALL_USE ? 1 : 0);
         } else {
             dev.launch_syrk(Dev::pick_tile(k), h->d_nsG, h->ns_ldg, nullptr, 0, k, (int)h->ns_ldg, h->d_nsth, nullptr, h->ns_fN.S, h->ns_fN.ld, 0, 0);
             dev.end(id);
-            hipLaunchKernelGGL(k_ns_copy_lower, dim3((unsigned)((k + 255) / 256), (unsigned)k), dim3(256), 0, h->stream, (const double*)h->ns_fN.S, h->ns_fN.ld, h->d_nsN0, h->ns_fN.ld, k);
+            hipLaunchKernelGGL(k_ns_copy_lower, dim3((unsigned)((k + 255) / 256), (unsigned)k), dim3(256), 0, h->stream, (const double*)h->ns_fN.S, h->ns_fN.ld, h->d_nsN0, h->ns_fN.ld, k, k <= ASM_SMALL_USE ? 1 : 0);
         }
         dev.diag_prepare(k, 0, 1e-13, 1e-30);
         dev.chol(k, 1e-14, false);

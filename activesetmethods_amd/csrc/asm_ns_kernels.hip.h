@@ -345,16 +345,20 @@ __global__ __launch_bounds__(256) void k_ns_symv_res(AsmBt abt, const double* __
     acc = wave_sum(acc);
     if (lane == 0) out[i] = rhs[i] - acc;
 }
-// lower triangle copy  dst[i, j] = src[i, j], j <= i < k
-__global__ __launch_bounds__(256) void k_ns_copy_lower(AsmBt abt, const double* __restrict__ src, int64_t lds_, double* __restrict__ dst, int64_t ldd, int k) {
-    ASM_BARGS(abt, src, lds_, dst, ldd, k);
+// copy of the lower triangle  dst[i, j] = src[i, j], j <= i < k;  full: mirrored into the upper triangle as well
+__global__ __launch_bounds__(256) void k_ns_copy_lower(AsmBt abt, const double* __restrict__ src, int64_t lds_, double* __restrict__ dst, int64_t ldd, int k, int full) {
+    ASM_BARGS(abt, src, lds_, dst, ldd, k, full);
     const int i = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j <= i && j < k) dst[(int64_t)i * ldd + j] = src[(int64_t)i * lds_ + j];
+    if (j <= i && j < k) {
+        const double v = src[(int64_t)i * lds_ + j];
+        dst[(int64_t)i * ldd + j] = v;
+        if (full) dst[(int64_t)j * ldd + i] = v;      // small systems (k_ns_reduced_solve): the copy is stored in full, its products read rows, never columns
+    }
 }
 // lower triangle of the sum of the split-K slices (fixed order), written to the factor buffer and to the unregularised copy
-__global__ __launch_bounds__(256) void k_ns_reduce_lower(AsmBt abt, const double* __restrict__ parts, int nsplit, int64_t pstride, int64_t ld, double* __restrict__ S, double* __restrict__ N0, int k) {
-    ASM_BARGS(abt, parts, nsplit, pstride, ld, S, N0, k);
+__global__ __launch_bounds__(256) void k_ns_reduce_lower(AsmBt abt, const double* __restrict__ parts, int nsplit, int64_t pstride, int64_t ld, double* __restrict__ S, double* __restrict__ N0, int k, int full) {
+    ASM_BARGS(abt, parts, nsplit, pstride, ld, S, N0, k, full);
     const int i = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j <= i && j < k) {
@@ -363,6 +367,7 @@ __global__ __launch_bounds__(256) void k_ns_reduce_lower(AsmBt abt, const double
         for (int s_ = 1; s_ < nsplit; ++s_) v += parts[(int64_t)s_ * pstride + o];
         S[o] = v;
         N0[o] = v;
+        if (full) N0[(int64_t)j * ld + i] = v;          // (see k_ns_copy_lower)
     }
 }
 // x = a + b
@@ -816,13 +821,12 @@ __global__ __launch_bounds__(1024) void k_small_solve(AsmBt abt, const double* _
     small_chol_solve(L, ld, Linv, k, x, t, part);
     for (int i = threadIdx.x; i < k; i += 1024) out[i] = x[i];
 }
-// r (LDS) = rhs - N0 x  with N0 symmetric, lower triangle stored: one wavefront per row
+// r (LDS) = rhs - N0 x  with N0 symmetric, stored in full: one wavefront per row
 __device__ __forceinline__ void small_symv_res(const double* __restrict__ N0, int64_t ld, int k, const double* x, const double* rhs, double* r) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int i = wv; i < k; i += 16) {
         double acc = 0.0;
-        for (int j = lane; j <= i; j += 64) acc = fma(N0[(int64_t)i * ld + j], x[j], acc);
-        for (int j = i + 1 + lane; j < k; j += 64) acc = fma(N0[(int64_t)j * ld + i], x[j], acc);
+        for (int j = lane; j < k; j += 64) acc = fma(N0[(int64_t)i * ld + j], x[j], acc);
         acc = wave_sum(acc);
         if (lane == 0) r[i] = rhs[i] - acc;
     }

@@ -2,7 +2,8 @@
 # runs every workload alternately with libasmhip_base.so (ASM_HIP_LIB) and libasmhip.so, twice each
 for w in "$@"; do
   for rep in 1 2; do
-    for lib in libasmhip_base.so libasmhip.so; do
+    if [ $rep = 1 ]; then order="libasmhip_base.so libasmhip.so"; else order="libasmhip.so libasmhip_base.so"; fi      # (order alternates: the second run of a pair sees a warmer chip)
+    for lib in $order; do
       ASM_HIP_LIB=$lib timeout -k 10 300 python bench.py --workload $w --no-cpu-baseline > gpurun_out/ab_${w}_${lib}_$rep.log 2>&1 || exit 1
       python - "$w" "$lib" gpurun_out/ab_${w}_${lib}_$rep.log <<'PY'
 import json, sys
