@@ -36,7 +36,8 @@ class SlpResult(C.Structure):
 
 class BatchStats(C.Structure):
     _fields_ = [("rounds", C.c_int64), ("ops", C.c_int64), ("launches", C.c_int64), ("releases", C.c_int64), ("blob_bytes", C.c_int64),
-                ("emit_ms", C.c_double), ("wait_ms", C.c_double), ("host_ms", C.c_double), ("wall_ms", C.c_double)]
+                ("emit_ms", C.c_double), ("wait_ms", C.c_double), ("host_ms", C.c_double), ("wall_ms", C.c_double),
+                ("panel_ms", C.c_double), ("panel_launches", C.c_int64), ("panel_ops", C.c_int64), ("panel_flops", C.c_double), ("panel_bytes", C.c_double)]
 
 
 _P = C.c_void_p

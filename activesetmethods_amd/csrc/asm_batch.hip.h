@@ -145,6 +145,26 @@ struct Sched {
     uint64_t n_rounds = 0, n_ops = 0, n_launches = 0, n_releases = 0, blob_bytes = 0;
     double t_emit_ms = 0, t_wait_ms = 0, t_host_ms = 0;
     bool verbose = false;                                   // ASM_BATCH_VERBOSE=1: per-kernel merge statistics at release
+    // HIP events around every merged launch of the dataflow panel kernels (OP_RESIDENT) on this group's stream: the family bench.py's roofline names
+    bool time_resident = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> res_events;
+    std::vector<hipEvent_t> res_pool;
+    double res_ms = 0.0;
+    uint64_t res_launches = 0, res_ops = 0;
+    hipEvent_t res_event() {
+        if (!res_pool.empty()) { hipEvent_t e = res_pool.back(); res_pool.pop_back(); return e; }
+        hipEvent_t e;
+        chk(hipEventCreate(&e), "hipEventCreate");
+        return e;
+    }
+    void resolve_resident() {                               // (the stream is idle: every round ends with a completion wait)
+        for (auto& pr : res_events) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) res_ms += ms;
+            res_pool.push_back(pr.first); res_pool.push_back(pr.second);
+        }
+        res_events.clear();
+    }
     std::map<const void*, std::pair<uint64_t, uint64_t>> per_kernel;      // kernel -> (operations recorded, launches made)
 
     static void chk(hipError_t e, const char* what) {
@@ -168,6 +188,7 @@ struct Sched {
     void init(int dev, hipStream_t s, int pwgs) {
         device = dev; stream = s; panel_wgs = pwgs;
         if (const char* v = std::getenv("ASM_BATCH_VERBOSE")) verbose = v[0] == '1';
+        if (const char* v = std::getenv("ASM_HIP_TIMING")) time_resident = v[0] != '0'; else time_resident = true;      // as for a handle: the panel family is timed by default
         chk(hipHostMalloc((void**)&h_sig, 64, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc(sig)");
         chk(hipHostGetDevicePointer((void**)&d_sig, h_sig, 0), "hipHostGetDevicePointer(sig)");
         *h_sig = 0;
@@ -308,7 +329,11 @@ struct Sched {
         for (const Launch& L : launches) {
             const Op& X = *L.op;
             AsmBt bt{(const void*)(d_blob + L.tab), X.arg_size, X.gz};
+            const bool timed = time_resident && (X.flags & OP_RESIDENT);
+            hipEvent_t ea = nullptr, eb = nullptr;
+            if (timed) { ea = res_event(); eb = res_event(); chk(hipEventRecord(ea, stream), "hipEventRecord"); }
             X.thunk(X.kfn, dim3(X.gx, X.gy, X.gz * L.nb), dim3(X.bx, X.by, X.bz), X.shmem, stream, bt);
+            if (timed) { chk(hipEventRecord(eb, stream), "hipEventRecord"); res_events.push_back({ea, eb}); res_launches += 1; res_ops += L.nb; }
         }
         round += 1;
         if (round == 0) round = 1;
@@ -317,6 +342,7 @@ struct Sched {
         const double t1 = now_ms();
         wait_round();
         const double t2 = now_ms();
+        if (!res_events.empty()) resolve_resident();
         for (Fiber* f : fl) {
             for (size_t i = 0; i < f->ops.size(); ++i)
                 if (f->ops[i].h_dst) std::memcpy(f->ops[i].h_dst, h_out + f->out_off[i], f->ops[i].out_bytes);

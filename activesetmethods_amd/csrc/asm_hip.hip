@@ -4052,8 +4052,12 @@ void run_fibers(asm_batch* b, int count, W&& work) {
     asm_batch_stats& st = b->stats;
     st.rounds = st.ops = st.launches = st.releases = st.blob_bytes = 0;
     st.emit_ms = st.wait_ms = st.host_ms = 0.0;
+    st.panel_ms = st.panel_flops = st.panel_bytes = 0.0;
+    st.panel_launches = st.panel_ops = 0;
+    for (asm_handle* sh : b->slots) { st.panel_flops += sh->kstats.flops[ASM_K_PANEL_KERNEL]; st.panel_bytes += sh->kstats.bytes[ASM_K_PANEL_KERNEL]; }
     for (BatchGroup* g : b->groups) {
         const asmb::Sched& S = g->sched;
+        st.panel_ms += S.res_ms; st.panel_launches += (int64_t)S.res_launches; st.panel_ops += (int64_t)S.res_ops;
         st.rounds += (int64_t)S.n_rounds; st.ops += (int64_t)S.n_ops; st.launches += (int64_t)S.n_launches; st.releases += (int64_t)S.n_releases;
         st.blob_bytes += (int64_t)S.blob_bytes; st.emit_ms += S.t_emit_ms; st.wait_ms += S.t_wait_ms; st.host_ms += S.t_host_ms;
     }

@@ -171,6 +171,18 @@ def run_batch(args, rank, world, local_rank, dist, torch):
                                "ipm_iterations_per_lp": sum(r.ipm_iters for r in runs) / max(1, sum(r.lp_solves for r in runs))},
                "host": {"cpu_quota": _host_cpu_quota(), "blas_threads": HOST_THREADS, "cgroup_throttled_s": round(thr, 3),
                         "rank_seconds": [round(v, 3) for v in rank_s], "rank_throttled_s": [round(v, 3) for v in rank_thr]}}
+        # roofline of the dominant kernel family as the batch runs it (rank 0's GPU): the dataflow panel kernels, HIP events around every MERGED
+        # launch on its group's stream (include/asm_hip.h: asm_batch_stats.panel_*); algorithmic flops = what the slots' factorisations account
+        if d.get("panel_launches", 0) > 0 and d.get("panel_ms", 0.0) > 0.0:
+            tf = d["panel_flops"] / (d["panel_ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "k_chol_panel_solo + k_chol_panel_inv (dataflow panel kernels) as merged launches of the lockstep batch: "
+                                                          "one launch factors the same inner panel of several scenarios - a dependent chain of 64-wide steps, latency-bound",
+                               "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "avg_launch_ms": d["panel_ms"] / d["panel_launches"], "launches": int(d["panel_launches"]),
+                               "scenario_launches_merged": int(d["panel_ops"]), "scenarios_per_launch": d["panel_ops"] / d["panel_launches"],
+                               "share_of_stream_time": d["panel_ms"] / max(1e-9, 1e3 * mine * hb.groups),
+                               "algorithmic_bytes_per_launch": d["panel_bytes"] / d["panel_launches"],
+                               "note": "rank 0; the groups' streams run side by side, so the family's share is taken of groups x wall time; traffic: no PMC pass of the batch is committed"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = c5_cpu_baseline(base, lo, args, runs)
         print(json.dumps(out))

@@ -275,6 +275,11 @@ typedef struct {
     int64_t releases;      /* barrier groups released */
     int64_t blob_bytes;    /* argument tables + copy payloads sent to the device */
     double  emit_ms, wait_ms, host_ms, wall_ms;   /* merging + launching, waiting for the device, solver host code, total */
+    /* the dataflow panel kernels (k_chol_panel*: ASM_K_PANEL_KERNEL of a handle) as the batch runs them: HIP events around every merged launch
+     * on its group's stream (ASM_HIP_TIMING != 0), the launches the slots recorded, and their algorithmic flops / bytes summed over the slots */
+    double  panel_ms;
+    int64_t panel_launches, panel_ops;
+    double  panel_flops, panel_bytes;
 } asm_batch_stats;
 int asm_batch_get_stats(const asm_batch* b, asm_batch_stats* out);
 
