@@ -881,7 +881,38 @@ struct Dev {
             }
         }
     }
+    // Banded factor, every inner panel with its whole trailing update in ONE launch (k_chol_panel_band): no rank-K launches between the panels.
+    // Possible when a panel and the band's reach fit ASM_PNL_NRT row tiles and the workgroups (one per row tile + one per trailing tile) are
+    // all resident; a batch slot keeps the launch sequence (its panel launches are merged across scenarios).
+    bool band_panels_ok(int Ms) const {
+        static const bool env = [] { const char* v = std::getenv("ASM_BAND_PANELS"); return !(v && v[0] == '0'); }();
+        if (!env || fband <= 0 || !h->fused_panel || h->batch_slot || Ms <= CHOL_NBI + 2 * ASM_NB) return false;
+        const int nrt = (CHOL_NBI + 2 * ASM_NB + (int)round_up(fband, 64) + ASM_NB - 1) / ASM_NB + 1;
+        const int m = nrt - CHOL_NBI / ASM_NB;
+        return nrt <= ASM_PNL_NRT && nrt + m * (m + 1) / 2 <= h->panel_wgs;
+    }
+    void chol_launches_band(int Ms, double thr) {
+        cur = h->stream;
+        for (int I0 = 0, I1 = 0; I0 < Ms; I0 = I1) {
+            I1 = (Ms - I0 <= CHOL_NBI + 2 * ASM_NB) ? Ms : I0 + CHOL_NBI;
+            const int Mi = rowlim(Ms, I1);
+            const int nrt = (Mi - I0 + ASM_NB - 1) / ASM_NB, nst = (I1 - I0 + ASM_NB - 1) / ASM_NB, m = nrt - nst;
+            h->panel_epoch += 1;
+            if (h->panel_epoch == 0) h->panel_epoch = 1;
+            double pfl = 0.0;
+            for (int k0 = I0; k0 < I1; k0 += ASM_NB) {
+                const double r = std::max(0, Mi - (k0 + ASM_NB));
+                pfl += 2.0 / 3.0 * ASM_NB * ASM_NB * ASM_NB + 2.0 * r * ASM_NB * ASM_NB + 2.0 * ASM_NB * (0.5 * r * r);      // factor, panel solve, update of everything in reach
+            }
+            int pid = begin(ASM_K_PANEL_KERNEL, pfl, 8.0 * 2.0 * (double)(Mi - I0) * (double)(Mi - I0) * 0.5, cur);
+            const int nhelp = (m * (m + 1) / 2 + ASM_BAND_TPH - 1) / ASM_BAND_TPH;      // helper workgroups: one per trailing tile
+            asmb::launch_resident(k_chol_panel_band, dim3((unsigned)(nrt + nhelp)), dim3(256), 0, cur, fS, fld, I0, I1, Mi, (const double*)h->d_diag0, thr,
+                                  fLinv, h->d_pflags, h->d_ptmo, h->panel_epoch, nrt);
+            end(pid);
+        }
+    }
     void chol_launches(int Ms, double thr) {
+        if (band_panels_ok(Ms)) { chol_launches_band(Ms, thr); return; }
         // Two-level right-looking blocking with look-ahead.  64-wide steps inside a 1024-wide outer panel touch only the
         // panel's own columns; the trailing matrix is read-modify-written once per outer panel (K = 1024), in two parts:
         // (a) the columns of the NEXT outer panel, (b) the rest.  The next panel's serial block chain then runs on a second

@@ -898,18 +898,39 @@ __device__ __forceinline__ void pnl_wait(unsigned* flag, unsigned epoch, unsigne
     }
     __syncthreads();
 }
+// the same wait for helper workgroups (k_chol_panel_inv, k_chol_panel_band), which are not on the critical path of the factorisation
+__device__ __forceinline__ void pnl_wait_helper(unsigned* flag, unsigned epoch, unsigned* tmo) {
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+            __builtin_amdgcn_s_sleep(24);          // helpers are not on the critical path of the factorisation: they poll rarely
+            ++spins;
+            if (spins > (1u << 20) || ((spins & 63u) == 0 && __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
 // test hook: workgroups waiting for a flag that no producer of the launch sets (the bounded spin must end and report)
 __global__ __launch_bounds__(256) void k_pnl_wait_probe(AsmBt abt, unsigned* flag, unsigned epoch, unsigned* tmo) {
     ASM_BARGS(abt, flag, epoch, tmo);
     pnl_wait(flag, epoch, tmo);
 }
 #define ASM_PNL_LDS (2 * ASM_NB * ASM_XP + 4 * 16 * 17 + 2 * ASM_NB)
+#define ASM_PNL_NRT 40      // BAND variant: most row tiles of one launch (panel + reach of the band)
 #define ASM_PNL_NS 10       // most 64-wide steps of one panel launch: eight, or up to ten when the last inner panel absorbs a short remainder (flag words: NS for the diagonal blocks + NS * NS for the panel tiles)
 // Register budget: two wavefronts per SIMD = 256 registers per lane, AGPRs included.  The panel kernel runs beside k_syrk_upd
 // (256 per wavefront, two per SIMD): a panel wavefront must fit into the slot ONE retiring update wavefront frees.  Left to
 // itself the compiler takes 256 VGPRs + 56 AGPRs (occupancy 1 is allowed for a 256-thread kernel), such a wavefront fits
 // nowhere while updates are queued and the look-ahead chain starts only after the whole trailing update (measured at
 // M = 18637: first panel launch 5.2 ms instead of 1.0 ms).
+// BAND: the variant for banded factors whose trailing update runs inside the launch too (k_chol_panel_band below): every solved panel tile is
+// published (flag stride ASM_PNL_NRT), not only those of the panel's own diagonal rows.
+template <bool BAND>
 __device__ __forceinline__ void chol_panel_body(double* __restrict__ sm, double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms,
                                                 const double* __restrict__ diag0, double thr, double* __restrict__ Linv,
                                                 unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch, const int G, const int wg) {
@@ -987,12 +1008,12 @@ __device__ __forceinline__ void chol_panel_body(double* __restrict__ sm, double*
                     B0[row * ASM_XP + col] = acc[t][r];
                     if (gi < Ms && col < nb) {
                         double* dst = S + (int64_t)gi * ldS + k0 + col;
-                        if (rt < nsteps) __hip_atomic_store(dst, acc[t][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // operand for others
+                        if (BAND || rt < nsteps) __hip_atomic_store(dst, acc[t][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // operand for others
                         else *dst = acc[t][r];
                     }
                 }
             QSTAMP(k == 1 && rt == 2);
-            if (rt < nsteps) pnl_publish(flags + ASM_PNL_NS + ASM_PNL_NS * k + rt, epoch);      // a later diagonal row tile: its X is an operand for others
+            if (BAND || rt < nsteps) pnl_publish(flags + ASM_PNL_NS + (BAND ? ASM_PNL_NRT : ASM_PNL_NS) * k + rt, epoch);      // a later diagonal row tile (BAND: any row tile): its X is an operand for others
             else __syncthreads();
             QSTAMP(k == 1 && rt == 2);
             // ---- rank-64 update of the panel's remaining column tiles tj = k+1 .. min(rt, nsteps-1)
@@ -1001,7 +1022,7 @@ __device__ __forceinline__ void chol_panel_body(double* __restrict__ sm, double*
                 const int c0 = I0 + tj * ASM_NB, c_end = min(c0 + ASM_NB, min(I1, Ms));
                 const double* Pb = B0;
                 if (tj != rt) {
-                    pnl_wait(flags + ASM_PNL_NS + ASM_PNL_NS * k + tj, epoch, tmo);
+                    pnl_wait(flags + ASM_PNL_NS + (BAND ? ASM_PNL_NRT : ASM_PNL_NS) * k + tj, epoch, tmo);
                     {
                         double tv[ASM_NB * ASM_NB / 256];
 #pragma unroll
@@ -1070,12 +1091,104 @@ __device__ __forceinline__ void chol_panel_body(double* __restrict__ sm, double*
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chol_panel(AsmBt abt, double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms, const double* __restrict__ diag0, double thr, double* __restrict__ Linv, unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch) {
     ASM_BARGS(abt, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch);
     __shared__ __attribute__((aligned(16))) double sm[ASM_PNL_LDS];
-    chol_panel_body(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, (int)gridDim.x, (int)blockIdx.x);
+    chol_panel_body<false>(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, (int)gridDim.x, (int)blockIdx.x);
 }
 __global__ __launch_bounds__(256) void k_chol_panel_solo(AsmBt abt, double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms, const double* __restrict__ diag0, double thr, double* __restrict__ Linv, unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch) {
     ASM_BARGS(abt, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch);
     __shared__ __attribute__((aligned(16))) double sm[ASM_PNL_LDS];
-    chol_panel_body(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, (int)gridDim.x, (int)blockIdx.x);
+    chol_panel_body<false>(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, (int)gridDim.x, (int)blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Banded factors (the S0 = A_EF A_EF' of the null-space form in reverse Cuthill-McKee order: 10 673 rows, band 1 398 at case1354pegase
+// size): the whole step of the blocked factorisation for one 512-wide panel in ONE launch.  Everything the panel reaches lies within
+// `band` rows of its last column (Ms = that limit here), i.e. ~30 row tiles, and the rank-512 update of the tiles behind the panel - two
+// k_syrk launches of 60-70 us on the factorisation's chain per 1024 columns before - is a few hundred 64 x 64 tiles with eight 64^3
+// products each.  Helper workgroups (behind the main ones in the grid, one per trailing tile (rt, ct), ct >= the panel's steps) subtract
+// X(rt, k) X(ct, k)' as the solved tiles of step k arrive (every panel tile is published in this variant) and store the tile once.  After
+// the last step's panel solve two products remain.  The helpers only wait for main workgroups; all workgroups must be resident.
+#define ASM_BAND_TPH 1      // trailing tiles per helper workgroup (2 and 3 - all workgroups then fit one per CU - measured the same within 0.3 %, with 159 spilled registers)
+__device__ __forceinline__ void chol_band_update_tile(double* __restrict__ sm, double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms,
+                                                      unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch, int hx, int nhelp) {
+    double* Pa = sm;
+    double* Pb = sm + ASM_NB * ASM_XP;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nsteps = (I1 - I0 + ASM_NB - 1) / ASM_NB;
+    const int nrt = (Ms - I0 + ASM_NB - 1) / ASM_NB, m = nrt - nsteps, ntiles = m * (m + 1) / 2;
+    // trailing tiles in rows of a triangle: index -> (a, b), b <= a;  rt = nsteps + a, ct = nsteps + b.  This workgroup owns the tiles hx, hx + nhelp, ...
+    int rtv[ASM_BAND_TPH], ctv[ASM_BAND_TPH];
+    v4f64 acc[ASM_BAND_TPH][4];
+#pragma unroll
+    for (int j = 0; j < ASM_BAND_TPH; ++j) {
+        const int ti = hx + j * nhelp;
+        int a = 0;
+        while ((a + 1) * (a + 2) / 2 <= ti) ++a;
+        rtv[j] = ti < ntiles ? nsteps + a : -1;
+        ctv[j] = nsteps + (ti - a * (a + 1) / 2);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = I0 + rtv[j] * ASM_NB + w * 16 + (lane >> 4) + 4 * r, col = I0 + ctv[j] * ASM_NB + t * 16 + (lane & 15);
+                const int rc = max(0, min(row, Ms - 1));
+                const double v = S[(int64_t)rc * ldS + max(0, min(col, rc))];
+                acc[j][t][r] = ((rtv[j] >= 0) & (row < Ms) & (col <= row)) ? v : 0.0;
+            }
+    }
+    for (int k = 0; k < nsteps; ++k) {
+        const int k0 = I0 + k * ASM_NB;
+        const int nb = min(ASM_NB, Ms - k0);
+#pragma unroll
+        for (int j = 0; j < ASM_BAND_TPH; ++j) {
+            if (rtv[j] < 0) continue;                 // (uniform over the workgroup)
+            const int r0 = I0 + rtv[j] * ASM_NB, c0 = I0 + ctv[j] * ASM_NB;
+            pnl_wait_helper(flags + ASM_PNL_NS + ASM_PNL_NRT * k + rtv[j], epoch, tmo);
+            if (ctv[j] != rtv[j]) pnl_wait_helper(flags + ASM_PNL_NS + ASM_PNL_NRT * k + ctv[j], epoch, tmo);
+            double pv[ASM_NB * ASM_NB / 256], qv[ASM_NB * ASM_NB / 256];
+#pragma unroll
+            for (int it = 0; it < ASM_NB * ASM_NB / 256; ++it) {
+                const int e = tid + 256 * it, rr = e >> 6, c = e & 63;
+                pv[it] = S[(int64_t)min(r0 + rr, Ms - 1) * ldS + k0 + min(c, nb - 1)];
+                qv[it] = S[(int64_t)min(c0 + rr, Ms - 1) * ldS + k0 + min(c, nb - 1)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                          // the previous product has consumed the LDS images
+#pragma unroll
+            for (int it = 0; it < ASM_NB * ASM_NB / 256; ++it) {
+                const int e = tid + 256 * it, rr = e >> 6, c = e & 63;
+                Pa[rr * ASM_XP + c] = ((r0 + rr < Ms) & (c < nb)) ? -pv[it] : 0.0;
+                Pb[rr * ASM_XP + c] = ((c0 + rr < Ms) & (c < nb)) ? qv[it] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int kk = 0; kk < ASM_NB; kk += 4) {
+                double af = Pa[(w * 16 + (lane & 15)) * ASM_XP + kk + (lane >> 4)];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    double bf = Pb[(t * 16 + (lane & 15)) * ASM_XP + kk + (lane >> 4)];
+                    acc[j][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc[j][t], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < ASM_BAND_TPH; ++j) {
+        if (rtv[j] < 0) continue;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = I0 + rtv[j] * ASM_NB + w * 16 + (lane >> 4) + 4 * r, col = I0 + ctv[j] * ASM_NB + t * 16 + (lane & 15);
+                if (row < Ms && col <= row) S[(int64_t)row * ldS + col] = acc[j][t][r];
+            }
+    }
+}
+// (two wavefronts per SIMD like k_chol_panel: main + helper workgroups are up to ~360 and must all be resident, two per CU)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chol_panel_band(AsmBt abt, double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms, const double* __restrict__ diag0, double thr, double* __restrict__ Linv, unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch, int G) {
+    ASM_BARGS(abt, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, G);
+    __shared__ __attribute__((aligned(16))) double sm[ASM_PNL_LDS];
+    if ((int)blockIdx.x < G) chol_panel_body<true>(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, G, (int)blockIdx.x);
+    else chol_band_update_tile(sm, S, ldS, I0, I1, Ms, flags, tmo, epoch, (int)blockIdx.x - G, (int)gridDim.x - G);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1090,23 +1203,7 @@ __global__ __launch_bounds__(256) void k_chol_panel_solo(AsmBt abt, double* __re
 // read as zero).  Helpers come after the main workgroups in the grid and only wait for workgroups with smaller indices.
 #define ASM_PNL_FW (ASM_PNL_NS * (ASM_PNL_NS + 1))
 #define ASM_PNL_WT 16          // most 64-blocks of one wide block (wb <= 1024)
-#define ASM_PNL_FLAGS (ASM_PNL_FW + ASM_PNL_NS * ASM_PNL_WT)
-__device__ __forceinline__ void pnl_wait_helper(unsigned* flag, unsigned epoch, unsigned* tmo) {
-    if (threadIdx.x == 0) {
-        unsigned spins = 0;
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-            __builtin_amdgcn_s_sleep(24);          // helpers are not on the critical path of the factorisation: they poll rarely
-            ++spins;
-            if (spins > (1u << 20) || ((spins & 63u) == 0 && __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-}
+#define ASM_PNL_FLAGS (ASM_PNL_NS * (ASM_PNL_NRT + 1) > ASM_PNL_FW + ASM_PNL_NS * ASM_PNL_WT ? ASM_PNL_NS * (ASM_PNL_NRT + 1) : ASM_PNL_FW + ASM_PNL_NS * ASM_PNL_WT)
 __device__ __forceinline__ void chol_inv_tile(double* __restrict__ sm, const double* __restrict__ S, int64_t ldS, int I0, int Ms, const double* __restrict__ Linv,
                                               unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch, double* __restrict__ X, double* __restrict__ XT,
                                               int wb, int hx) {
@@ -1212,7 +1309,7 @@ __device__ __forceinline__ void chol_inv_tile(double* __restrict__ sm, const dou
 __global__ __launch_bounds__(256) void k_chol_panel_inv(AsmBt abt, double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms, const double* __restrict__ diag0, double thr, double* __restrict__ Linv, unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch, double* __restrict__ Binv, double* __restrict__ BinvT, int wb, int G) {
     ASM_BARGS(abt, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, Binv, BinvT, wb, G);
     __shared__ __attribute__((aligned(16))) double sm[ASM_PNL_LDS];
-    if ((int)blockIdx.x < G) chol_panel_body(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, G, (int)blockIdx.x);
+    if ((int)blockIdx.x < G) chol_panel_body<false>(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, G, (int)blockIdx.x);
     else chol_inv_tile(sm, S, ldS, I0, Ms, Linv, flags, tmo, epoch, Binv, BinvT, wb, (int)blockIdx.x - G);
 }
 
