@@ -303,6 +303,7 @@ struct asm_handle {
     bool spin_read = true;          // ASM_HIP_SPIN=0: hipMemcpyAsync + hipStreamSynchronize instead (14.5 us per read-back instead of 6.7 us)
     int* d_idx = nullptr;
     double* h_pin = nullptr;        // pinned staging (max(ldn, Mp) doubles) x 2
+    double* h_up = nullptr;         // pinned staging of the LP vectors an LP uploads (3 ldn + Mp + 3 nsp doubles, zero beyond the vectors' lengths)
     int64_t pin_len = 0;
 
     // ---- host copies of the evaluation results (slp.jl:8-21) ----
@@ -1164,6 +1165,27 @@ struct Solver {
     void ipm_upload_lp() {
         ipm_bind();
         P.n = lp.n; P.M = lp.M; P.ns = lp.ns; P.scale_q = lp.scale_q;
+        if (!asmb::in_fiber() && h->h_up) {
+            // seven vectors as three copies from pinned staging (q | lb | ub and w | slo | scoef are neighbours in the arena): a copy from a
+            // pageable std::vector is staged by the runtime and blocks the host for tens of microseconds each, twice per LP
+            const int64_t ln = h->ldn, lm = h->Mp, ls = h->nsp;
+            double* st = h->h_up;
+            std::memcpy(st, lp.q.data(), lp.n * sizeof(double));
+            std::memcpy(st + ln, lp.lb.data(), lp.n * sizeof(double));
+            std::memcpy(st + 2 * ln, lp.ub.data(), lp.n * sizeof(double));
+            std::memcpy(st + 3 * ln, lp.r.data(), lp.M * sizeof(double));
+            HIPCHK(hipMemcpyAsync((void*)P.q, st, 3 * ln * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync((void*)P.r, st + 3 * ln, lp.M * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            if (lp.ns) {
+                double* ss = st + 3 * ln + lm;
+                std::memcpy(ss, lp.w.data(), lp.ns * sizeof(double));
+                std::memcpy(ss + ls, lp.slo.data(), lp.ns * sizeof(double));
+                std::memcpy(ss + 2 * ls, h->scoef.data(), lp.ns * sizeof(double));
+                HIPCHK(hipMemcpyAsync((void*)P.w, ss, 3 * ls * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            }
+            h2d_done(h);
+            return;
+        }
         up(P.q, lp.q); up(P.lb, lp.lb); up(P.ub, lp.ub); up(P.r, lp.r);
         up(P.w, lp.w); up(P.slo, lp.slo);
         vec sc(h->scoef.begin(), h->scoef.begin() + lp.ns);
@@ -1416,9 +1438,15 @@ struct Solver {
         int64_t nF = 0;
         for (int64_t j = 0; j < n; ++j) nF += lp.ub[j] > lp.lb[j];
         {
-            vec fm(h->ldn, 0.0);
-            for (int64_t j = 0; j < n; ++j) fm[j] = lp.ub[j] > lp.lb[j] ? 1.0 : 0.0;
-            HIPCHK(hipMemcpyAsync(h->d_nsFm, fm.data(), h->ldn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            if (!asmb::in_fiber()) {                // (pinned staging: the copy does not go through the runtime's pageable path)
+                double* fm = h->h_pin;
+                for (int64_t j = 0; j < h->ldn; ++j) fm[j] = (j < n && lp.ub[j] > lp.lb[j]) ? 1.0 : 0.0;
+                HIPCHK(hipMemcpyAsync(h->d_nsFm, fm, h->ldn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            } else {
+                vec fm(h->ldn, 0.0);
+                for (int64_t j = 0; j < n; ++j) fm[j] = lp.ub[j] > lp.lb[j] ? 1.0 : 0.0;
+                HIPCHK(hipMemcpyAsync(h->d_nsFm, fm.data(), h->ldn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            }
             h2d_done(h);
         }
         double t_v = now_ms();
@@ -2650,6 +2678,8 @@ void free_device(asm_handle* h) {
     if (h->h_nsdots) (void)hipHostFree(h->h_nsdots);
     h->d_Zbuf = h->d_nsu = h->d_nsdots = h->h_nsdots = nullptr;
     if (h->h_pin) (void)hipHostFree(h->h_pin);
+    if (h->h_up) (void)hipHostFree(h->h_up);
+    h->h_up = nullptr;
     h->d_perm = h->d_ustart = h->d_uoff = h->d_adjoff = nullptr;
     h->d_dE = h->d_J = h->d_Ah = h->d_S = h->d_c = h->d_rho = h->d_theta = h->d_diag = h->d_diag0 = nullptr;
     h->d_vecN = h->d_vecM = h->d_vecM2 = h->d_partial = nullptr;
@@ -2958,6 +2988,8 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     }
     h->pin_len = std::max(std::max(h->ldn, h->Mp), h->nsp);
     HIPCHK(hipHostMalloc((void**)&h->h_pin, 2 * h->pin_len * sizeof(double)));
+    HIPCHK(hipHostMalloc((void**)&h->h_up, (3 * h->ldn + h->Mp + 3 * h->nsp + 16) * sizeof(double)));
+    std::memset(h->h_up, 0, (3 * h->ldn + h->Mp + 3 * h->nsp + 16) * sizeof(double));
     HIPCHK(hipMemsetAsync(h->d_J, 0, h->Mp * h->ldn * sizeof(double), h->stream));
     HIPCHK(hipMemsetAsync(h->d_Ah, 0, h->Mp * h->ldn * sizeof(double), h->stream));
     HIPCHK(hipMemsetAsync(h->d_vecN, 0, h->ldn * sizeof(double), h->stream));
