@@ -1667,7 +1667,7 @@ struct Solver {
         double *dpb = nsv(0), *kdpb = nsv(1), *atw = nsv(4), *yM = nsv(5), *aM = nsv(6);
         const double* th = h->d_nsth;
         const double* thI = h->d_nsth + ldn;
-        hipLaunchKernelGGL(k_ns_theta, dim3((unsigned)((std::max<int64_t>(ldn, h->ns_nIp) + 255) / 256)), dim3(256), 0, h->stream, P, X, IPM_RHO_P, h->d_nsth, ldn, h->ns_nIp);
+        // (theta~ was formed with the interior-point theta: k_ipm_theta_ns in ipm_run)
         dev.use_factor(h->ns_fN);
         int id = dev.begin(ASM_K_SYRK, (double)k * (k + 1) * h->ns_ldg, 8.0 * (k * (double)h->ns_ldg + 0.5 * k * (double)k));
         // the k range (free columns + inequality rows, 19 000 at n = 11 192) is long and the matrix small (k = 519: 45 tiles of 64 x 64):
@@ -1682,13 +1682,13 @@ struct Solver {
             dev.launch_syrk(T, h->d_nsG, h->ns_ldg, nullptr, 0, k, (int)h->ns_ldg, h->d_nsth, nullptr, h->d_nsNp, h->ns_fN.ld, 0, 0, -1, nullptr, 0, -1.0, nsplit, pstride);
             dev.end(id);
             hipLaunchKernelGGL(k_ns_reduce_lower, dim3((unsigned)((k + 255) / 256), (unsigned)k), dim3(256), 0, h->stream, (const double*)h->d_nsNp, nsplit, pstride, h->ns_fN.ld,
-                               h->ns_fN.S, h->d_nsN0, k, k <= ASM_SMALL_USE ? 1 : 0);
+                               h->ns_fN.S, h->d_nsN0, k, k <= ASM_SMALL_USE ? 1 : 0, h->d_diag0, 1e-13, 1e-30);      // (+ k_diag_prepare, mode 0)
         } else {
             dev.launch_syrk(Dev::pick_tile(k), h->d_nsG, h->ns_ldg, nullptr, 0, k, (int)h->ns_ldg, h->d_nsth, nullptr, h->ns_fN.S, h->ns_fN.ld, 0, 0);
             dev.end(id);
             hipLaunchKernelGGL(k_ns_copy_lower, dim3((unsigned)((k + 255) / 256), (unsigned)k), dim3(256), 0, h->stream, (const double*)h->ns_fN.S, h->ns_fN.ld, h->d_nsN0, h->ns_fN.ld, k, k <= ASM_SMALL_USE ? 1 : 0);
+            dev.diag_prepare(k, 0, 1e-13, 1e-30);
         }
-        dev.diag_prepare(k, 0, 1e-13, 1e-30);
         dev.chol(k, 1e-14, false);
         // dpbar = -e: the component of the iterate outside pbar + null(A_EF), split off once per LP and shrunk by (1 - a) with every step
         double* e = nsv(14);
@@ -1702,8 +1702,8 @@ struct Solver {
         }
         // (fused launches: negation + clearing of the residual measure; sparse product + its row- / column-wise kernel)
         const double* vals = dev.sparse_vals(h->d_Ah);
-        hipLaunchKernelGGL(k_ns_neg_clear, dim3(gN), dim3(256), 0, h->stream, (const double*)e, dpb, ldn, P.scal + SC_NSERR);
-        hipLaunchKernelGGL(k_ns_spmvn_wm, dim3(gM), dim3(256), 0, h->stream, (const int*)h->d_sp_ptr, (const int*)h->d_sp_col, vals, (const double*)dpb, X, thI, yM, M);
+        hipLaunchKernelGGL(k_ns_spmvn_wm_neg, dim3(std::max(gM, gN)), dim3(256), 0, h->stream, (const int*)h->d_sp_ptr, (const int*)h->d_sp_col, vals, (const double*)e, dpb, ldn,
+                           P.scal + SC_NSERR, X, thI, yM, M);
         hipLaunchKernelGGL(k_ns_spmvt_kx, dim3((unsigned)((ldn * 8 + 255) / 256)), dim3(256), 0, h->stream, (const int*)h->d_sc_ptr, (const int*)h->d_sc_row, (const int*)h->d_sc_pos, vals,
                            (const double*)yM, th, (const double*)dpb, kdpb, lp.n, ldn);
         (void)aM; (void)atw;
@@ -1739,8 +1739,12 @@ struct Solver {
             hipLaunchKernelGGL(k_ns_symv_res, dim3((unsigned)((k + 3) / 4)), dim3(256), 0, h->stream, (const double*)h->d_nsN0, h->ns_fN.ld, k, (const double*)du, (const double*)ru, rr);
             hipLaunchKernelGGL(k_ns_relres, dim3(1), dim3(1024), 0, h->stream, (const double*)rr, (const double*)ru, k, P.scal + SC_NSERR);
         }
-        ns_gemv_t_dense(du, k, v);
-        hipLaunchKernelGGL(k_ns_dp, dim3(gN), dim3(256), 0, h->stream, P, D, th, (const double*)dpb, res, (const double*)v, ldn);
+        if (k <= ASM_SMALL_USE) {
+            hipLaunchKernelGGL(k_gemv_t_small_dp, dim3(gN), dim3(256), 0, h->stream, (const double*)h->d_nsG, h->ns_ldg, k, (const double*)du, P, D, th, (const double*)dpb, res, ldn);
+        } else {
+            ns_gemv_t_dense(du, k, v);
+            hipLaunchKernelGGL(k_ns_dp, dim3(gN), dim3(256), 0, h->stream, P, D, th, (const double*)dpb, res, (const double*)v, ldn);
+        }
         hipLaunchKernelGGL(k_ns_spmvn_rows, dim3(gM), dim3(256), 0, h->stream, (const int*)h->d_sp_ptr, (const int*)h->d_sp_col, vals, P, D, X, thI, (const double*)bI, yM);
         (void)aM; (void)atw;
     }
@@ -1878,7 +1882,11 @@ struct Solver {
                 if (ns_live()) ns_finish_y();
                 return ip.status = ASM_OTHER;
             }
-            hipLaunchKernelGGL(k_ipm_theta, dim3(grid_all()), dim3(256), 0, h->stream, P, IPM_RHO_P);
+            if (ip.ns_ok && !ip.ns_off)      // null-space form: its theta~ in the same launch (ns_iter_setup)
+                hipLaunchKernelGGL(k_ipm_theta_ns, dim3(std::max(grid_all(), (unsigned)((std::max<int64_t>(h->ldn, h->ns_nIp) + 255) / 256))), dim3(256), 0, h->stream, P, IPM_RHO_P, nsX(), h->d_nsth, h->ldn,
+                                   h->ns_nIp);
+            else
+                hipLaunchKernelGGL(k_ipm_theta, dim3(grid_all()), dim3(256), 0, h->stream, P, IPM_RHO_P);
             // column form (oracle: IPM.run): K = Th + Ah' D^-1 Ah (n x n) while its Sherman-Morrison-Woodbury preconditioner
             // keeps the CG short, the row form S = Ah Th^-1 Ah' + D (M x M) otherwise
             use_red = false;

@@ -270,6 +270,34 @@ __global__ __launch_bounds__(256) void k_ns_theta(AsmBt abt, IpmPtrs P, NsIdx X,
     if (t < nIp) th[ldn + t] = t < X.nI ? 1.0 / P.dS[X.Iidx[t]] : 0.0;
 }
 
+// k_ipm_theta + k_ns_theta in one launch (the reciprocal of dS on the inequality rows is formed from the row's own terms: another thread of
+// this launch writes P.dS)
+__global__ __launch_bounds__(256) void k_ipm_theta_ns(AsmBt abt, IpmPtrs P, double rho_p, NsIdx X, double* __restrict__ th, int64_t ldn, int nIp) {
+    ASM_BARGS(abt, P, rho_p, X, th, ldn, nIp);
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    auto dS_of = [&](int64_t i) {
+        double d = P.rtype[i] != 0 ? P.g[i] / P.pi[i] : 0.0;
+        if (P.ns) {
+            const int k0 = P.rs0[i], k1 = P.rs1[i];
+            if (k0 >= 0) d += P.ts[k0] / P.mus[k0];
+            if (k1 >= 0) d += P.ts[k1] / P.mus[k1];
+        }
+        return d;
+    };
+    if (t < P.n) {
+        const bool fr = P.ub[t] > P.lb[t];
+        P.thp_inv[t] = fr ? 1.0 / (P.muL[t] / P.tL[t] + P.muU[t] / P.tU[t] + rho_p) : 0.0;
+    }
+    if (t < P.ns) P.ths_inv[t] = P.ts[t] / P.mus[t];
+    if (t < P.M) P.dS[t] = dS_of(t);
+    if (t < ldn) {
+        double v = 0.0;
+        if (t < P.n && P.ub[t] > P.lb[t]) v = P.muL[t] / P.tL[t] + P.muU[t] / P.tU[t] + rho_p;
+        th[t] = v;
+    }
+    if (t < nIp) th[ldn + t] = t < X.nI ? 1.0 / dS_of(X.Iidx[t]) : 0.0;
+}
+
 // ---- vector kernels of the null-space Newton solve (oracle: IPM.run, solve_ns).  thI = theta~ + ldn = D_I^-1 by position in I.
 // out[e] = scale * r[Eidx[e]]
 __global__ __launch_bounds__(256) void k_ns_gather_e(AsmBt abt, NsIdx X, const double* __restrict__ r, double scale, double* __restrict__ out) {
@@ -357,15 +385,17 @@ __global__ __launch_bounds__(256) void k_ns_copy_lower(AsmBt abt, const double* 
     }
 }
 // lower triangle of the sum of the split-K slices (fixed order), written to the factor buffer and to the unregularised copy
-__global__ __launch_bounds__(256) void k_ns_reduce_lower(AsmBt abt, const double* __restrict__ parts, int nsplit, int64_t pstride, int64_t ld, double* __restrict__ S, double* __restrict__ N0, int k, int full) {
-    ASM_BARGS(abt, parts, nsplit, pstride, ld, S, N0, k, full);
+__global__ __launch_bounds__(256) void k_ns_reduce_lower(AsmBt abt, const double* __restrict__ parts, int nsplit, int64_t pstride, int64_t ld, double* __restrict__ S, double* __restrict__ N0, int k, int full, double* __restrict__ diag0, double rel, double absv) {
+    ASM_BARGS(abt, parts, nsplit, pstride, ld, S, N0, k, full, diag0, rel, absv);
     const int i = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j <= i && j < k) {
         const int64_t o = (int64_t)i * ld + j;
         double v = parts[o];
         for (int s_ = 1; s_ < nsplit; ++s_) v += parts[(int64_t)s_ * pstride + o];
-        S[o] = v;
+        // diag0 != null: k_diag_prepare (mode 0) on the way - diag0[i] = S_ii, S_ii += rel S_ii + absv (the copy keeps the unregularised value)
+        S[o] = (diag0 && j == i) ? v + (rel * v + absv) : v;
+        if (diag0 && j == i) diag0[i] = v;
         N0[o] = v;
         if (full) N0[(int64_t)j * ld + i] = v;          // (see k_ns_copy_lower)
     }
@@ -498,6 +528,19 @@ __global__ __launch_bounds__(256) void k_ns_spmvn_wm(AsmBt abt, const int* __res
     if (i >= M) return;
     double acc = 0.0;
     for (int k = ptr[i]; k < ptr[i + 1]; ++k) acc += vals[k] * x[col[k]];
+    const int ip = X.Ipos[i];
+    wM[i] = ip >= 0 ? thI[ip] * acc : 0.0;
+}
+// k_ns_neg_clear + k_ns_spmvn_wm: dpbar = -e is formed on the way (stored by the first len threads), the products read -e directly
+__global__ __launch_bounds__(256) void k_ns_spmvn_wm_neg(AsmBt abt, const int* __restrict__ ptr, const int* __restrict__ col, const double* __restrict__ vals, const double* __restrict__ e,
+                                                         double* __restrict__ dpb, int64_t len, double* __restrict__ clear, NsIdx X, const double* __restrict__ thI, double* __restrict__ wM, int64_t M) {
+    ASM_BARGS(abt, ptr, col, vals, e, dpb, len, clear, X, thI, wM, M);
+    int64_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < len) dpb[i] = -e[i];
+    if (i == 0) *clear = 0.0;
+    if (i >= M) return;
+    double acc = 0.0;
+    for (int k = ptr[i]; k < ptr[i + 1]; ++k) acc += vals[k] * (-e[col[k]]);
     const int ip = X.Ipos[i];
     wM[i] = ip >= 0 ? thI[ip] * acc : 0.0;
 }
@@ -862,6 +905,27 @@ __global__ __launch_bounds__(256) void k_gemv_t_small(AsmBt abt, const double* _
     double acc = 0.0;
     for (int c = 0; c < k; ++c) acc = fma(Zt[(int64_t)c * ld + j], us[c], acc);
     out[j] = acc;
+}
+
+// k_gemv_t_small + k_ns_dp: zu[j] = sum_c Zt[c, j] u[c] goes straight into dp = res dpbar + Z du and the bound multipliers' directions
+__global__ __launch_bounds__(256) void k_gemv_t_small_dp(AsmBt abt, const double* __restrict__ Zt, int64_t ld, int k, const double* __restrict__ u, IpmPtrs P, IpmDir D, const double* __restrict__ th,
+                                                         const double* __restrict__ dpb, double res, int64_t ldn) {
+    ASM_BARGS(abt, Zt, ld, k, u, P, D, th, dpb, res, ldn);
+    __shared__ double us[ASM_SMALL_MAX];
+    for (int i = threadIdx.x; i < k; i += 256) us[i] = u[i];
+    __syncthreads();
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= ldn) return;
+    double acc = 0.0;
+    for (int c = 0; c < k; ++c) acc = fma(Zt[(int64_t)c * ld + t], us[c], acc);
+    double dp = 0.0, dL = 0.0, dU = 0.0;
+    if (t < P.n && th[t] != 0.0) {
+        dp = res * dpb[t] + acc;
+        dL = (P.rcL[t] - P.muL[t] * dp) / P.tL[t];
+        dU = (P.rcU[t] + P.muU[t] * dp) / P.tU[t];
+    }
+    D.dp[t] = dp;
+    if (t < P.n) { D.dmuL[t] = dL; D.dmuU[t] = dU; }
 }
 
 // ---- banded S0 = A_EF A_EF' built from its structural pattern (equality rows in reverse Cuthill-McKee order)
