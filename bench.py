@@ -610,12 +610,13 @@ def main():
     ks = opt.kernel_stats()
     trace = list(state.get("trace_all", []))        # (the all-families pass below appends to the live list)
     # ---- roofline.  Every launch of the two MFMA kernel families is timed with HIP events on the stream it runs on:
-    #   panel_kernel   k_chol_panel / k_chol_panel_solo: the 64-wide steps of the Cholesky factorisations (a dependent chain: latency-bound)
+    #   panel_kernel   k_chol_panel / _solo / _inv / _band: the 64-wide steps of the Cholesky factorisations (a dependent chain: latency-bound)
     #   syrk_kernel    k_syrk_upd + k_syrk<T>: rank-K updates of the factorisations and the Schur / reduced-matrix builds
     # `roofline` describes the family with the larger share of the step; both are listed under `families`.
     fams = {}
-    for key, label in (("panel_kernel", "k_chol_panel + k_chol_panel_solo (dataflow panel kernel: factor + inverse of the 64 x 64 diagonal block, panel solve, rank-64 "
-                                        "update per step; a dependent chain of 64-wide steps - latency-bound, the matrix pipe idles between them)"),
+    for key, label in (("panel_kernel", "k_chol_panel / _solo / _inv / _band (dataflow panel kernels: factor + inverse of the 64 x 64 diagonal block, panel solve, rank-64 "
+                                        "update per step; _inv also forms the explicit inverse of a one-wide-block factor and _band the whole trailing update of a "
+                                        "banded factor by helper workgroups; a dependent chain of 64-wide steps - latency-bound, the matrix pipe idles between them)"),
                        ("syrk_kernel", "k_syrk_upd + k_syrk<T> (f64 MFMA rank-K kernels: Cholesky updates, Schur and reduced-matrix builds)")):
         d = ks[key]
         a = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
