@@ -2489,7 +2489,8 @@ struct Solver {
         btag = 90;
         asmb::barrier(btag);
         ipm_init();
-        const double tols[3] = {1e-9, 1e-10, 1e-12};      // oracle: IPM_STAGES
+        static const double tol0_env = [] { const char* v = std::getenv("ASM_IPM_TOL0"); return v ? std::atof(v) : 3e-10; }();      // (measurement knob: tolerance of the first identification)
+        const double tols[3] = {tol0_env, 0.1 * tol0_env, 1e-12};      // oracle: IPM_STAGES
         const int more[3] = {IPM_MAXIT, 6, 6};
         bool have_sets = false;
         double best_m = INF, m_last = INF;

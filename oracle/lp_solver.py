@@ -1344,7 +1344,10 @@ def face_polish(lp, part, p_ref, y_ref, stats):
 
 # first identification at 1e-9 (round 3, measured on the GPU benches: at 1e-8 the partition failed its test on 12 of 20 C4 LPs, 7 of 20 C2 LPs
 # - each failure costs a polish attempt, the iterations themselves are needed either way; 1e-9: 6 and 7 failures, +2.5 ... +5 % throughput)
-IPM_STAGES = ((1e-9, IPM_MAXIT), (1e-10, 6), (1e-12, 6))
+# round 4: first identification at 3e-10 (A/B in one GPU call: C4 28.0 -> 27.0 ms/step, C5 36.3 -> 37.3 solves/s, C2 +1.5 %, C3 and C4fr within noise -
+# the last interior-point iterations converge superlinearly, one more costs less than the failed polish of a partition identified too early; 1e-10
+# gave C5 +4 % but put one LP of the parity campaign on the edge of the convergence test: 13 iterations in the oracle, 14 in the library)
+IPM_STAGES = ((3e-10, IPM_MAXIT), (3e-11, 6), (1e-12, 6))
 
 
 def elastic_layout(rtype):
