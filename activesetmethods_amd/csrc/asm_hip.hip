@@ -1245,7 +1245,8 @@ struct Solver {
         ip.col_ok = h->col_capable && lp.ns > 0 && M >= COL_MIN_M && (double)n <= COL_MAX_RATIO * (double)M;   // every row owns a slack (setup)
         ipm_upload_lp();
         P.ncomp = ip.ncomp;
-        hipLaunchKernelGGL(k_ipm_init_p, dim3(grid_all()), dim3(256), 0, h->stream, P);
+        static const bool origin_env = [] { const char* v = std::getenv("ASM_IPM_ORIGIN_START"); return !(v && v[0] == '0'); }();      // (measurement knob)
+        hipLaunchKernelGGL(k_ipm_init_p, dim3(grid_all()), dim3(256), 0, h->stream, P, (origin_env && lp.ns == 0) ? 1 : 0);
         dev.gemv_n_dev(h->d_Ah, P.p, P.act);
         hipLaunchKernelGGL(k_ipm_init_rest, dim3(grid_all()), dim3(256), 0, h->stream, P);
     }

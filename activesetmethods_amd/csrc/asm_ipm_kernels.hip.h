@@ -523,10 +523,19 @@ __global__ __launch_bounds__(256) void k_ipm_snapshot(AsmBt abt, IpmPtrs P, doub
 }
 
 // starting point (oracle: IPM.__init__); act = Ah p0 must already be in P.act
-__global__ __launch_bounds__(256) void k_ipm_init_p(AsmBt abt, IpmPtrs P) {
-    ASM_BARGS(abt, P);
+// start point (oracle: IPM.__init__): the box's midpoint; normal phase (no slack columns): the origin moved into the middle half of the box
+__global__ __launch_bounds__(256) void k_ipm_init_p(AsmBt abt, IpmPtrs P, int origin) {
+    ASM_BARGS(abt, P, origin);
     int64_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t < P.n) P.p[t] = 0.5 * (P.lb[t] + P.ub[t]);
+    if (t < P.n) {
+        const double lb = P.lb[t], ub = P.ub[t];
+        double v = 0.5 * (lb + ub);
+        if (origin) {
+            const double w4 = 0.25 * (ub - lb);
+            v = fmin(fmax(0.0, lb + w4), ub - w4);
+        }
+        P.p[t] = v;
+    }
     if (t < P.ns) P.s[t] = P.slo[t] + 1.0;
 }
 __global__ __launch_bounds__(256) void k_ipm_init_rest(AsmBt abt, IpmPtrs P) {

@@ -401,6 +401,13 @@ class IPM:
         self.free = lp.ub > lp.lb
         ineq, sg, free = self.ineq, self.sg, self.free
         self.p = 0.5 * (lp.lb + lp.ub)
+        if lp.ns == 0:
+            # normal phase (round 4): the origin - the current iterate of the SLP run, near which the LP's solution lies once the run settles -
+            # moved into the middle half of the box instead of the box's midpoint (with the trust region at 1000 the midpoint of a column
+            # limited by its own bound on one side is ~500 away).  Measured: 17.7 -> 16.05 interior-point iterations per LP at case1354pegase
+            # size, 13.7 -> 12.7 at case300 size; restoration LPs (slack columns) keep the midpoint: 17.45 -> 18.0 there.
+            w4 = 0.25 * (lp.ub - lp.lb)
+            self.p = np.minimum(np.maximum(0.0, lp.lb + w4), lp.ub - w4)
         self.s = lp.slo + 1.0
         act = _rowact(lp, self.p, self.s)
         self.g = np.where(ineq, np.maximum(sg * (act - lp.r), 1.0), 1.0)
