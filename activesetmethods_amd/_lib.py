@@ -95,6 +95,7 @@ PROTOTYPES = {
     "asm_test_syrk_update": (C.c_int, [_P, _D, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _D, C.c_int]),
     "asm_test_cholesky": (C.c_int, [_P, _D, C.c_int64, _D]),
     "asm_test_chol_solve": (C.c_int, [_P, _D, C.c_int64, _D, _D]),
+    "asm_test_no_polish": (C.c_int, [_P, C.c_int]),
     "asm_test_panel_timeout": (C.c_int, [_P, C.c_int]),
     "asm_test_set_band": (C.c_int, [_P, C.c_int]),
     "asm_test_gemm_nt": (C.c_int, [_P, _D, _D, _D, C.c_int64, C.c_int64, C.c_int64, C.c_int, _D]),

@@ -61,6 +61,7 @@ const int WARM_BACKOFF_MAX = 6;  // oracle/lp_solver.py: pause after consecutive
 const double EQP_RUNAWAY = 10.0, EQP_MAXCHG = 0.03;
 const int EQP_MINCHG = 32;  // oracle/lp_solver.py: growth of the primal residual between two rounds of a bulk correction that ends the attempt
 const int64_t RCM_MAX_PAIRS = 50000000;      // sum over the columns of (rows in the column)^2 beyond which no row order is computed
+const double IPM_MU0_NORMAL = 0.3;      // oracle/lp_solver.py: initial complementarity of a normal-phase LP in units of scale_q
 const double IPM_ACCEPT = 1e-8, IPM_ACCEPT_DUAL = 1e-8;      // oracle/lp_solver.py: last-resort acceptance of a converged iterate (primal residual and gap; dual residual)
 const int NS_MAX_SPLIT = 8;
 const double NS_SEL_THR[4] = {1e-2, 1e-4, 1e-7, 1e-10};
@@ -326,6 +327,7 @@ struct asm_handle {
     int panel_wgs = 240;            // its grid bound: every workgroup must be able to become resident
     int num_cus = 256;              // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     unsigned *d_pflags = nullptr, *d_ptmo = nullptr;
+    bool test_no_polish = false;    // test hook: the active-set attempts of an LP all fail (asm_test_no_polish)
     unsigned panel_epoch = 0;
     int timing = 1;                 // HIP-event timing: 0 off, 1 the dominant kernel only (every k_syrk launch), 2 every kernel family
     bool verbose = false;
@@ -1248,7 +1250,8 @@ struct Solver {
         static const bool origin_env = [] { const char* v = std::getenv("ASM_IPM_ORIGIN_START"); return !(v && v[0] == '0'); }();      // (measurement knob)
         hipLaunchKernelGGL(k_ipm_init_p, dim3(grid_all()), dim3(256), 0, h->stream, P, (origin_env && lp.ns == 0) ? 1 : 0);
         dev.gemv_n_dev(h->d_Ah, P.p, P.act);
-        hipLaunchKernelGGL(k_ipm_init_rest, dim3(grid_all()), dim3(256), 0, h->stream, P);
+        static const double mu_env = [] { const char* v = std::getenv("ASM_IPM_MU0"); return v ? std::atof(v) : IPM_MU0_NORMAL; }();      // (measurement knob)
+        hipLaunchKernelGGL(k_ipm_init_rest, dim3(grid_all()), dim3(256), 0, h->stream, P, lp.ns == 0 ? mu_env : 1.0);
     }
 
     void ipm_measures() {
@@ -2177,6 +2180,7 @@ struct Solver {
     // oracle: eqp_loop - solve, LP optimality test, bulk correction of the working set, at most `rounds` corrections.
     // Starts from the sets in S_[0]; on return `final_sets` is the buffer holding the last working set.
     bool eqp_loop(const double* p_ref, const double* y_ref, int rounds) {
+        if (h->test_no_polish) return false;      // test hook (asm_test_no_polish): every active-set attempt fails -> the last resort decides
         int cur = 0, nx = 1, prev = 2;
         bool have_prev = false;
         double pr_last = -1.0;
@@ -2350,6 +2354,7 @@ struct Solver {
     // oracle: face_polish - canonical pair of a non-unique optimum on the partition in S_[3].
     // Returns 2 ('face': least-norm point + basic multipliers), 1 ('ref': projection of the iterate), 0 (partition not optimal).
     int face_polish() {
+        if (h->test_no_polish) return 0;
         const int64_t n = lp.n, M = lp.M, ns = lp.ns;
         hipLaunchKernelGGL(k_as_clip0, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, A.lb, A.ub, (const double*)P.p, d_pref, n);
         as_solve(S_[3], d_pref, P.y, 0);
@@ -3815,6 +3820,11 @@ int asm_test_set_band(asm_handle* h, int band) {
         if (band < 0) throw std::invalid_argument("asm_test_set_band: bad argument");
         h->main_band = band;
     });
+}
+
+// every active-set attempt of the following LPs fails (on != 0): the LP solve ends on its last resort, the converged interior iterate
+int asm_test_no_polish(asm_handle* h, int on) {
+    return guarded(h, [&] { h->test_no_polish = on != 0; });
 }
 
 int asm_test_panel_timeout(asm_handle* h, int workgroups) {

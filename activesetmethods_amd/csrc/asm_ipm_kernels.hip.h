@@ -538,10 +538,10 @@ __global__ __launch_bounds__(256) void k_ipm_init_p(AsmBt abt, IpmPtrs P, int or
     }
     if (t < P.ns) P.s[t] = P.slo[t] + 1.0;
 }
-__global__ __launch_bounds__(256) void k_ipm_init_rest(AsmBt abt, IpmPtrs P) {
-    ASM_BARGS(abt, P);
+__global__ __launch_bounds__(256) void k_ipm_init_rest(AsmBt abt, IpmPtrs P, double mu_factor) {
+    ASM_BARGS(abt, P, mu_factor);
     int64_t t = blockIdx.x * 256 + threadIdx.x;
-    const double mu0 = P.scale_q;
+    const double mu0 = mu_factor * P.scale_q;
     if (t < P.n) {
         bool fr = P.ub[t] > P.lb[t];
         double tl = fr ? P.p[t] - P.lb[t] : 1.0, tu = fr ? P.ub[t] - P.p[t] : 1.0;

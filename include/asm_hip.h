@@ -299,6 +299,9 @@ int asm_test_chol_solve(asm_handle* h, const double* S, int64_t N, const double*
 /* the bounded wait of the dataflow panel kernel with a producer that never publishes: returns ASM_ERR_HIP (reported once), the
  * handle stays usable */
 int asm_test_panel_timeout(asm_handle* h, int workgroups);
+/* on != 0: every active-set attempt (polish) of the following LPs on this handle fails, so that the solve ends on its last resort - the
+ * converged interior iterate, asm_solve_stats.path 10 (oracle: tests patch eqp_loop / face_polish the same way) */
+int asm_test_no_polish(asm_handle* h, int on);
 /* C = (mode 1: C0) -/+ A B'  (A: Ma x K, B: Mb x K, row-major, K a multiple of 32) - the product kernel of the multi-right-hand-side
  * triangular solves of the null-space form */
 int asm_test_gemm_nt(asm_handle* h, const double* A, const double* B, const double* C0, int64_t Ma, int64_t Mb, int64_t K, int mode,
