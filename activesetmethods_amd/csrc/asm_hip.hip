@@ -1860,6 +1860,8 @@ struct Solver {
         hipLaunchKernelGGL(k_ipm_dir, dim3(g), dim3(256), 0, h->stream, P, D, d_tN);
     }
 
+    static int sig_exp() { static const int e = [] { const char* v = std::getenv("ASM_IPM_SIGEXP"); return v ? std::atoi(v) : 3; }(); return e; }      // (measurement knob)
+    static double eta0() { static const double e = [] { const char* v = std::getenv("ASM_IPM_ETA0"); return v ? std::atof(v) : 0.995; }(); return e; }
     int btag = 100;      // alignment tags of a scenario batch grow in program order inside one LP (asm_batch.hip.h)
     int ipm_run(double tol, int max_more) {
         const int M = (int)lp.M;
@@ -1978,7 +1980,7 @@ struct Solver {
                 cg_fail = false;
                 if (use_ns) ns_newton(0, dirA, dirA); else ipm_solve(0, dirA, dirA, 0.0, 0.0, deferred ? 1 : 0);
                 hipLaunchKernelGGL(k_ipm_steps, dim3(red_grid()), dim3(1024), 0, h->stream, P, dirA, 0u);
-                hipLaunchKernelGGL(k_ipm_muaff, dim3(red_grid()), dim3(1024), 0, h->stream, P, dirA);
+                hipLaunchKernelGGL(k_ipm_muaff, dim3(red_grid()), dim3(1024), 0, h->stream, P, dirA, sig_exp());
                 if (use_ns) ns_newton(1, dirA, dirC); else ipm_solve(1, dirA, dirC, 0.0, 0.0, deferred ? 2 : 0);
                 unsigned pub = pub_next();
                 hipLaunchKernelGGL(k_ipm_steps, dim3(red_grid()), dim3(1024), 0, h->stream, P, dirC, pub);
@@ -2019,7 +2021,7 @@ struct Solver {
                 ip.red_off = true;
                 continue;
             }
-            const double eta = ip.mu >= 1.0 ? 0.995 : std::min(std::max(0.995, 1.0 - ip.mu / lp.scale_q), 0.999999);
+            const double eta = ip.mu >= 1.0 ? eta0() : std::min(std::max(eta0(), 1.0 - ip.mu / lp.scale_q), 0.999999);
             if (use_ns)
                 hipLaunchKernelGGL(k_ns_update, dim3(grid_all()), dim3(256), 0, h->stream, P, dirC, std::min(1.0, eta * ap), std::min(1.0, eta * ad), nsv(14),
                                    1.0 - std::min(1.0, eta * ap), h->ldn);

@@ -417,8 +417,8 @@ __global__ __launch_bounds__(1024) void k_ipm_steps(AsmBt abt, IpmPtrs P, IpmDir
 }
 
 // mu_aff -> sigma = (mu_aff/mu)^3 -> sm = sigma mu
-__global__ __launch_bounds__(1024) void k_ipm_muaff(AsmBt abt, IpmPtrs P, IpmDir A) {
-    ASM_BARGS(abt, P, A);
+__global__ __launch_bounds__(1024) void k_ipm_muaff(AsmBt abt, IpmPtrs P, IpmDir A, int sexp) {
+    ASM_BARGS(abt, P, A, sexp);
     __shared__ double sh[16];
     __shared__ bool last;
     const double ap = P.scal[SC_AP], ad = P.scal[SC_AD];
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(1024) void k_ipm_muaff(AsmBt abt, IpmPtrs P, IpmDir
         double mu = P.scal[SC_MU];
         double mu_aff = acc / (double)P.ncomp;
         double r = mu > 0.0 ? mu_aff / mu : 0.0;
-        P.scal[SC_SM] = r * r * r * mu;
+        P.scal[SC_SM] = (sexp == 2 ? r * r : (sexp == 4 ? r * r * r * r : r * r * r)) * mu;      // Mehrotra's centring (r^3; 2 / 4: measurement knob)
     }
 }
 
