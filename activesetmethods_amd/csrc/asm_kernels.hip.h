@@ -232,15 +232,25 @@ template <int T, int NW, int KC, int WPE>
 __global__ __launch_bounds__(64 * NW, WPE) void k_syrk(AsmBt abt, const double* __restrict__ A, int64_t ld, const int* __restrict__ idx, int64_t row0, int Ms, int K, const double* __restrict__ theta, const double* __restrict__ diag, double* __restrict__ S, int64_t ldS, int64_t srow0, int mode, int MsB, int ntj, const unsigned char* __restrict__ nzflags, int nzpitch, int64_t ksplit) {
     ASM_BARGS(abt, A, ld, idx, row0, Ms, K, theta, diag, S, ldS, srow0, mode, MsB, ntj, nzflags, nzpitch, ksplit);
     constexpr int TS = 32 * T;
+    int slice_tile = -1;                      // >= 0: split-K with slice-major placement - the tile pair of this workgroup by plain triangular enumeration
     if (gridDim.y > 1) {
-        // split-K (small matrices with a long k range: the k x k Newton matrix of the null-space form): slice blockIdx.y of the
-        // chunks, summed into its own copy of S (`ksplit` doubles apart); the caller adds the copies in a fixed order
+        // split-K (small matrices with a long k range: the k x k Newton matrix of the null-space form): one slice of the
+        // chunks, summed into its own copy of S (`ksplit` doubles apart); the caller adds the copies in a fixed order.
+        // Placement: workgroups L, L + 8, ... share an XCD and its L2.  With a multiple of eight slices the workgroups of ONE slice are put
+        // on ONE XCD (slice = label + 8 * ...): the XCD streams that slice of the operand once for all its tile pairs instead of every
+        // XCD streaming the row blocks of its tile pairs over the whole k range (pure placement: any dispatch order is correct).
+        int sl = (int)blockIdx.y;
+        if (ntj == 0 && !nzflags && (gridDim.y & 7u) == 0u) {
+            const unsigned Lin = blockIdx.x + blockIdx.y * gridDim.x, q = Lin >> 3;
+            sl = (int)((Lin & 7u) + 8u * (q / gridDim.x));
+            slice_tile = (int)(q % gridDim.x);
+        }
         const int per = ((K / KC + (int)gridDim.y - 1) / (int)gridDim.y) * KC;
-        const int k0s = (int)blockIdx.y * per;
+        const int k0s = sl * per;
         A += k0s;
         if (theta) theta += k0s;
         K = max(0, min(per, K - k0s));
-        S += (int64_t)blockIdx.y * ksplit;
+        S += (int64_t)sl * ksplit;
     }
     // two LDS stages: the global loads of chunk c+1 are issued before the MFMAs of chunk c and written to the
     // other stage afterwards, so HBM/L2 latency hides under 16*T*T/4 matrix instructions; one barrier per chunk.
@@ -252,6 +262,13 @@ __global__ __launch_bounds__(64 * NW, WPE) void k_syrk(AsmBt abt, const double* 
         bi = blockIdx.x / ntj;
         bj = blockIdx.x - bi * ntj;
         if (bj > bi) return;
+    } else if (slice_tile >= 0) {
+        const int ntr = (Ms + TS - 1) / TS;
+        if (slice_tile >= ntr * (ntr + 1) / 2) return;
+        bi = (int)((sqrt(8.0 * (double)slice_tile + 1.0) - 1.0) * 0.5);
+        while ((bi + 1) * (bi + 2) / 2 <= slice_tile) ++bi;
+        while (bi * (bi + 1) / 2 > slice_tile) --bi;
+        bj = slice_tile - bi * (bi + 1) / 2;
     } else {
         if (!tri_tile_xcd((Ms + TS - 1) / TS, bi, bj, nzflags != nullptr)) return;
     }
