@@ -598,7 +598,12 @@ struct Dev {
         // 64 x 64 tiles leave CUs idle when there are few right-hand sides: 32-row tiles then (same sums, same order)
         const int64_t t64 = (int64_t)((Mb + 63) / 64) * ((Ma + 63) / 64);
         static const int ta_env = [] { const char* v = std::getenv("ASM_GEMM_TA"); return v ? std::atoi(v) : 0; }();
-        if ((ta_env == 32 || (ta_env == 0 && t64 < 2 * (int64_t)h->num_cus)) && Ma > 32)
+        // ... and 96 columns per workgroup when 32 x 64 tiles overshoot one workgroup per CU and 32 x 96 tiles do not
+        const int64_t t3264 = (int64_t)((Mb + 63) / 64) * ((Ma + 31) / 32), t3296 = (int64_t)((Mb + 95) / 96) * ((Ma + 31) / 32);
+        static const int tb_env = [] { const char* v = std::getenv("ASM_GEMM_TB"); return v ? std::atoi(v) : 0; }();
+        if ((ta_env == 32 || (ta_env == 0 && t64 < 2 * (int64_t)h->num_cus)) && Ma > 32 && (tb_env == 96 || (tb_env == 0 && t3264 > h->num_cus && t3296 <= h->num_cus)))
+            hipLaunchKernelGGL(k_gemm_nt32w, dim3((unsigned)((Mb + 95) / 96), (unsigned)((Ma + 31) / 32)), dim3(256), 0, h->stream, A, lda, B, ldb, C0, ldc0, C, ldc, Ma, Mb, K, mode);
+        else if ((ta_env == 32 || (ta_env == 0 && t64 < 2 * (int64_t)h->num_cus)) && Ma > 32)
             hipLaunchKernelGGL(k_gemm_nt32, dim3((unsigned)((Mb + 63) / 64), (unsigned)((Ma + 31) / 32)), dim3(256), 0, h->stream, A, lda, B, ldb, C0, ldc0, C, ldc, Ma, Mb, K, mode);
         else
             hipLaunchKernelGGL(k_gemm_nt, dim3((unsigned)((Mb + 63) / 64), (unsigned)((Ma + 63) / 64)), dim3(256), 0, h->stream, A, lda, B, ldb, C0, ldc0, C, ldc, Ma, Mb, K, mode);
@@ -3861,6 +3866,14 @@ int asm_test_gemm_nt(asm_handle* h, const double* A, const double* B, const doub
         HIPCHK(hipMemcpy(dA, A, Ma * K * sizeof(double), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(dB, B, Mb * K * sizeof(double), hipMemcpyHostToDevice));
         if (mode != 0) HIPCHK(hipMemcpy(dC, C0, Ma * Mb * sizeof(double), hipMemcpyHostToDevice));
+        const char* var = std::getenv("ASM_TEST_GEMM");      // tile variant under test: 32 (32 x 64), 32w (32 x 96), default 64 x 64
+        if (var && std::string(var) == "32w")
+            hipLaunchKernelGGL(k_gemm_nt32w, dim3((unsigned)((Mb + 95) / 96), (unsigned)((Ma + 31) / 32)), dim3(256), 0, h->stream, (const double*)dA, K, (const double*)dB, K,
+                               (const double*)(mode != 0 ? dC : nullptr), Mb, dC, Mb, (int)Ma, (int)Mb, (int)K, mode);
+        else if (var && std::string(var) == "32")
+            hipLaunchKernelGGL(k_gemm_nt32, dim3((unsigned)((Mb + 63) / 64), (unsigned)((Ma + 31) / 32)), dim3(256), 0, h->stream, (const double*)dA, K, (const double*)dB, K,
+                               (const double*)(mode != 0 ? dC : nullptr), Mb, dC, Mb, (int)Ma, (int)Mb, (int)K, mode);
+        else
         hipLaunchKernelGGL(k_gemm_nt, dim3((unsigned)((Mb + 63) / 64), (unsigned)((Ma + 63) / 64)), dim3(256), 0, h->stream, (const double*)dA, K, (const double*)dB, K,
                            (const double*)(mode != 0 ? dC : nullptr), Mb, dC, Mb, (int)Ma, (int)Mb, (int)K, mode);
         HIPCHK(hipStreamSynchronize(h->stream));

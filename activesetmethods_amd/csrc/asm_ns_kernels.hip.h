@@ -20,25 +20,27 @@
 // explicit inverse of a wide diagonal block).
 // TA = rows of A per workgroup: 64, or 32 when 64 x 64 tiles would leave CUs idle (519 right-hand sides against one wide block: 9 x 16 = 144
 // workgroups on 256 CUs; with 32-row tiles 17 x 16 = 272) - every entry of C is the same sum in the same order either way.
-template <int TA>
+// TB = columns of C (rows of B) per workgroup: 64, or 96 when that brings the grid down to one workgroup per CU (519 right-hand sides against
+// one wide block: 17 x 16 = 272 workgroups - sixteen CUs get a second one and the launch takes two workgroup times; 17 x 11 = 187 take 1.5).
+template <int TA, int TB = 64>
 __device__ __forceinline__ void gemm_nt_body(const double* __restrict__ A, int64_t lda, const double* __restrict__ B, int64_t ldb, const double* C0, int64_t ldc0, double* C, int64_t ldc, int Ma, int Mb, int K, int mode) {
-    constexpr int TS = 64, KC = 32, PITCH = KC + 2, NI = TA / 32, HA = TA / 2;
+    constexpr int TS = TB, KC = 32, PITCH = KC + 2, NI = TA / 32, HA = TA / 2, NJ = TB / 32, HB = TB / 2;
     __shared__ __attribute__((aligned(16))) double As[2][TA * PITCH];
     __shared__ __attribute__((aligned(16))) double Bs[2][TS * PITCH];
     const int bi = blockIdx.y, bj = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 1, wc = w & 1;
-    v4f64 acc[NI][2];
+    v4f64 acc[NI][NJ];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
             if (mode != 0 && C0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = bi * TA + wr * HA + i * 16 + (lane >> 4) + 4 * r;
-                    const int col = bj * TS + wc * 32 + j * 16 + (lane & 15);
+                    const int col = bj * TS + wc * HB + j * 16 + (lane & 15);
                     const double v = C0[(int64_t)min(row, Ma - 1) * ldc0 + min(col, Mb - 1)];
                     acc[i][j][r] = (row < Ma && col < Mb) ? v : 0.0;
                 }
@@ -48,29 +50,29 @@ __device__ __forceinline__ void gemm_nt_body(const double* __restrict__ A, int64
     // staging: TA / 64 rows x 32 doubles per operand; thread moves 2 doubles per pass, 16 threads per row, 16 rows per pass
     const int lr = tid >> 4, lk = (tid & 15) * 2;
     const double* arow[TA / 16];
-    const double* brow[4];
+    const double* brow[TB / 16];
 #pragma unroll
     for (int ps = 0; ps < TA / 16; ++ps) {
         const int ga = bi * TA + ps * 16 + lr;
         arow[ps] = ga < Ma ? A + (int64_t)ga * lda : nullptr;
     }
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
+    for (int ps = 0; ps < TB / 16; ++ps) {
         const int gb = bj * TS + ps * 16 + lr;
         brow[ps] = gb < Mb ? B + (int64_t)gb * ldb : nullptr;
     }
-    double2 ra[TA / 16], rb[4];
+    double2 ra[TA / 16], rb[TB / 16];
     auto gload = [&](int k0) {
 #pragma unroll
         for (int ps = 0; ps < TA / 16; ++ps) ra[ps] = arow[ps] ? *reinterpret_cast<const double2*>(arow[ps] + k0 + lk) : make_double2(0.0, 0.0);
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps) rb[ps] = brow[ps] ? *reinterpret_cast<const double2*>(brow[ps] + k0 + lk) : make_double2(0.0, 0.0);
+        for (int ps = 0; ps < TB / 16; ++ps) rb[ps] = brow[ps] ? *reinterpret_cast<const double2*>(brow[ps] + k0 + lk) : make_double2(0.0, 0.0);
     };
     auto lstore = [&](int st) {
 #pragma unroll
         for (int ps = 0; ps < TA / 16; ++ps) *reinterpret_cast<double2*>(&As[st][(ps * 16 + lr) * PITCH + lk]) = make_double2(asign * ra[ps].x, asign * ra[ps].y);
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps) *reinterpret_cast<double2*>(&Bs[st][(ps * 16 + lr) * PITCH + lk]) = rb[ps];
+        for (int ps = 0; ps < TB / 16; ++ps) *reinterpret_cast<double2*>(&Bs[st][(ps * 16 + lr) * PITCH + lk]) = rb[ps];
     };
     const int nchunks = K / KC;
     if (nchunks > 0) {
@@ -83,15 +85,15 @@ __device__ __forceinline__ void gemm_nt_body(const double* __restrict__ A, int64
         if (c + 1 < nchunks) gload((c + 1) * KC);
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 4) {
-            double af[NI], bf[2];
+            double af[NI], bf[NJ];
 #pragma unroll
             for (int i = 0; i < NI; ++i) af[i] = As[st][(wr * HA + i * 16 + (lane & 15)) * PITCH + kk + (lane >> 4)];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = Bs[st][(wc * 32 + j * 16 + (lane & 15)) * PITCH + kk + (lane >> 4)];
+            for (int j = 0; j < NJ; ++j) bf[j] = Bs[st][(wc * HB + j * 16 + (lane & 15)) * PITCH + kk + (lane >> 4)];
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
         if (c + 1 < nchunks) lstore(st ^ 1);
         __syncthreads();
@@ -99,11 +101,11 @@ __device__ __forceinline__ void gemm_nt_body(const double* __restrict__ A, int64
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = bi * TA + wr * HA + i * 16 + (lane >> 4) + 4 * r;
-                const int col = bj * TS + wc * 32 + j * 16 + (lane & 15);
+                const int col = bj * TS + wc * HB + j * 16 + (lane & 15);
                 if (row < Ma && col < Mb) C[(int64_t)row * ldc + col] = acc[i][j][r];
             }
 }
@@ -114,6 +116,10 @@ __global__ __launch_bounds__(256) void k_gemm_nt(AsmBt abt, const double* __rest
 __global__ __launch_bounds__(256) void k_gemm_nt32(AsmBt abt, const double* __restrict__ A, int64_t lda, const double* __restrict__ B, int64_t ldb, const double* C0, int64_t ldc0, double* C, int64_t ldc, int Ma, int Mb, int K, int mode) {
     ASM_BARGS(abt, A, lda, B, ldb, C0, ldc0, C, ldc, Ma, Mb, K, mode);
     gemm_nt_body<32>(A, lda, B, ldb, C0, ldc0, C, ldc, Ma, Mb, K, mode);
+}
+__global__ __launch_bounds__(256) void k_gemm_nt32w(AsmBt abt, const double* __restrict__ A, int64_t lda, const double* __restrict__ B, int64_t ldb, const double* C0, int64_t ldc0, double* C, int64_t ldc, int Ma, int Mb, int K, int mode) {
+    ASM_BARGS(abt, A, lda, B, ldb, C0, ldc0, C, ldc, Ma, Mb, K, mode);
+    gemm_nt_body<32, 96>(A, lda, B, ldb, C0, ldc0, C, ldc, Ma, Mb, K, mode);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -140,18 +140,24 @@ def test_mfma_f64_probe_runs(hip_lib, handle):
 
 # ----------------------------------------------------------------------------- round 3: kernels of the null-space form
 @pytest.mark.parametrize("Ma,Mb,K,mode", [(64, 64, 32, 0), (130, 200, 96, 0), (130, 200, 96, 1), (519, 1024, 1024, 1), (37, 469, 480, 0)])
-def test_gemm_nt_matches_numpy(hip_lib, handle, Ma, Mb, K, mode):
-    """C = (C0) -/+ A B' on the matrix cores (k_gemm_nt): ragged tile edges, both modes, in-place accumulation."""
+def test_gemm_nt_matches_numpy(hip_lib, handle, Ma, Mb, K, mode, monkeypatch):
+    """C = (C0) -/+ A B' on the matrix cores (k_gemm_nt and its 32 x 64 / 32 x 96 tile variants): ragged tile edges, both modes, in-place
+    accumulation; the variants give the same bits (every entry is the same sum in the same order)."""
     rng = np.random.default_rng(Ma + Mb + K)
     A = rng.standard_normal((Ma, K)); B = rng.standard_normal((Mb, K)); C0 = rng.standard_normal((Ma, Mb))
-    Cout = np.zeros((Ma, Mb))
-    rc = hip_lib.asm_test_gemm_nt(handle, _d(A), _d(B), _d(C0), Ma, Mb, K, mode, _d(Cout))
-    assert rc == 0, hip_lib.asm_last_error(handle)
     ref = A @ B.T if mode == 0 else C0 - A @ B.T
-    assert np.abs(Cout - ref).max() / np.abs(ref).max() < 1e-13
+    outs = []
+    for variant in ("64", "32", "32w"):
+        monkeypatch.setenv("ASM_TEST_GEMM", variant)
+        Cout = np.zeros((Ma, Mb))
+        rc = hip_lib.asm_test_gemm_nt(handle, _d(A), _d(B), _d(C0), Ma, Mb, K, mode, _d(Cout))
+        assert rc == 0, hip_lib.asm_last_error(handle)
+        assert np.abs(Cout - ref).max() / np.abs(ref).max() < 1e-13, variant
+        outs.append(Cout)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
-@pytest.mark.parametrize("N,nrhs,backward", [(100, 5, 1), (700, 37, 0), (700, 37, 1), (1500, 64, 1), (2600, 130, 1), (981, 107, 1)])
+@pytest.mark.parametrize("N,nrhs,backward", [(100, 5, 1), (700, 37, 0), (700, 37, 1), (1500, 64, 1), (2600, 130, 1), (981, 107, 1), (3000, 520, 1)])      # (the last: 32 x 96 tiles, k_gemm_nt32w)
 def test_multi_rhs_triangular_solves(hip_lib, handle, N, nrhs, backward):
     """Rows of R solved against the Cholesky factor by right-looking block substitution (products with the explicit inverses of
     the wide diagonal blocks + one update of all remaining columns per block): forward only and forward + backward."""
