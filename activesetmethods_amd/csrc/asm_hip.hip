@@ -983,7 +983,7 @@ struct Dev {
             const int Me = rowlim(Ms, b1);
             int rem = Me - b1;
             if (rem > 0)
-                hipLaunchKernelGGL((k_wtrsv_fwd_panel<WB>), dim3((unsigned)((rem + 31) / 32)), dim3(256), 0, h->stream, fS, fld, B, Me, z, w);
+                hipLaunchKernelGGL((k_wtrsv_fwd_panel<WB>), dim3((unsigned)((rem + 4 * ASM_FWD_RPW - 1) / (4 * ASM_FWD_RPW))), dim3(256), 0, h->stream, fS, fld, B, Me, z, w);
         }
         for (int B = nB - 1; B >= 0; --B) {
             int b1 = std::min((B + 1) * WB, Ms);

@@ -1600,8 +1600,12 @@ __global__ __launch_bounds__(256) void k_wtrsv_fwd_diag(AsmBt abt, const double*
     acc = wave_sum(acc);
     if (lane == 0) z[b0 + row] = acc;
 }
-// forward panel update:  w[i] -= L[i, b0:b1] . z[b0:b1]   for i >= b1.  A wavefront owns 8 rows: their 64 loads are issued
-// together, the 8 sums are reduced, and lanes 0..7 apply the 8 read-modify-writes in parallel.
+// forward panel update:  w[i] -= L[i, b0:b1] . z[b0:b1]   for i >= b1.  A wavefront owns ASM_FWD_RPW rows: their loads are issued
+// together, the sums are reduced, and the first lanes apply the read-modify-writes in parallel.  (Round 3: 8 rows per wavefront, i.e. 44
+// workgroups for the 1 400 rows a wide block of the banded S0 reaches - 13 us on a sixth of the chip; 2 rows: 175 workgroups.)
+#ifndef ASM_FWD_RPW
+#define ASM_FWD_RPW 2
+#endif
 template <int WB>
 __global__ __launch_bounds__(256) void k_wtrsv_fwd_panel(AsmBt abt, const double* __restrict__ L, int64_t ld, int B, int Ms, const double* __restrict__ z, double* __restrict__ w) {
     ASM_BARGS(abt, L, ld, B, Ms, z, w);
@@ -1610,12 +1614,12 @@ __global__ __launch_bounds__(256) void k_wtrsv_fwd_panel(AsmBt abt, const double
     for (int c = threadIdx.x; c < WB; c += 256) zs[c] = c < wdt ? z[b0 + c] : 0.0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int i0 = b1 + blockIdx.x * 32 + wv * 8;
+    const int i0 = b1 + blockIdx.x * (4 * ASM_FWD_RPW) + wv * ASM_FWD_RPW;
     double wold = 0.0;
-    if (lane < 8 && i0 + lane < Ms) wold = w[i0 + lane];
-    double acc[8];
+    if (lane < ASM_FWD_RPW && i0 + lane < Ms) wold = w[i0 + lane];
+    double acc[ASM_FWD_RPW];
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
+    for (int rr = 0; rr < ASM_FWD_RPW; ++rr) {
         int i = i0 + rr;
         double a = 0.0;
         if (i < Ms) {
@@ -1630,14 +1634,16 @@ __global__ __launch_bounds__(256) void k_wtrsv_fwd_panel(AsmBt abt, const double
     }
     double mine = 0.0;
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
+    for (int rr = 0; rr < ASM_FWD_RPW; ++rr) {
         double t = wave_sum(acc[rr]);
         if (lane == rr) mine = t;
     }
-    if (lane < 8 && i0 + lane < Ms) w[i0 + lane] = wold - mine;
+    if (lane < ASM_FWD_RPW && i0 + lane < Ms) w[i0 + lane] = wold - mine;
 }
 // backward partial sums for wide block B over chunks of 64 rows i >= b1:  part[g][c] = sum_i L[i, b0+c] x[i]
-#define ASM_WBROWS 64
+#ifndef ASM_WBROWS
+#define ASM_WBROWS 16      // rows per partial sum of the backward panel product (round 3: 64, i.e. 22 workgroups for the reach of a wide block of S0)
+#endif
 template <int WB>
 __global__ __launch_bounds__(256) void k_wtrsv_bwd_panel(AsmBt abt, const double* __restrict__ L, int64_t ld, int B, int Ms, const double* __restrict__ x, double* __restrict__ part) {
     ASM_BARGS(abt, L, ld, B, Ms, x, part);
