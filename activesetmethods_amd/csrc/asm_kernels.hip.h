@@ -607,11 +607,18 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 }
 // body shared by the stand-alone kernel and the fused panel kernel: D, W are ASM_NB x ASM_DP LDS buffers, T 4 x (16 x 17)
 typedef double potrf_T_t[16 * 17];
-template <bool SC1>
+template <bool SC1, bool OPQ = false>
 __device__ __forceinline__ void potrf64_body(double* __restrict__ D, double* __restrict__ W, potrf_T_t* __restrict__ T, double* __restrict__ d0,
                                              double* __restrict__ dinv, double* __restrict__ S, int64_t ldS, int k0, int nb,
                                              const double* __restrict__ diag0, double thr, double* __restrict__ Linv) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // OPQ: the thread index is made opaque per call.  Inside the panel kernels this body sits in the step loop, and what the compiler derives
+    // from a loop-invariant index (address offsets, the identity pattern of the tile fill) is hoisted out of that loop and - at the 256-register
+    // cap of k_chol_panel_band - spilled; the reloads sat on the chain of every step (eight dependent scratch round trips, 22 k cycles for the
+    // tile fill instead of 4 k).  Kernels with the full register file keep the hoisting: every recomputed instruction costs the chain's lone
+    // wavefront ~8 cycles.
+    int tid_ = threadIdx.x;
+    if (OPQ) asm volatile("" : "+v"(tid_));
+    const int tid = tid_, lane = tid & 63, wv = tid >> 6;
 #ifdef ASM_POTRF_PROF
     long long stamp_[16]; int ns_ = 0;
 #define PSTAMP() do { if (tid == 0) stamp_[ns_++] = clock64(); } while (0)
@@ -947,7 +954,7 @@ __global__ __launch_bounds__(256) void k_pnl_wait_probe(AsmBt abt, unsigned* fla
 // M = 18637: first panel launch 5.2 ms instead of 1.0 ms).
 // BAND: the variant for banded factors whose trailing update runs inside the launch too (k_chol_panel_band below): every solved panel tile is
 // published (flag stride ASM_PNL_NRT), not only those of the panel's own diagonal rows.
-template <bool BAND>
+template <bool BAND, bool OPQ, bool PREF>
 __device__ __forceinline__ void chol_panel_body(double* __restrict__ sm, double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms,
                                                 const double* __restrict__ diag0, double thr, double* __restrict__ Linv,
                                                 unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch, const int G, const int wg) {
@@ -956,17 +963,17 @@ __device__ __forceinline__ void chol_panel_body(double* __restrict__ sm, double*
     potrf_T_t* Tt = reinterpret_cast<potrf_T_t*>(sm + 2 * ASM_NB * ASM_XP);
     double* d0 = sm + 2 * ASM_NB * ASM_XP + 4 * 16 * 17;
     double* dinv = d0 + ASM_NB;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nsteps = (I1 - I0 + ASM_NB - 1) / ASM_NB;
     const int nrt = (Ms - I0 + ASM_NB - 1) / ASM_NB;
 #ifdef ASM_PANEL_PROF
+    const int tid = threadIdx.x;
     long long qs_[12]; int qn_ = 0;
 #define QSTAMP(cond) do { if (tid == 0 && (cond)) qs_[qn_++] = clock64(); } while (0)
 #else
 #define QSTAMP(cond) do {} while (0)
 #endif
     if (wg == 0) {
-        potrf64_body<true>(B0, B1, Tt, d0, dinv, S, ldS, I0, min(ASM_NB, Ms - I0), diag0, thr, Linv);
+        potrf64_body<true, OPQ>(B0, B1, Tt, d0, dinv, S, ldS, I0, min(ASM_NB, Ms - I0), diag0, thr, Linv);
         pnl_publish(flags + 0, epoch);
     }
     for (int k = 0; k < nsteps; ++k) {
@@ -978,20 +985,36 @@ __device__ __forceinline__ void chol_panel_body(double* __restrict__ sm, double*
         int rt = wg;
         while (rt <= k) rt += G;
         for (; rt < nrt; rt += G) {
-            QSTAMP(k == 1 && rt == 2);
-            if (!waited) { pnl_wait(flags + k, epoch, tmo); waited = true; }
+            // OPQ (the register-capped kernels): the thread index is opaque per tile, as in potrf64_body - nothing derived from it is hoisted out of
+            // the step loop and spilled.  The kernels with the full register file keep the hoisting (recomputing it costs the lone
+            // wavefronts of the chain instructions: every one is ~8 cycles there)
+            int tq_ = threadIdx.x;
+            if (OPQ) asm volatile("" : "+v"(tq_));
+            const int tid = tq_, lane = tid & 63, w = tid >> 6;
             QSTAMP(k == 1 && rt == 2);
             const int i0 = I0 + rt * ASM_NB;
             const double* Lb = Linv + (int64_t)(k0 / ASM_NB) * ASM_NB * ASM_NB;
+            // PREF: the tile's own entries are this workgroup's history (all its earlier updates were made here): their loads - 64 rows a whole
+            // matrix row apart, the slow part of the step's fetch in a banded factor - go out BEFORE the wait for the diagonal block
+            double tv[ASM_NB * ASM_NB / 256];
+            if (PREF) {
+#pragma unroll
+                for (int it = 0; it < ASM_NB * ASM_NB / 256; ++it) {
+                    const int e = tid + 256 * it, rr = e >> 6, c = e & 63;
+                    tv[it] = S[(int64_t)min(i0 + rr, Ms - 1) * ldS + k0 + min(c, nb - 1)];
+                }
+            }
+            if (!waited) { pnl_wait(flags + k, epoch, tmo); waited = true; }
+            QSTAMP(k == 1 && rt == 2);
             // ---- panel solve of the tile: X = S[tile, k0:k1] Linv'
             __syncthreads();
             {
-                double lv[ASM_NB * ASM_NB / 256], tv[ASM_NB * ASM_NB / 256];
+                double lv[ASM_NB * ASM_NB / 256];
 #pragma unroll
                 for (int it = 0; it < ASM_NB * ASM_NB / 256; ++it) {
                     const int e = tid + 256 * it, rr = e >> 6, c = e & 63;
                     lv[it] = Lb[e];
-                    tv[it] = S[(int64_t)min(i0 + rr, Ms - 1) * ldS + k0 + min(c, nb - 1)];
+                    if (!PREF) tv[it] = S[(int64_t)min(i0 + rr, Ms - 1) * ldS + k0 + min(c, nb - 1)];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1087,16 +1110,16 @@ __device__ __forceinline__ void chol_panel_body(double* __restrict__ sm, double*
             // ---- look-ahead: this tile is the next diagonal block and has all its updates now
             if (rt == k + 1 && rt < nsteps) {
                 QSTAMP(k == 1 && rt == 2);
+                const int kn = I0 + rt * ASM_NB;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 QSTAMP(k == 1 && rt == 2);
-                const int kn = I0 + rt * ASM_NB;
-                potrf64_body<true>(B0, B1, Tt, d0, dinv, S, ldS, kn, min(ASM_NB, Ms - kn), diag0, thr, Linv);
+                potrf64_body<true, OPQ>(B0, B1, Tt, d0, dinv, S, ldS, kn, min(ASM_NB, Ms - kn), diag0, thr, Linv);
                 QSTAMP(k == 1 && rt == 2);
                 pnl_publish(flags + rt, epoch);
                 QSTAMP(k == 1 && rt == 2);
 #ifdef ASM_PANEL_PROF
-                if (tid == 0 && k == 1 && I0 == 256) { printf("panel stamps (wait, load, trsm+store, publish, update, drain, potrf, publish):"); for (int q = 1; q < qn_; ++q) printf(" %lld", qs_[q] - qs_[q - 1]); printf("\n"); }
+                if (tid == 0 && k == 1 && (I0 == 0 || I0 == 1024)) { printf("panel stamps (wait, load, trsm+store, publish, update, drain, potrf, publish):"); for (int q = 1; q < qn_; ++q) printf(" %lld", qs_[q] - qs_[q - 1]); printf("\n"); }
 #endif
             }
         }
@@ -1108,12 +1131,12 @@ __device__ __forceinline__ void chol_panel_body(double* __restrict__ sm, double*
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chol_panel(AsmBt abt, double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms, const double* __restrict__ diag0, double thr, double* __restrict__ Linv, unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch) {
     ASM_BARGS(abt, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch);
     __shared__ __attribute__((aligned(16))) double sm[ASM_PNL_LDS];
-    chol_panel_body<false>(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, (int)gridDim.x, (int)blockIdx.x);
+    chol_panel_body<false, false, false>(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, (int)gridDim.x, (int)blockIdx.x);
 }
 __global__ __launch_bounds__(256) void k_chol_panel_solo(AsmBt abt, double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms, const double* __restrict__ diag0, double thr, double* __restrict__ Linv, unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch) {
     ASM_BARGS(abt, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch);
     __shared__ __attribute__((aligned(16))) double sm[ASM_PNL_LDS];
-    chol_panel_body<false>(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, (int)gridDim.x, (int)blockIdx.x);
+    chol_panel_body<false, false, true>(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, (int)gridDim.x, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1204,8 +1227,10 @@ __device__ __forceinline__ void chol_band_update_tile(double* __restrict__ sm, d
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chol_panel_band(AsmBt abt, double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms, const double* __restrict__ diag0, double thr, double* __restrict__ Linv, unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch, int G) {
     ASM_BARGS(abt, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, G);
     __shared__ __attribute__((aligned(16))) double sm[ASM_PNL_LDS];
-    if ((int)blockIdx.x < G) chol_panel_body<true>(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, G, (int)blockIdx.x);
-    else chol_band_update_tile(sm, S, ldS, I0, I1, Ms, flags, tmo, epoch, (int)blockIdx.x - G, (int)gridDim.x - G);
+    if ((int)blockIdx.x < G) {
+        __builtin_amdgcn_s_setprio(3);      // the chain's wavefronts win the issue slots of a SIMD they share with a helper's
+        chol_panel_body<true, true, true>(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, G, (int)blockIdx.x);
+    } else chol_band_update_tile(sm, S, ldS, I0, I1, Ms, flags, tmo, epoch, (int)blockIdx.x - G, (int)gridDim.x - G);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1326,7 +1351,7 @@ __device__ __forceinline__ void chol_inv_tile(double* __restrict__ sm, const dou
 __global__ __launch_bounds__(256) void k_chol_panel_inv(AsmBt abt, double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms, const double* __restrict__ diag0, double thr, double* __restrict__ Linv, unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch, double* __restrict__ Binv, double* __restrict__ BinvT, int wb, int G) {
     ASM_BARGS(abt, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, Binv, BinvT, wb, G);
     __shared__ __attribute__((aligned(16))) double sm[ASM_PNL_LDS];
-    if ((int)blockIdx.x < G) chol_panel_body<false>(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, G, (int)blockIdx.x);
+    if ((int)blockIdx.x < G) chol_panel_body<false, false, true>(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, G, (int)blockIdx.x);
     else chol_inv_tile(sm, S, ldS, I0, Ms, Linv, flags, tmo, epoch, Binv, BinvT, wb, (int)blockIdx.x - G);
 }
 
