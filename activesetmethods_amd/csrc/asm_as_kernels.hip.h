@@ -639,6 +639,18 @@ __global__ __launch_bounds__(1024) void k_face_kkt(AsmBt abt, AsPtrs A, AsSets D
     }
 }
 
+// the answer of an LP packed for ONE device-to-host copy (Solver::as_download): p | z | y | act | s as doubles, then the working set's
+// three state vectors as 32-bit integers behind them
+__global__ __launch_bounds__(256) void k_as_pack(AsmBt abt, const double* __restrict__ p, const double* __restrict__ z, const double* __restrict__ y, const double* __restrict__ act,
+                                                 const double* __restrict__ s, AsSets S, int64_t n, int64_t M, int64_t ns, double* __restrict__ dst) {
+    ASM_BARGS(abt, p, z, y, act, s, S, n, M, ns, dst);
+    const int64_t t = blockIdx.x * 256 + threadIdx.x;
+    int* di = reinterpret_cast<int*>(dst + 2 * n + 2 * M + ns);
+    if (t < n) { dst[t] = p[t]; dst[n + t] = z[t]; di[M + t] = S.bst[t]; }
+    if (t < M) { dst[2 * n + t] = y[t]; dst[2 * n + M + t] = act[t]; di[t] = S.rowst[t]; }
+    if (t < ns) { dst[2 * n + 2 * M + t] = s[t]; di[M + n + t] = S.sst[t]; }
+}
+
 // copy of a working set
 __global__ __launch_bounds__(256) void k_as_copy_sets(AsmBt abt, AsSets dst, AsSets src, int64_t M, int64_t n, int64_t ns) {
     ASM_BARGS(abt, dst, src, M, n, ns);

@@ -304,6 +304,8 @@ struct asm_handle {
     bool spin_read = true;          // ASM_HIP_SPIN=0: hipMemcpyAsync + hipStreamSynchronize instead (14.5 us per read-back instead of 6.7 us)
     int* d_idx = nullptr;
     double* h_pin = nullptr;        // pinned staging (max(ldn, Mp) doubles) x 2
+    double* d_dl = nullptr;         // the answer of an LP packed on the device (k_as_pack) and its pinned host image: one device-to-host copy per LP instead of eight
+    double* h_dl = nullptr;
     double* h_up = nullptr;         // pinned staging of the LP vectors an LP uploads (3 ldn + Mp + 3 nsp doubles, zero beyond the vectors' lengths)
     int64_t pin_len = 0;
 
@@ -2108,6 +2110,25 @@ struct Solver {
     // final answer of the LP (device -> host): p, s, y, z, act and the working set `final_sets`
     void as_download(EqpOut& o, ActiveSet& as) {
         const int64_t n = lp.n, M = lp.M, ns = lp.ns;
+        if (!asmb::in_fiber() && h->d_dl) {
+            // outside a batch: packed on the device, one copy into pinned memory (eight copies into pageable vectors cost the host tens of
+            // microseconds each, with the GPU idle in between)
+            hipLaunchKernelGGL(k_as_pack, dim3(grid_all()), dim3(256), 0, h->stream, (const double*)A.p, (const double*)A.z, (const double*)A.y, (const double*)A.act,
+                               (const double*)A.s, S_[final_sets], n, M, ns, h->d_dl);
+            const size_t bytes = (size_t)(2 * n + 2 * M + ns) * sizeof(double) + (size_t)(M + n + ns) * sizeof(int);
+            HIPCHK(hipMemcpyAsync(h->h_dl, h->d_dl, bytes, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            const double* st = h->h_dl;
+            o.p.assign(st, st + n); o.z.assign(st + n, st + 2 * n); o.y.assign(st + 2 * n, st + 2 * n + M); o.act.assign(st + 2 * n + M, st + 2 * n + 2 * M);
+            o.s.assign(st + 2 * n + 2 * M, st + 2 * n + 2 * M + ns);
+            const int* bi = reinterpret_cast<const int*>(st + 2 * n + 2 * M + ns);
+            as.rowst.resize(M); as.bst.resize(n); as.sst.resize(ns);
+            for (int64_t i = 0; i < M; ++i) as.rowst[i] = (int8_t)bi[i];
+            for (int64_t j = 0; j < n; ++j) as.bst[j] = (int8_t)bi[M + j];
+            for (int64_t k = 0; k < ns; ++k) as.sst[k] = (int8_t)bi[M + n + k];
+            as.valid = true;
+            return;
+        }
         down(o.p, A.p, n); down(o.z, A.z, n); down(o.y, A.y, M); down(o.act, A.act, M); down(o.s, A.s, ns);
         std::vector<int> buf((size_t)(M + n + ns));
         if (M) HIPCHK(hipMemcpyAsync(buf.data(), S_[final_sets].rowst, M * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -2702,6 +2723,9 @@ void free_device(asm_handle* h) {
     if (h->h_pin) (void)hipHostFree(h->h_pin);
     if (h->h_up) (void)hipHostFree(h->h_up);
     h->h_up = nullptr;
+    if (h->h_dl) (void)hipHostFree(h->h_dl);
+    F(h->d_dl);
+    h->h_dl = h->d_dl = nullptr;
     h->d_perm = h->d_ustart = h->d_uoff = h->d_adjoff = nullptr;
     h->d_dE = h->d_J = h->d_Ah = h->d_S = h->d_c = h->d_rho = h->d_theta = h->d_diag = h->d_diag0 = nullptr;
     h->d_vecN = h->d_vecM = h->d_vecM2 = h->d_partial = nullptr;
@@ -3012,6 +3036,11 @@ void do_setup(asm_handle* h, int64_t n, int64_t m, int64_t nnz, const int64_t* j
     HIPCHK(hipHostMalloc((void**)&h->h_pin, 2 * h->pin_len * sizeof(double)));
     HIPCHK(hipHostMalloc((void**)&h->h_up, (3 * h->ldn + h->Mp + 3 * h->nsp + 16) * sizeof(double)));
     std::memset(h->h_up, 0, (3 * h->ldn + h->Mp + 3 * h->nsp + 16) * sizeof(double));
+    {
+        const int64_t dl = 2 * h->ldn + 2 * h->Mp + h->nsp + (h->ldn + h->Mp + h->nsp + 1) / 2 + 16;
+        dmalloc(&h->d_dl, dl);
+        HIPCHK(hipHostMalloc((void**)&h->h_dl, dl * sizeof(double)));
+    }
     HIPCHK(hipMemsetAsync(h->d_J, 0, h->Mp * h->ldn * sizeof(double), h->stream));
     HIPCHK(hipMemsetAsync(h->d_Ah, 0, h->Mp * h->ldn * sizeof(double), h->stream));
     HIPCHK(hipMemsetAsync(h->d_vecN, 0, h->ldn * sizeof(double), h->stream));
@@ -3746,6 +3775,47 @@ int asm_slp_line_search(asm_handle* h, const double* p, const double* nu, const 
     });
 }
 
+// The native SLP driver's step: compute_phi(x, 0, p), compute_derivative and compute_alpha in one upload and - when one of the first eight
+// trial steps is accepted, i.e. nearly always - one read-back (asm_slp_merit twice + asm_slp_line_search: three uploads of nu | slacks | p and
+// three read-backs).  The trial points do not depend on phi0 and D, only the acceptance test does: same launches per quantity, same values.
+static void slp_merit_and_search(asm_handle* h, const double* p, const double* nu, const double* p_slack, int feasibility, double prim_infeas, double eta, double tau,
+                                 double min_alpha, double* phi0_out, double* D_out, double* alpha_out, double* phi_out, int* trials_out, int* ok_out) {
+    const int64_t n = h->n, m = h->m;
+    double* v = h->d_ev_vecs + 2 * m + 2 * n + m + 2 * n;    // nu | ps | p
+    double *nud = v, *psd = v + m, *pd = psd + 2 * m, *outd = pd + n + h->ldn + h->Mp;
+    double* st = h->h_ev;
+    if (m) { std::memcpy(st, nu, m * sizeof(double)); std::memcpy(st + m, p_slack, 2 * m * sizeof(double)); }
+    std::memcpy(st + 3 * m, p, n * sizeof(double));
+    HIPCHK(hipMemcpyAsync(nud, st, (3 * m + n) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    const SlpVecs V = ev_vecs(h, nullptr, nullptr, nullptr, nullptr, nullptr);
+    constexpr int CH = 8;
+    for (int mode = 0; mode < 2; ++mode)
+        hipLaunchKernelGGL(k_slp_merit, dim3(1), dim3(1024), 0, h->stream, V, (const double*)h->d_ev_E, (const double*)nud, (const double*)psd, (const double*)pd, 0.0, feasibility,
+                           prim_infeas, (const double*)h->d_ev_f, mode, outd + CH + mode, TrialAlphas(), (int64_t)0);
+    double alpha = 1.0, a[CH], phi0 = 0.0, D = 0.0;
+    int trials = 0;
+    *ok_out = -1;
+    for (int round = 0; *ok_out < 0; ++round) {
+        asmb::barrier(920);
+        TrialAlphas al;
+        for (int t = 0; t < CH; ++t) { a[t] = al.a[t] = alpha; alpha *= tau; }
+        const int64_t ldx = round_up(n, 32), ldE = round_up(std::max<int64_t>(m, 1), 32);
+        hipLaunchKernelGGL(k_axpy_trials, dim3((unsigned)((n + 255) / 256), CH), dim3(256), 0, h->stream, (const double*)h->d_ev_x, al, (const double*)pd, h->d_ev_xt, n, ldx);
+        ev_launch(h, h->d_ev_xt, h->d_ev_Et, h->d_ev_f + 1, false, CH, ldx, ldE);
+        hipLaunchKernelGGL(k_slp_merit, dim3(CH), dim3(1024), 0, h->stream, V, (const double*)h->d_ev_Et, (const double*)nud, (const double*)psd, (const double*)pd, 0.0,
+                           feasibility, prim_infeas, (const double*)(h->d_ev_f + 1), 0, outd, al, ldE);
+        HIPCHK(hipMemcpyAsync(st, outd, (CH + (round == 0 ? 2 : 0)) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (round == 0) { phi0 = st[CH]; D = st[CH + 1]; }
+        for (int t = 0; t < CH && *ok_out < 0; ++t) {
+            trials += 1;
+            if (!(st[t] > phi0 + eta * a[t] * D)) { *ok_out = 1; *alpha_out = a[t]; *phi_out = st[t]; }
+            else if (a[t] < min_alpha) { *ok_out = 0; *alpha_out = a[t]; *phi_out = st[t]; }
+        }
+    }
+    *phi0_out = phi0; *D_out = D; *trials_out = trials;
+}
+
 // --------------------------------------------------------------------------------- kernel test hooks
 static void test_alloc(asm_handle* h, int64_t M, int64_t K) {
     // minimal "problem" so that the generic buffers exist: dense pattern M x K
@@ -4038,12 +4108,11 @@ struct SlpRunLS {
             }
             for (int64_t i = 0; i < m; ++i) nu[i] = iter == 1 ? std::fabs(lam[i]) : std::max(nu[i], std::fabs(lam[i]));       // :251-261
             asmb::barrier(910);
-            chk(asm_slp_merit(h, 0, 0.0, p.data(), nu.data(), ps.data(), fr ? 1 : 0, finite_or_zero(prim_infeas), &phi), "asm_slp_merit");
-            chk(asm_slp_merit(h, 1, 0.0, p.data(), nu.data(), ps.data(), fr ? 1 : 0, finite_or_zero(prim_infeas), &D), "asm_slp_merit");
             int trials = 0, ok = 0;
             double phi_a = 0.0;
-            chk(asm_slp_line_search(h, p.data(), nu.data(), ps.data(), fr ? 1 : 0, finite_or_zero(prim_infeas), phi, D, o.eta, o.tau, o.min_alpha, &alpha, &phi_a,
-                                    &trials, &ok), "asm_slp_line_search");                                // :222-244
+            // compute_phi, compute_derivative, compute_alpha (:222-244) - as asm_slp_merit (modes 0, 1) + asm_slp_line_search, with one upload
+            chk(guarded(h, [&] { slp_merit_and_search(h, p.data(), nu.data(), ps.data(), fr ? 1 : 0, finite_or_zero(prim_infeas), o.eta, o.tau, o.min_alpha, &phi, &D, &alpha,
+                                                      &phi_a, &trials, &ok); }), "slp_merit_and_search");
             ls_trials += trials;
             if (!ok && fr) ret = -3;
             const bool valid = ok != 0;
