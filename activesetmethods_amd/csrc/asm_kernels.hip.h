@@ -607,7 +607,7 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 }
 // body shared by the stand-alone kernel and the fused panel kernel: D, W are ASM_NB x ASM_DP LDS buffers, T 4 x (16 x 17)
 typedef double potrf_T_t[16 * 17];
-template <bool SC1, bool OPQ = false>
+template <bool SC1, bool OPQ = false, bool PADSKIP = false>
 __device__ __forceinline__ void potrf64_body(double* __restrict__ D, double* __restrict__ W, potrf_T_t* __restrict__ T, double* __restrict__ d0,
                                              double* __restrict__ dinv, double* __restrict__ S, int64_t ldS, int k0, int nb,
                                              const double* __restrict__ diag0, double thr, double* __restrict__ Linv) {
@@ -665,8 +665,17 @@ __device__ __forceinline__ void potrf64_body(double* __restrict__ D, double* __r
             for (int rr = 0; rr < 16; ++rr) W[(c0 + rr) * ASM_DP + c0 + t] = x[rr];
         }
     };
+    // sub-blocks past the nb live columns are identity padding (k = 519: the ninth diagonal block has 7 columns): no pivot chain, no update,
+    // identity inverse - the block costs what its live sub-blocks cost, not a full 64-column chain
+    auto identity_inverse = [&](int c0) { if (lane < 16) W[(c0 + lane) * ASM_DP + c0 + lane] = 1.0; };
     for (int sb = 0; sb < 4; ++sb) {
         const int c0 = sb * 16;
+        if (PADSKIP && c0 >= nb) {
+            if (wv == 0 && lane < 16) dinv[c0 + lane] = 1.0;
+            if (wv == 1 && sb > 0) { if (c0 - 16 < nb) diag_inverse(c0 - 16); else identity_inverse(c0 - 16); }
+            __syncthreads();
+            continue;
+        }
         if (wv == 0) {
             // (1) 16 columns of the factor over ALL remaining rows at once: lane r owns row c0 + r.  Lanes 0..15 hold the
             //     diagonal sub-block; the same sixteen broadcast-and-update steps that factor it solve the rows below it
@@ -727,7 +736,7 @@ __device__ __forceinline__ void potrf64_body(double* __restrict__ D, double* __r
     // ---- the factor goes back to S (wavefronts 0, 2, 3) while wavefront 1 inverts the last diagonal sub-block; then the inverse
     // W = L^-1 by 16x16 blocks (diagonal blocks 0..2 were inverted beside the factorisation of their successors)
     if (wv == 1) {
-        diag_inverse(48);
+        if (!PADSKIP || 48 < nb) diag_inverse(48); else identity_inverse(48);
     } else {
         const int t3 = (wv == 0 ? 0 : wv - 1) * 64 + lane;          // 0..191
         for (int e = t3; e < ASM_NB * ASM_NB; e += 192) {
@@ -740,6 +749,7 @@ __device__ __forceinline__ void potrf64_body(double* __restrict__ D, double* __r
     PSTAMP();
     for (int dlev = 1; dlev < 4; ++dlev) {               // off-diagonal blocks (i, j = i - dlev), one wavefront per block,
         const int i = wv + dlev, j = wv;                 // 16x16x16 products on the matrix cores
+        if (PADSKIP && dlev * 16 >= nb) break;                      // (uniform) every block of this and the later levels lies in the padding: zero
         if (i < 4) {
             // T = sum_{k=j}^{i-1} L_ik W_kj
             v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
@@ -954,7 +964,10 @@ __global__ __launch_bounds__(256) void k_pnl_wait_probe(AsmBt abt, unsigned* fla
 // M = 18637: first panel launch 5.2 ms instead of 1.0 ms).
 // BAND: the variant for banded factors whose trailing update runs inside the launch too (k_chol_panel_band below): every solved panel tile is
 // published (flag stride ASM_PNL_NRT), not only those of the panel's own diagonal rows.
-template <bool BAND, bool OPQ, bool PREF>
+// THIN: a row tile with at most 16 live rows (k = 519: the ninth has 7) keeps its products to the live 16-row block and deals the four 16-column
+// blocks to the four wavefronts - a quarter of the matrix instructions per wavefront.  The owner of the LAST row tile has the most updates per
+// step (one per remaining column tile); with nine or ten steps in one launch it finishes when the chain does, so its cost per update counts.
+template <bool BAND, bool OPQ, bool PREF, bool THIN = false>
 __device__ __forceinline__ void chol_panel_body(double* __restrict__ sm, double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms,
                                                 const double* __restrict__ diag0, double thr, double* __restrict__ Linv,
                                                 unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch, const int G, const int wg) {
@@ -973,7 +986,7 @@ __device__ __forceinline__ void chol_panel_body(double* __restrict__ sm, double*
 #define QSTAMP(cond) do {} while (0)
 #endif
     if (wg == 0) {
-        potrf64_body<true, OPQ>(B0, B1, Tt, d0, dinv, S, ldS, I0, min(ASM_NB, Ms - I0), diag0, thr, Linv);
+        potrf64_body<true, OPQ, THIN>(B0, B1, Tt, d0, dinv, S, ldS, I0, min(ASM_NB, Ms - I0), diag0, thr, Linv);
         pnl_publish(flags + 0, epoch);
     }
     for (int k = 0; k < nsteps; ++k) {
@@ -1026,32 +1039,56 @@ __device__ __forceinline__ void chol_panel_body(double* __restrict__ sm, double*
             }
             __syncthreads();
             QSTAMP(k == 1 && rt == 2);
+            const bool thin = THIN && Ms - i0 <= 16;
+            const int ws = __builtin_amdgcn_readfirstlane(w);      // (scalar: wavefront-uniform block offsets)
             v4f64 acc[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+            if (thin) {
+                // rows 0..15 of the tile x column block ws; rows 16.. of B0 stay the zeros of the fill
+                v4f64 a1 = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll 4
-            for (int kk = 0; kk < ASM_NB; kk += 4) {
-                double af = B0[(w * 16 + (lane & 15)) * ASM_XP + kk + (lane >> 4)];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    double bf = B1[(t * 16 + (lane & 15)) * ASM_XP + kk + (lane >> 4)];
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc[t], 0, 0, 0);
+                for (int kk = 0; kk < ASM_NB; kk += 4) {
+                    const double af = B0[(lane & 15) * ASM_XP + kk + (lane >> 4)];
+                    const double bf = B1[(ws * 16 + (lane & 15)) * ASM_XP + kk + (lane >> 4)];
+                    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, a1, 0, 0, 0);
                 }
-            }
-            __syncthreads();                          // every wavefront has read its rows of B0 and all of B1
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
+                __syncthreads();
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    int row = w * 16 + (lane >> 4) + 4 * r, col = t * 16 + (lane & 15);
-                    int gi = i0 + row;
-                    B0[row * ASM_XP + col] = acc[t][r];
+                    const int row = (lane >> 4) + 4 * r, col = ws * 16 + (lane & 15), gi = i0 + row;
+                    B0[row * ASM_XP + col] = a1[r];
                     if (gi < Ms && col < nb) {
                         double* dst = S + (int64_t)gi * ldS + k0 + col;
-                        if (BAND || rt < nsteps) __hip_atomic_store(dst, acc[t][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // operand for others
-                        else *dst = acc[t][r];
+                        if (BAND || rt < nsteps) __hip_atomic_store(dst, a1[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        else *dst = a1[r];
                     }
                 }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+                for (int kk = 0; kk < ASM_NB; kk += 4) {
+                    double af = B0[(w * 16 + (lane & 15)) * ASM_XP + kk + (lane >> 4)];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        double bf = B1[(t * 16 + (lane & 15)) * ASM_XP + kk + (lane >> 4)];
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc[t], 0, 0, 0);
+                    }
+                }
+                __syncthreads();                          // every wavefront has read its rows of B0 and all of B1
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int row = w * 16 + (lane >> 4) + 4 * r, col = t * 16 + (lane & 15);
+                        int gi = i0 + row;
+                        B0[row * ASM_XP + col] = acc[t][r];
+                        if (gi < Ms && col < nb) {
+                            double* dst = S + (int64_t)gi * ldS + k0 + col;
+                            if (BAND || rt < nsteps) __hip_atomic_store(dst, acc[t][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // operand for others
+                            else *dst = acc[t][r];
+                        }
+                    }
+            }
             QSTAMP(k == 1 && rt == 2);
             if (BAND || rt < nsteps) pnl_publish(flags + ASM_PNL_NS + (BAND ? ASM_PNL_NRT : ASM_PNL_NS) * k + rt, epoch);      // a later diagonal row tile (BAND: any row tile): its X is an operand for others
             else __syncthreads();
@@ -1080,31 +1117,53 @@ __device__ __forceinline__ void chol_panel_body(double* __restrict__ sm, double*
                     __syncthreads();
                     Pb = B1;
                 }
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
+                if (thin) {
+                    v4f64 a1;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        int row = i0 + w * 16 + (lane >> 4) + 4 * r, col = c0 + t * 16 + (lane & 15);
+                        const int row = i0 + (lane >> 4) + 4 * r, col = c0 + ws * 16 + (lane & 15);
                         const int rc = min(row, Ms - 1);
                         const double v = S[(int64_t)rc * ldS + min(col, min(c_end - 1, rc))];
-                        acc[t][r] = ((row < Ms) & (col < c_end) & (col <= row)) ? v : 0.0;
+                        a1[r] = ((row < Ms) & (col < c_end) & (col <= row)) ? v : 0.0;
                     }
 #pragma unroll 4
-                for (int kk = 0; kk < ASM_NB; kk += 4) {
-                    double af = -B0[(w * 16 + (lane & 15)) * ASM_XP + kk + (lane >> 4)];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        double bf = Pb[(t * 16 + (lane & 15)) * ASM_XP + kk + (lane >> 4)];
-                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc[t], 0, 0, 0);
+                    for (int kk = 0; kk < ASM_NB; kk += 4) {
+                        const double af = -B0[(lane & 15) * ASM_XP + kk + (lane >> 4)];
+                        const double bf = Pb[(ws * 16 + (lane & 15)) * ASM_XP + kk + (lane >> 4)];
+                        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, a1, 0, 0, 0);
                     }
-                }
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        int row = i0 + w * 16 + (lane >> 4) + 4 * r, col = c0 + t * 16 + (lane & 15);
-                        if (row < Ms && col < c_end && col <= row) S[(int64_t)row * ldS + col] = acc[t][r];
+                        const int row = i0 + (lane >> 4) + 4 * r, col = c0 + ws * 16 + (lane & 15);
+                        if (row < Ms && col < c_end && col <= row) S[(int64_t)row * ldS + col] = a1[r];
                     }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            int row = i0 + w * 16 + (lane >> 4) + 4 * r, col = c0 + t * 16 + (lane & 15);
+                            const int rc = min(row, Ms - 1);
+                            const double v = S[(int64_t)rc * ldS + min(col, min(c_end - 1, rc))];
+                            acc[t][r] = ((row < Ms) & (col < c_end) & (col <= row)) ? v : 0.0;
+                        }
+#pragma unroll 4
+                    for (int kk = 0; kk < ASM_NB; kk += 4) {
+                        double af = -B0[(w * 16 + (lane & 15)) * ASM_XP + kk + (lane >> 4)];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            double bf = Pb[(t * 16 + (lane & 15)) * ASM_XP + kk + (lane >> 4)];
+                            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc[t], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            int row = i0 + w * 16 + (lane >> 4) + 4 * r, col = c0 + t * 16 + (lane & 15);
+                            if (row < Ms && col < c_end && col <= row) S[(int64_t)row * ldS + col] = acc[t][r];
+                        }
+                }
                 __syncthreads();                      // B1 is reloaded for the next column tile
             }
             // ---- look-ahead: this tile is the next diagonal block and has all its updates now
@@ -1114,7 +1173,7 @@ __device__ __forceinline__ void chol_panel_body(double* __restrict__ sm, double*
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 QSTAMP(k == 1 && rt == 2);
-                potrf64_body<true, OPQ>(B0, B1, Tt, d0, dinv, S, ldS, kn, min(ASM_NB, Ms - kn), diag0, thr, Linv);
+                potrf64_body<true, OPQ, THIN>(B0, B1, Tt, d0, dinv, S, ldS, kn, min(ASM_NB, Ms - kn), diag0, thr, Linv);
                 QSTAMP(k == 1 && rt == 2);
                 pnl_publish(flags + rt, epoch);
                 QSTAMP(k == 1 && rt == 2);
@@ -1136,7 +1195,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 __global__ __launch_bounds__(256) void k_chol_panel_solo(AsmBt abt, double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms, const double* __restrict__ diag0, double thr, double* __restrict__ Linv, unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch) {
     ASM_BARGS(abt, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch);
     __shared__ __attribute__((aligned(16))) double sm[ASM_PNL_LDS];
-    chol_panel_body<false, false, true>(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, (int)gridDim.x, (int)blockIdx.x);
+    chol_panel_body<false, false, true, true>(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, (int)gridDim.x, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1351,7 +1410,7 @@ __device__ __forceinline__ void chol_inv_tile(double* __restrict__ sm, const dou
 __global__ __launch_bounds__(256) void k_chol_panel_inv(AsmBt abt, double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms, const double* __restrict__ diag0, double thr, double* __restrict__ Linv, unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch, double* __restrict__ Binv, double* __restrict__ BinvT, int wb, int G) {
     ASM_BARGS(abt, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, Binv, BinvT, wb, G);
     __shared__ __attribute__((aligned(16))) double sm[ASM_PNL_LDS];
-    if ((int)blockIdx.x < G) chol_panel_body<false, false, true>(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, G, (int)blockIdx.x);
+    if ((int)blockIdx.x < G) chol_panel_body<false, false, true, true>(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, G, (int)blockIdx.x);
     else chol_inv_tile(sm, S, ldS, I0, Ms, Linv, flags, tmo, epoch, Binv, BinvT, wb, (int)blockIdx.x - G);
 }
 
