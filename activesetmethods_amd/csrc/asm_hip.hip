@@ -1873,9 +1873,24 @@ struct Solver {
     int ipm_run(double tol, int max_more) {
         const int M = (int)lp.M;
         int done = 0;
+        // null-space iterations apply their step on the device (k_ns_update_dev) and are checked with the NEXT measures: one read-back per
+        // iteration.  ns_pending: the last iteration was one of those and its accuracy check is still owed
+        static const bool ns_defer = [] { const char* v = std::getenv("ASM_NS_DEFER"); return !(v && v[0] == '0'); }();      // (measurement knob)
+        bool ns_pending = false;
         while (true) {
             asmb::barrier(btag);                 // scenario batch: iterations of different scenarios run in lockstep (min-PC-first)
             ipm_measures();
+            if (ns_pending) {
+                ns_pending = false;
+                if (h->verbose) std::fprintf(stderr, "[asm]     ap %.3e ad %.3e (null-space step, applied on the device)\n", h->h_scal[SC_AP], h->h_scal[SC_AD]);
+                if (h->h_scal[SC_NSERR] > NS_RERR) {
+                    // the reduced system lost its accuracy and the device left the iterate alone: redo the iteration in row form
+                    // (oracle: IPM.run) - measured again below as the row form measures it
+                    ns_finish_y();
+                    ip.ns_off = true;
+                    continue;
+                }
+            }
             if (h->verbose) std::fprintf(stderr, "[asm] ipm %3d pinf %.3e dinf %.3e gap %.3e\n", ip.iters, ip.pinf, ip.dinf, ip.gap);
             if (ip.pinf <= tol && ip.gap <= tol && (ip.dinf <= tol || (ip.gap <= IPM_GAP_DONE * tol && ip.dinf <= IPM_DINF_FLOOR))) {
                 if (ns_live()) ns_finish_y();
@@ -1989,6 +2004,10 @@ struct Solver {
                 hipLaunchKernelGGL(k_ipm_steps, dim3(red_grid()), dim3(1024), 0, h->stream, P, dirA, 0u);
                 hipLaunchKernelGGL(k_ipm_muaff, dim3(red_grid()), dim3(1024), 0, h->stream, P, dirA, sig_exp());
                 if (use_ns) ns_newton(1, dirA, dirC); else ipm_solve(1, dirA, dirC, 0.0, 0.0, deferred ? 2 : 0);
+                if (use_ns && ns_defer) {       // step lengths stay on the device (k_ns_update_dev below)
+                    hipLaunchKernelGGL(k_ipm_steps, dim3(red_grid()), dim3(1024), 0, h->stream, P, dirC, 0u);
+                    return true;
+                }
                 unsigned pub = pub_next();
                 hipLaunchKernelGGL(k_ipm_steps, dim3(red_grid()), dim3(1024), 0, h->stream, P, dirC, pub);
                 read_scal(pub);
@@ -2014,6 +2033,12 @@ struct Solver {
             static const bool spec_env = [] { const char* v = std::getenv("ASM_IPM_DEFER_CHECK"); return !(v && v[0] == '0'); }();
             const bool defer = spec_env && !use_ns && !use_col && !use_red;      // the factor of S itself is the preconditioner
             if (!(defer && solves(true))) solves(false);
+            if (use_ns && ns_defer) {
+                const double eta = ip.mu >= 1.0 ? eta0() : std::min(std::max(eta0(), 1.0 - ip.mu / lp.scale_q), 0.999999);
+                hipLaunchKernelGGL(k_ns_update_dev, dim3(grid_all()), dim3(256), 0, h->stream, P, dirC, eta, nsv(14), h->ldn, NS_RERR);
+                ns_pending = true;
+                continue;
+            }
             if (h->verbose) std::fprintf(stderr, "[asm]     ap %.3e ad %.3e  cg steps so far %lld\n", ap, ad, (long long)h->stats_pcg);
             if (use_ns && h->h_scal[SC_NSERR] > NS_RERR) {
                 ns_finish_y();

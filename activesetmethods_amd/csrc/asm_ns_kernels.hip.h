@@ -597,6 +597,37 @@ __global__ __launch_bounds__(256) void k_ns_update(AsmBt abt, IpmPtrs P, IpmDir 
     }
     if (t < ldn) e[t] *= es;
 }
+// The same update with the step lengths taken from the scalar block on the device (k_ipm_steps left them there): the host does not wait
+// for them - one read-back per null-space iteration (the measures) instead of two.  al = min(1, eta ap), be = min(1, eta ad) as the host
+// formed them.  An iteration whose reduced solves lost their accuracy (SC_NSERR > rerr) leaves the iterate alone: the host sees the same
+// number with the next measures and redoes the iteration in row form (Solver::ipm_run).
+__global__ __launch_bounds__(256) void k_ns_update_dev(AsmBt abt, IpmPtrs P, IpmDir C, double eta, double* __restrict__ e, int64_t ldn, double rerr) {
+    ASM_BARGS(abt, P, C, eta, e, ldn, rerr);
+    if (P.scal[SC_NSERR] > rerr) return;
+    const double al = fmin(1.0, eta * P.scal[SC_AP]), be = fmin(1.0, eta * P.scal[SC_AD]), es = 1.0 - al;
+    int64_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < P.n) {
+        bool fr = P.ub[t] > P.lb[t];
+        P.p[t] += al * C.dp[t];
+        P.tL[t] = fr ? P.tL[t] + al * C.dp[t] : 1.0;
+        P.tU[t] = fr ? P.tU[t] - al * C.dp[t] : 1.0;
+        P.muL[t] += be * C.dmuL[t];
+        P.muU[t] += be * C.dmuU[t];
+    }
+    if (t < P.ns) {
+        P.s[t] += al * C.ds[t];
+        P.ts[t] += al * C.ds[t];
+        P.mus[t] += be * C.dmus[t];
+    }
+    if (t < P.M) {
+        bool ineq = P.rtype[t] != 0;
+        P.g[t] = ineq ? P.g[t] + al * C.dg[t] : 1.0;
+        double pi = P.pi[t] + be * C.dpi[t];
+        P.pi[t] = pi;
+        P.y[t] = ineq ? (double)P.rtype[t] * pi : P.y[t] + be * C.dy[t];
+    }
+    if (t < ldn) e[t] *= es;
+}
 // k_ns_neg (dpbar = -e) + clearing the accumulated residual measure of the iteration's reduced solves
 __global__ __launch_bounds__(256) void k_ns_neg_clear(AsmBt abt, const double* __restrict__ x, double* __restrict__ out, int64_t len, double* __restrict__ clear) {
     ASM_BARGS(abt, x, out, len, clear);
