@@ -60,7 +60,7 @@ def test_cholesky_update_matches_numpy(hip_lib, handle, Ms, K, MsB, srow0, tile)
     assert np.array_equal(S[~mask], S0[~mask])          # nothing outside the updated region is touched
 
 
-@pytest.mark.parametrize("N", [1, 17, 64, 65, 200, 513, 1000, 2500, 4700])
+@pytest.mark.parametrize("N", [1, 17, 64, 65, 200, 513, 519, 530, 1000, 2500, 4700])      # (519: the thin ninth row tile of the C4 reduced matrix; 530: 18 live rows, padded sub-blocks only)
 def test_cholesky_and_solve(hip_lib, handle, N):
     rng = np.random.default_rng(N)
     B = rng.standard_normal((N, N + 5))

@@ -410,3 +410,28 @@ def test_scenario_batch_is_independent_of_the_stream_pool():
         assert a.ret == b.ret == 0 and a.iter == b.iter and a.lp_solves == b.lp_solves
         assert np.array_equal(a.x, b.x) and np.array_equal(a.lam, b.lam)
         assert [r['stats']['path'] for r in a.trace] == [r['stats']['path'] for r in b.trace]
+
+
+def test_device_side_step_of_null_space_iterations_is_bit_identical():
+    """The null-space iterations apply their step on the device and are checked with the next measures (one read-back per iteration,
+    k_ns_update_dev); ASM_NS_DEFER=0 is the host-side step of the rounds before.  Same arithmetic: the two runs must agree bit for bit
+    (knobs are read once per process, hence two child processes, one after the other)."""
+    import hashlib, os, subprocess, sys
+    code = ("import hashlib, numpy as np, activesetmethods_amd as A\n"
+            "from activesetmethods_amd import acopf\n"
+            "pr = acopf.function_model(acopf.synthetic_case('case118', 1, 0.5)).to_problem('case118-sized')\n"
+            "m = A.Model.from_problem(pr, A.Parameters(algorithm='Line Search', max_iter=6, device_eval=True))\n"
+            "s = A.optimize(m)\n"
+            "hh = hashlib.sha256()\n"
+            "for r in s.trace:\n"
+            "    hh.update(np.ascontiguousarray(r['p'], dtype=np.float64).tobytes()); hh.update(np.ascontiguousarray(r['lam'], dtype=np.float64).tobytes())\n"
+            "print('HASH', hh.hexdigest(), len(s.trace), sum(r.get('ns_iters', 0) for r in s.trace))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for v in ("1", "0"):
+        env = dict(os.environ, ASM_NS_DEFER=v, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("HASH")][-1].split())
+    assert outs[0][1] == outs[1][1], (outs[0], outs[1])
+    assert int(outs[0][2]) >= 5
