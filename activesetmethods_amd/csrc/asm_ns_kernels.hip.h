@@ -830,13 +830,19 @@ __device__ __forceinline__ void small_chol_solve(const double* __restrict__ L, i
     // forward: L z = x   (z overwrites x block by block)
     for (int b = 0; b < nb; ++b) {
         const int b0 = b << 6;
-        for (int rr = wv; rr < 64; rr += 16) {                     // t_b = x_b - L[b, 0:b0] z[0:b0]: one wavefront per row, lanes along the row
-            const int row = b0 + rr;
-            double acc = 0.0;
-            if (row < k)
-                for (int j = lane; j < b0; j += 64) acc = fma(L[(int64_t)row * ld + j], x[j], acc);
-            acc = wave_sum(acc);
-            if (lane == 0) t[rr] = row < k ? x[row] - acc : 0.0;
+        {                                                          // t_b = x_b - L[b, 0:b0] z[0:b0]: one wavefront per row, lanes along the row;
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};                  // the wavefront's four rows together (their loads in one round trip, each row's sum as before)
+            for (int j = lane; j < b0; j += 64) {
+                const double xj = x[j];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] = fma(L[(int64_t)min(b0 + wv + 16 * u, k - 1) * ld + j], xj, acc[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rr = wv + 16 * u, row = b0 + rr;
+                const double a = wave_sum(acc[u]);
+                if (lane == 0) t[rr] = row < k ? x[row] - a : 0.0;
+            }
         }
         __syncthreads();
         {                                                          // z_b = Linv_b t_b  (64 x 64, lower triangular)
@@ -904,11 +910,19 @@ __global__ __launch_bounds__(1024) void k_small_solve(AsmBt abt, const double* _
 // r (LDS) = rhs - N0 x  with N0 symmetric, stored in full: one wavefront per row
 __device__ __forceinline__ void small_symv_res(const double* __restrict__ N0, int64_t ld, int k, const double* x, const double* rhs, double* r) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int i = wv; i < k; i += 16) {
-        double acc = 0.0;
-        for (int j = lane; j < k; j += 64) acc = fma(N0[(int64_t)i * ld + j], x[j], acc);
-        acc = wave_sum(acc);
-        if (lane == 0) r[i] = rhs[i] - acc;
+    for (int i0 = wv; i0 < k; i0 += 64) {                          // four rows of a wavefront together: their loads in one round trip, each row's sum as before
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int j = lane; j < k; j += 64) {
+            const double xj = x[j];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = fma(N0[(int64_t)min(i0 + 16 * u, k - 1) * ld + j], xj, acc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 16 * u;
+            const double a = wave_sum(acc[u]);
+            if (lane == 0 && i < k) r[i] = rhs[i] - a;
+        }
     }
     __syncthreads();
 }
