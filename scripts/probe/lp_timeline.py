@@ -1,6 +1,6 @@
 """Where one steady-state LP spends its time (development probe): reads the kernel trace CSV of a rocprofv3 --kernel-trace run of `bench.py --workload c4`,
 cuts the timeline at the LP boundaries (k_ns_zero_band = first kernel of the null-space set-up of an LP) and, inside an LP, at the interior-point
-iterations (k_ns_theta), and prints for the LAST LPs: per phase the wall span, the sum of kernel durations and the idle time (no kernel running on any
+iterations (k_ipm_theta_ns; k_ns_theta before the fusion), and prints for the LAST LPs: per phase the wall span, the sum of kernel durations and the idle time (no kernel running on any
 stream), plus the per-kernel busy / gap table of one LP.   usage: lp_timeline.py <prefix>_kernel_trace.csv [n_lps]"""
 import csv, collections, sys
 rows = []
@@ -20,7 +20,7 @@ for li in range(len(starts) - nl - 1, len(starts) - 1):
     seg = rows[starts[li]:starts[li + 1]]
     wall, busy = span_stats(seg)
     # phases: set-up = up to the first k_ns_theta, ipm = first theta .. last k_ns_update/k_ipm_steps region, rest = polish + SLP
-    th = [i for i, r in enumerate(seg) if r[2].startswith("k_ns_theta")]
+    th = [i for i, r in enumerate(seg) if (r[2].startswith("k_ns_theta") or r[2].startswith("k_ipm_theta_ns"))]
     if not th:
         print("LP %d: %.1f us wall (no null-space iterations)" % (li, wall)); continue
     last_upd = max(i for i, r in enumerate(seg) if r[2].startswith("k_ns_update"))
@@ -38,7 +38,7 @@ print("\nlast LP by kernel: calls, busy us, idle us in front of its launches")
 for n, d in sorted(agg.items(), key=lambda kv: -(kv[1][1] + kv[1][2]))[:45]:
     print("  %-60s %5d %9.1f %9.1f" % (n[:60], d[0], d[1], d[2]))
 # one interior-point iteration of the last LP, launch by launch
-th = [i for i, r in enumerate(seg) if r[2].startswith("k_ns_theta")]
+th = [i for i, r in enumerate(seg) if (r[2].startswith("k_ns_theta") or r[2].startswith("k_ipm_theta_ns"))]
 if len(th) > 6:
     it = seg[th[5]:th[6]]
     print("\none iteration (launch, duration us, gap to the previous end us):")
