@@ -1190,7 +1190,7 @@ __device__ __forceinline__ void chol_panel_body(double* __restrict__ sm, double*
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chol_panel(AsmBt abt, double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms, const double* __restrict__ diag0, double thr, double* __restrict__ Linv, unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch) {
     ASM_BARGS(abt, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch);
     __shared__ __attribute__((aligned(16))) double sm[ASM_PNL_LDS];
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(3);      // beside the trailing update: the chain's wavefronts win the issue slots of the SIMDs they share
     chol_panel_body<false, true, true>(sm, S, ldS, I0, I1, Ms, diag0, thr, Linv, flags, tmo, epoch, (int)gridDim.x, (int)blockIdx.x);
 }
 __global__ __launch_bounds__(256) void k_chol_panel_solo(AsmBt abt, double* __restrict__ S, int64_t ldS, int I0, int I1, int Ms, const double* __restrict__ diag0, double thr, double* __restrict__ Linv, unsigned* __restrict__ flags, unsigned* __restrict__ tmo, unsigned epoch) {
