@@ -1867,6 +1867,8 @@ struct Solver {
         hipLaunchKernelGGL(k_ipm_dir, dim3(g), dim3(256), 0, h->stream, P, D, d_tN);
     }
 
+    // accuracy bound of the reduced solves of a null-space iteration (ASM_NS_RERR: test knob - a tiny bound sends every LP through the fall-back to the row form)
+    static double ns_rerr() { static const double e = [] { const char* v = std::getenv("ASM_NS_RERR"); return v ? std::atof(v) : NS_RERR; }(); return e; }
     static int sig_exp() { static const int e = [] { const char* v = std::getenv("ASM_IPM_SIGEXP"); return v ? std::atoi(v) : 3; }(); return e; }      // (measurement knob)
     static double eta0() { static const double e = [] { const char* v = std::getenv("ASM_IPM_ETA0"); return v ? std::atof(v) : 0.995; }(); return e; }
     int btag = 100;      // alignment tags of a scenario batch grow in program order inside one LP (asm_batch.hip.h)
@@ -1883,7 +1885,7 @@ struct Solver {
             if (ns_pending) {
                 ns_pending = false;
                 if (h->verbose) std::fprintf(stderr, "[asm]     ap %.3e ad %.3e (null-space step, applied on the device)\n", h->h_scal[SC_AP], h->h_scal[SC_AD]);
-                if (h->h_scal[SC_NSERR] > NS_RERR) {
+                if (h->h_scal[SC_NSERR] > ns_rerr()) {
                     // the reduced system lost its accuracy and the device left the iterate alone: redo the iteration in row form
                     // (oracle: IPM.run) - measured again below as the row form measures it
                     ns_finish_y();
@@ -2035,12 +2037,12 @@ struct Solver {
             if (!(defer && solves(true))) solves(false);
             if (use_ns && ns_defer) {
                 const double eta = ip.mu >= 1.0 ? eta0() : std::min(std::max(eta0(), 1.0 - ip.mu / lp.scale_q), 0.999999);
-                hipLaunchKernelGGL(k_ns_update_dev, dim3(grid_all()), dim3(256), 0, h->stream, P, dirC, eta, nsv(14), h->ldn, NS_RERR);
+                hipLaunchKernelGGL(k_ns_update_dev, dim3(grid_all()), dim3(256), 0, h->stream, P, dirC, eta, nsv(14), h->ldn, ns_rerr());
                 ns_pending = true;
                 continue;
             }
             if (h->verbose) std::fprintf(stderr, "[asm]     ap %.3e ad %.3e  cg steps so far %lld\n", ap, ad, (long long)h->stats_pcg);
-            if (use_ns && h->h_scal[SC_NSERR] > NS_RERR) {
+            if (use_ns && h->h_scal[SC_NSERR] > ns_rerr()) {
                 ns_finish_y();
                 ip.ns_off = true;          // the reduced system lost its accuracy: redo the iteration in row form (oracle: IPM.run)
                 continue;
